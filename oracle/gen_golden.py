@@ -1,0 +1,265 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+TEST INFRASTRUCTURE ONLY; container-only (needs /root/reference, which never
+travels).  Usage:  python -m oracle.gen_golden  [--only NAME]
+
+What is recorded: for seeded synthetic scenes the inputs
+(fp32-representable points, counts, dt) and, per frame, the reference's
+association vector, DBSCAN labels, track list (every float field of every
+track), ring lengths and `format_single_frame` feature tensors; plus
+`normalize_data` in/out pairs, `apply_DBscan` labels at sizes that cross the
+BallTree node-count thresholds, and the `OfflineManager` frame sequence on a
+synthetic 2-shard CSV (captures the 40th-frame truncation quirk).
+
+Environment of the recorded run is stored in every file (`meta`): numpy /
+scikit-learn / scipy versions (the reference pins numpy 1.26.3, sklearn 1.3.2,
+filterpy 1.4.5; here: numpy 2.2.x, sklearn 1.7.x, filterpy = own shim).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from mmwave_msc_amd.synth import make_scene  # noqa: E402
+from oracle.c_oracle import TRACK_DTYPE  # noqa: E402
+from oracle.ref_import import have_reference, load_reference  # noqa: E402
+from oracle.ref_runner import RefScene  # noqa: E402
+
+GOLDEN_DIR = os.path.join(_ROOT, "tests", "golden")
+
+# name -> dict(seed, N, K, F, overrides, ragged, presence/dt builders, feat_every)
+SCENARIOS = {
+    "n60_k1": dict(seed=101, N=60, K=1, F=24, over={}),
+    "n200_k2": dict(seed=102, N=200, K=2, F=40, over={}),
+    "n256_k4": dict(seed=103, N=256, K=4, F=24, over={}),
+    "n256_k3_ragged": dict(seed=104, N=256, K=3, F=24, over={}, ragged=True),
+    "n512_k8": dict(seed=105, N=512, K=8, F=12, over={"TR_MAX_TRACKS": 8}),
+    "n512_k5": dict(seed=106, N=512, K=5, F=12, over={"TR_MAX_TRACKS": 8}),
+    "expiry": dict(seed=107, N=128, K=2, F=60, over={}, presence="gap"),
+    "var_dt": dict(seed=108, N=160, K=2, F=40, over={}, presence="flicker", dt="var"),
+    "const_vel": dict(seed=109, N=128, K=2, F=24, over={"MOTION_MODEL": "CONST_VEL_MODEL"}),
+    "dense_k1": dict(seed=110, N=512, K=1, F=10, over={}),
+    "clutter_only": dict(seed=111, N=400, K=0, F=5, over={}),
+    "fb0": dict(seed=112, N=128, K=2, F=16, over={"FB_FRAMES_BATCH": 0}),
+    "empty_frames": dict(seed=113, N=96, K=1, F=16, over={}, zero_frames=(3, 9)),
+}
+
+
+def _meta():
+    import sklearn, scipy  # noqa: E401
+    return json.dumps({
+        "numpy": np.__version__, "sklearn": sklearn.__version__, "scipy": scipy.__version__,
+        "filterpy": "own shim (oracle/filterpy_shim), filterpy 1.4.5 absent from image",
+        "reference": "AsteriosPar/mmWave_MSc @ /root/reference/src (Tracking.py, Utils.py, constants.py)",
+    })
+
+
+def _presence(kind, f, k):
+    if kind is None:
+        return None
+    p = np.ones((f, k), dtype=bool)
+    if kind == "gap":  # both targets vanish for > 3 s, then come back
+        p[10:48, :] = False
+    elif kind == "flicker":
+        p[8:12, 0] = False
+        p[20:30, 1] = False
+    return p
+
+
+def gen_scenario(name, sc):
+    f, n, k = sc["F"], sc["N"], sc["K"]
+    rng = np.random.default_rng(sc["seed"] + 7000)
+    dt_seq = None
+    if sc.get("dt") == "var":
+        dt_seq = np.round(rng.uniform(0.05, 0.3, size=f), 3)
+    pts, cnt, dt = make_scene(sc["seed"], f, n, k, ragged=sc.get("ragged", False),
+                              presence=_presence(sc.get("presence"), f, k), dt_seq=dt_seq)
+    for zf in sc.get("zero_frames", ()):
+        cnt[zf] = 0
+        pts[zf] = 0
+    over = dict(sc["over"])
+    const, _, _ = load_reference()
+    if "MOTION_MODEL" in over:
+        over["MOTION_MODEL"] = getattr(const, over["MOTION_MODEL"])
+    ref = RefScene(over)
+    ring = ref.const.FB_FRAMES_BATCH + 1
+    tmax = 0
+    rec = dict(assoc=np.full((f, n), -2, np.int16), db_n=np.full(f, -1, np.int32),
+               labels=np.full((f, ring * n), -2, np.int16), n_tracks=np.zeros(f, np.int32),
+               ring_len=np.zeros(f, np.int32), ring_n=np.zeros((f, 4), np.int32))
+    tracks, feats, owners = [], [], []
+    for i in range(f):
+        if cnt[i] == 0:
+            # offline_main.py:56 skips track()/estimate_posture() for empty frames
+            rec["n_tracks"][i] = ref.n_tracks
+            rec["ring_len"][i] = len(ref.batch_ring())
+            rec["ring_n"][i, : rec["ring_len"][i]] = ref.batch_ring()
+            tracks.append(ref.tracks())
+            feats.append(None)
+            owners.append(None)
+            continue
+        a, lab = ref.track(pts[i, : cnt[i]].astype(np.float64), float(dt[i]))
+        rec["assoc"][i, : cnt[i]] = a
+        if lab is not None:
+            rec["db_n"][i] = len(lab)
+            rec["labels"][i, : len(lab)] = lab
+        rec["n_tracks"][i] = ref.n_tracks
+        br = ref.batch_ring()
+        rec["ring_len"][i] = len(br)
+        rec["ring_n"][i, : len(br)] = br
+        tracks.append(ref.tracks())
+        fe, ow = ref.features()
+        feats.append(fe)
+        owners.append(ow)
+        tmax = max(tmax, ref.n_tracks)
+    ref.close()
+    tmax = max(tmax, 1)
+    trk = np.zeros((f, tmax), dtype=TRACK_DTYPE)
+    fshape = (3, 8, 8, 5) if ring > 1 else (8, 8, 5)
+    if ring > 1:
+        fshape = (ring, 8, 8, 5)
+    feat = np.zeros((f, tmax) + fshape, np.float32)
+    n_feat = np.full(f, -1, np.int32)
+    owner = np.full((f, tmax), -1, np.int32)
+    for i in range(f):
+        trk[i, : len(tracks[i])] = tracks[i]
+        if feats[i] is not None:
+            n_feat[i] = len(owners[i])
+            if len(owners[i]):
+                feat[i, : len(owners[i])] = feats[i]
+                owner[i, : len(owners[i])] = owners[i]
+    over_json = {k2: (v.__name__ if hasattr(v, "__name__") else v) for k2, v in over.items()}
+    np.savez_compressed(
+        os.path.join(GOLDEN_DIR, f"track_{name}.npz"), pts=pts, cnt=cnt, dt=dt, tracks=trk,
+        feat=feat, n_feat=n_feat, owner=owner, overrides=json.dumps(over_json), meta=_meta(), **rec)
+    print(f"  {name}: F={f} N={n} K={k} tracks(max)={tmax} dbscan_frames={(rec['db_n'] >= 0).sum()}")
+
+
+def gen_normalize():
+    const, utils, _ = load_reference()
+    rng = np.random.default_rng(2024)
+    n = 300
+    raw = np.zeros((n, 5))
+    raw[:, 0] = rng.uniform(-4, 4, n)
+    raw[:, 1] = rng.uniform(-1, 9, n)
+    raw[:, 2] = rng.uniform(-3, 2, n)
+    raw[:, 3] = rng.normal(0, 0.6, n)
+    raw[:, 4] = rng.integers(0, 400, n)
+    raw[0, :3] = 0.0          # r == 0 branch (Utils.py:387-390)
+    raw[1, 2] = (2.5 - const.S_HEIGHT)  # near the z <= 2.5 edge
+    raw = raw.astype(np.float32).astype(np.float64)
+    det = {"x": list(raw[:, 0]), "y": list(raw[:, 1]), "z": list(raw[:, 2]),
+           "doppler": list(raw[:, 3]), "peakVal": list(raw[:, 4])}
+    out = utils.normalize_data(det)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "normalize.npz"), raw=raw, out=out,
+                        s_height=const.S_HEIGHT, s_tilt=const.S_TILT, meta=_meta())
+    print(f"  normalize: {n} -> {out.shape[0]} rows")
+
+
+def gen_dbscan():
+    const, utils, _ = load_reference()
+    from sklearn.cluster import DBSCAN
+    sizes = [1, 2, 30, 60, 61, 120, 121, 240, 241, 480, 481, 700, 961, 1536]
+    data = {}
+    for n in sizes:
+        k = max(1, min(8, n // 60))
+        f = 3 if n >= 90 else 1
+        per = -(-n // f)
+        pts, _, _ = make_scene(5000 + n, f, per, k)
+        x = pts.reshape(-1, 8)[:n].astype(np.float64)
+        for ms in (35, 8):
+            lab = DBSCAN(eps=const.DB_EPS, min_samples=ms, metric=utils.altered_EuclideanDist).fit_predict(x)
+            data[f"labels_{n}_{ms}"] = lab.astype(np.int16)
+        data[f"pts_{n}"] = x.astype(np.float32)
+        # apply_DBscan cluster lists (row order kept): store sizes only, rows follow from labels
+        cl = utils.apply_DBscan(x)
+        data[f"sizes_{n}"] = np.array([len(c) for c in cl], dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "dbscan.npz"), sizes=np.array(sizes), meta=_meta(), **data)
+    print(f"  dbscan: sizes {sizes}")
+
+
+def gen_offline():
+    """OfflineManager + offline_main dt logic (Utils.py:53-177, offline_main.py:40-62).
+    offline_main.py itself cannot be imported (PyQt5/keras); its loop is 12 lines and
+    is replayed here against the REAL OfflineManager/normalize_data/TrackBuffer."""
+    const, utils, tracking = load_reference()
+    rng = np.random.default_rng(77)
+    n_frames, per_shard = 130, const.FB_EXPERIMENT_FILE_SIZE
+    pts, cnt, _ = make_scene(909, n_frames, 48, 1)
+    rows = []
+    t_ms = 1_700_000_000_000
+    for fr in range(1, n_frames + 1):
+        t_ms += int(rng.integers(90, 115))
+        m = int(rng.integers(20, 48))
+        for r in range(m):
+            p = pts[fr - 1, r]
+            # raw sensor frame: undo the height so normalize_data keeps most rows
+            rows.append((fr, float(p[0]), float(p[1]), float(p[2]) - 1.5, float(p[6]), int(p[7]), t_ms))
+    shards = {1: [r for r in rows if r[0] <= 100], 2: [r for r in rows if r[0] > 100]}
+    csv_text = {}
+    with tempfile.TemporaryDirectory() as d:
+        for k, rr in shards.items():
+            txt = "".join(f"{a},{b!r},{c!r},{e!r},{g!r},{h},{i}\n" for (a, b, c, e, g, h, i) in rr)
+            csv_text[k] = txt
+            with open(os.path.join(d, f"{k}.csv"), "w") as fh:
+                fh.write(txt)
+        man = utils.OfflineManager(d)
+        seq = []  # (ok, frame_count, n_points, posix0)
+        tb, batch = tracking.TrackBuffer(), tracking.BatchedData()
+        first = True
+        ntr, dts, nnorm = [], [], []
+        while not man.is_finished():
+            ok, fc, det = man.get_data()
+            if ok:
+                seq.append((1, fc, len(det["x"]), det["posix"][0]))
+                if first:
+                    tb.dt = 0.1
+                    first = False
+                else:
+                    tb.dt = det["posix"][0] / 1000 - tb.t
+                tb.t = det["posix"][0] / 1000
+                eff = utils.normalize_data(det)
+                if eff.shape[0] != 0:
+                    tb.track(eff, batch)
+                ntr.append(len(tb.effective_tracks)); dts.append(tb.dt); nnorm.append(eff.shape[0])
+            else:
+                seq.append((0, fc, 0, 0))
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "offline.npz"), csv1=csv_text[1], csv2=csv_text[2],
+                        seq=np.array(seq, dtype=np.int64), n_tracks=np.array(ntr, np.int32),
+                        dt=np.array(dts), n_norm=np.array(nnorm, np.int32), meta=_meta())
+    print(f"  offline: {len(seq)} get_data() calls, {sum(s[0] for s in seq)} frames delivered, "
+          f"1-point frames at {[s[1] for s in seq if s[0] and s[2] == 1]}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    if not have_reference():
+        print("reference not present: nothing generated")
+        return 0
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    for name, sc in SCENARIOS.items():
+        if args.only and args.only != name:
+            continue
+        gen_scenario(name, sc)
+    if not args.only or args.only == "normalize":
+        gen_normalize()
+    if not args.only or args.only == "dbscan":
+        gen_dbscan()
+    if not args.only or args.only == "offline":
+        gen_offline()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,81 @@
+"""Pin the CPU oracle (oracle/c) against the golden vectors recorded from the
+reference (oracle/gen_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_scenario, overrides_to_cfg_kwargs,
+                           scenario_names)
+
+import os
+
+
+@pytest.mark.parametrize("name", scenario_names())
+def test_tracker_matches_reference_golden(name):
+    g = load_scenario(name)
+    cfg = co.default_config(**overrides_to_cfg_kwargs(g["overrides"]))
+    n = g["pts"].shape[1]
+    sc = co.OracleScene(cfg, n)
+    ring = cfg.fb_frames_batch + 1
+    for f in range(g["pts"].shape[0]):
+        c = int(g["cnt"][f])
+        if c == 0:  # offline_main.py:56: empty frames never reach track()
+            continue
+        assoc, labels = sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
+        assert np.array_equal(assoc, g["assoc"][f, :c]), f"{name} f{f}: association differs"
+        dbn = int(g["db_n"][f])
+        if dbn < 0:
+            assert labels is None, f"{name} f{f}: DBSCAN ran but reference did not"
+        else:
+            assert labels is not None and len(labels) == dbn
+            assert np.array_equal(labels, g["labels"][f, :dbn]), f"{name} f{f}: DBSCAN labels differ"
+        nt = int(g["n_tracks"][f])
+        assert sc.n_tracks == nt
+        assert_tracks_match(sc.tracks(), g["tracks"][f, :nt], ctx=f"{name} f{f}")
+        br = sc.batch_ring()
+        assert len(br) == g["ring_len"][f] and np.array_equal(br, g["ring_n"][f, : len(br)])
+        feat, owner = sc.features()
+        nf = int(g["n_feat"][f])
+        assert len(owner) == nf and np.array_equal(owner, g["owner"][f, :nf])
+        if nf:
+            assert_feat_equal(feat, g["feat"][f, :nf], ctx=f"{name} f{f}")
+    assert ring >= 1
+
+
+def test_normalize_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "normalize.npz"))
+    cfg = co.default_config(s_height=float(z["s_height"]), s_tilt=float(z["s_tilt"]))
+    out = co.normalize(cfg, z["raw"])
+    assert out.shape == z["out"].shape
+    assert np.allclose(out, z["out"], rtol=0, atol=1e-12)
+    # pass-through columns are exact
+    assert np.array_equal(out[:, [0, 6, 7]], z["out"][:, [0, 6, 7]])
+
+
+def test_dbscan_matches_sklearn_golden():
+    z = np.load(os.path.join(GOLDEN, "dbscan.npz"))
+    cfg = co.default_config()
+    for n in z["sizes"]:
+        pts = z[f"pts_{n}"].astype(np.float64)
+        for ms in (35, 8):
+            lab = co.dbscan(cfg, pts, min_samples=ms)
+            assert np.array_equal(lab, z[f"labels_{n}_{ms}"]), f"n={n} min_samples={ms}"
+        lab = co.dbscan(cfg, pts)
+        sizes = np.array([(lab == k).sum() for k in range(lab.max() + 1)], dtype=np.int32)
+        assert np.array_equal(sizes, z[f"sizes_{n}"])
+
+
+def test_log_and_pairwise_sum_helpers():
+    import math
+
+    rng = np.random.default_rng(5)
+    L = co.lib()
+    xs = np.concatenate([rng.uniform(1e-300, 1e300, 2000), rng.uniform(0.5, 2.0, 4000), 10.0 ** rng.uniform(-20, 20, 4000)])
+    for x in xs:
+        got, want = L.orc_log(float(x)), math.log(float(x))
+        assert abs(got - want) <= 2.3e-16 * max(1.0, abs(want)), (x, got, want)
+    for n in [0, 1, 5, 7, 8, 9, 57, 64, 127, 128, 129, 200, 256, 257, 460, 1000, 1536]:
+        a = rng.normal(size=max(n, 1))[:n]
+        got = L.orc_np_pairwise_sum(np.ascontiguousarray(a).ctypes.data_as(co.C.POINTER(co.C.c_double)), n)
+        want = float(np.add.reduce(a)) if n else 0.0
+        assert got == want, (n, got, want)
