@@ -1,0 +1,204 @@
+/*
+ * mmw.h -- C-ABI of libmmw_hip.so: the MI355X (gfx950) implementation of the
+ * per-frame point-cloud hot path of AsteriosPar/mmWave_MSc.
+ *
+ * The reference has no FFI for this path: it is plain Python
+ * (`TrackBuffer.track`, `TrackBuffer.estimate_posture`, `Utils.normalize_data`,
+ * `Utils.apply_DBscan`).  Each entry point below names the reference interface
+ * it replaces (file:line under the reference's src/); INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++/torch types.
+ *  - Every function returns 0 on success, <0 on error (MMW_E_*); never throws.
+ *    `mmw_last_error(ctx)` returns a message (ctx may be NULL for create errors).
+ *  - One context = S independent scenes (one reference TrackBuffer + global
+ *    BatchedData each) resident on ONE device.  A context is used from one host
+ *    thread at a time; calls are ordered on the context's HIP stream and are
+ *    asynchronous unless stated ("sync").
+ *  - "dev" pointers are device memory of the context's device (hipMalloc,
+ *    torch.Tensor.data_ptr(), or mmw_dev_alloc); "host" pointers are host memory.
+ *  - There is NO CPU fallback: creation fails if no gfx950-capable HIP device
+ *    is usable.
+ *  - Numerics: tracker state and every decision in fp64 (the reference's numpy
+ *    dtype), features in fp32 (what Keras feeds the CNN).
+ */
+#ifndef MMW_H
+#define MMW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMW_RING_MAX 4      /* FB_FRAMES_BATCH + 1 <= 4 */
+#define MMW_NKP 57          /* 19 joints x (x,y,z)  (preprocessing.py:377) */
+#define MMW_MAX_PTS_LIMIT 1024
+#define MMW_TRACK_CAP_LIMIT 64
+
+#define MMW_OK 0
+#define MMW_E_ARG (-1)        /* bad argument / size */
+#define MMW_E_SINGULAR (-2)   /* a 6x6 gate/innovation matrix was singular (numpy raises LinAlgError) */
+#define MMW_E_DIVZERO (-3)    /* (N_est-1)*N == 0 in _get_Rc (Python raises ZeroDivisionError) */
+#define MMW_E_CAPACITY (-4)   /* more tracks than track_cap */
+#define MMW_E_HIP (-5)        /* HIP runtime error */
+#define MMW_E_NODEVICE (-6)   /* no usable gfx950 device: the library has no CPU path */
+
+/* Mirrors constants.py 1:1 (line numbers = /root/reference/src/constants.py). */
+typedef struct mmw_config {
+    int32_t fb_frames_batch;        /* FB_FRAMES_BATCH :66  (ring length = +1) */
+    int32_t db_min_samples;         /* DB_MIN_SAMPLES_MIN :73 */
+    int32_t tr_max_tracks;          /* TR_MAX_TRACKS :85 */
+    int32_t kf_enable_est;          /* KF_ENABLE_EST :100 */
+    int32_t model_min_input;        /* MODEL_MIN_INPUT :111 */
+    int32_t dim_x;                  /* MOTION_MODEL :246 -> 9 CONST_ACC_MODEL (176-215), 6 CONST_VEL_MODEL (218-243) */
+    int32_t ring_rows;              /* rows stored per frame of a per-track ring; >=64 (format_single_frame reads [:64]) */
+    int32_t track_cap;              /* capacity of effective_tracks per scene; 0 = (TR_MAX_TRACKS-1)+ring*max_pts/min_samples+1, <=64 */
+    double db_z_weight;             /* DB_Z_WEIGHT :70 */
+    double db_range_weight;         /* DB_RANGE_WEIGHT :71 */
+    double db_eps;                  /* DB_EPS :72 */
+    double tr_lifetime_dynamic;     /* TR_LIFETIME_DYNAMIC :86 */
+    double tr_lifetime_static;      /* TR_LIFETIME_STATIC :87 */
+    double tr_vel_thres;            /* TR_VEL_THRES :88 */
+    double tr_gate;                 /* TR_GATE :89 */
+    double kf_q_std;                /* KF_Q_STD :93 (passed as var= to Q_discrete_white_noise :212) */
+    double kf_p_init;               /* KF_P_INIT :96 */
+    double kf_group_disp_est_init;  /* KF_GROUP_DISP_EST_INIT :97 */
+    double kf_a_n;                  /* KF_A_N :101 */
+    double kf_est_pointnum;         /* KF_EST_POINTNUM :102 */
+    double kf_spread_lim[6];        /* KF_SPREAD_LIM :103 */
+    double kf_a_spr;                /* KF_A_SPR :104 */
+    double intensity_mu;            /* INTENSITY_MU :108 */
+    double intensity_std;           /* INTENSITY_STD :109 */
+    double s_height;                /* S_HEIGHT :41 */
+    double tilt_cos;                /* cos(radians(S_TILT)) :42, Utils.py:315-323 */
+    double tilt_sin;                /* sin(radians(S_TILT)) */
+    float default_posture[MMW_NKP]; /* MODEL_DEFAULT_POSTURE :112-172 */
+} mmw_config;
+
+/* One entry of TrackBuffer.effective_tracks (Tracking.py:139-230), flattened:
+ * ClusterTrack.{state.x, state.P, cluster.*, spread_est, group_disp_est, N_est,
+ * lifetime, batch (lengths), keypoints}.  P is stored 9x9 row-major (the
+ * leading 6x6 block is used for CONST_VEL_MODEL). */
+typedef struct mmw_track_record {
+    double x[9];
+    double P[81];
+    double centroid[6];
+    double min_vals[6];
+    double max_vals[6];
+    double spread_est[6];
+    double group_disp_est[36];
+    double n_est;
+    double lifetime;
+    int32_t point_num;
+    int32_t is_static;              /* cluster.status: STATIC=True (Tracking.py:17,132-136) */
+    int32_t ring_len;               /* len(track.batch.buffer) */
+    int32_t ring_n[MMW_RING_MAX];   /* rows per frame, oldest first */
+    float keypoints[MMW_NKP];
+} mmw_track_record;
+
+/* Fixed-size per-track summary exchanged between GPUs. */
+typedef struct mmw_track_summary {
+    int32_t scene;      /* global scene id (scene_base + local index) */
+    int32_t slot;       /* position in effective_tracks */
+    int32_t alive;      /* 1 if slot < n_tracks */
+    int32_t is_static;
+    int32_t point_num;
+    float lifetime;
+    float x[9];
+    float centroid[6];
+    float keypoints[MMW_NKP];
+} mmw_track_summary;
+
+typedef struct mmw_ctx mmw_ctx;
+
+/* constants.py defaults. */
+int mmw_config_default(mmw_config *cfg);
+
+/* TrackBuffer() + BatchedData() for `n_scenes` scenes (Tracking.py:504-511, 38-41;
+ * offline_main.py:32-34).  max_pts = largest point count of one frame. */
+int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t device, mmw_ctx **out);
+int mmw_destroy(mmw_ctx *ctx);
+const char *mmw_last_error(const mmw_ctx *ctx);
+/* Fresh TrackBuffer/BatchedData for every scene. */
+int mmw_reset(mmw_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = context's own. */
+int mmw_set_stream(mmw_ctx *ctx, void *hip_stream);
+int mmw_synchronize(mmw_ctx *ctx);                                   /* sync */
+int mmw_get_dims(const mmw_ctx *ctx, int32_t *n_scenes, int32_t *max_pts, int32_t *track_cap, int32_t *ring, int32_t *ring_rows);
+
+/* Thin device-memory helpers so a ctypes host needs no HIP binding. */
+int mmw_dev_alloc(mmw_ctx *ctx, size_t bytes, void **dptr);
+int mmw_dev_free(mmw_ctx *ctx, void *dptr);
+int mmw_memcpy_h2d(mmw_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* stream-ordered, sync on return */
+int mmw_memcpy_d2h(mmw_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* sync */
+
+/* Utils.normalize_data + point_transform_to_standard_axis (Utils.py:294-434):
+ * raw[S][max_pts][5] = (x,y,z,doppler,peakVal) -> pts[S][max_pts][8], kept rows
+ * compacted in input order; n_out[S].  All dev pointers. */
+int mmw_normalize(mmw_ctx *ctx, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out);
+
+/* TrackBuffer.track(pointcloud, batch) for every scene (Tracking.py:664-703):
+ *   pts[S][max_pts][8] fp64 (x,y,z,vx,vy,vz,doppler,peakVal), n_pts[S], dt[S] (= trackbuffer.dt).
+ *   A scene with n_pts[s] == 0 is skipped entirely (offline_main.py:56).
+ * Outputs (dev, each may be NULL):
+ *   assoc[S][max_pts]      _calc_dist_fun result: -1 = None, else index into the
+ *                          track list as it was BEFORE _maintain_tracks (Tracking.py:530-574)
+ *   db_labels[S][ring*max_pts], db_n[S]   sklearn labels of apply_DBscan on the global
+ *                          ring (Utils.py:272-278); db_n = -1 when it was not called. */
+int mmw_step(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double *dt,
+             int32_t *assoc, int32_t *db_labels, int32_t *db_n);
+/* Same with host pointers (H2D, step, D2H; sync). */
+int mmw_step_host(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double *dt,
+                  int32_t *assoc, int32_t *db_labels, int32_t *db_n);
+
+/* Utils.apply_DBscan (Utils.py:250-291) on arbitrary clouds: pts[S][max_n][8], n[S]
+ * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts). */
+int mmw_dbscan(mmw_ctx *ctx, const double *pts, const int32_t *n, int32_t max_n, double eps,
+               int32_t min_samples, int32_t *labels, int32_t *n_clusters);
+
+/* Feature side of TrackBuffer.estimate_posture (Tracking.py:718-730) =
+ * relative_coordinates + format_single_frame (Utils.py:437-520) for every track of
+ * every scene with len(batch.effective_data) > MODEL_MIN_INPUT, compacted in
+ * (scene, track) order:
+ *   feat[cap_rows][ring][8][8][5] fp32 (dev; [cap_rows][8][8][5] when FB_FRAMES_BATCH == 0)
+ *   owner[cap_rows][2] int32 (dev) = (scene, track index)
+ *   *n_rows (host) = rows written (sync).  MMW_E_CAPACITY if cap_rows is too small. */
+int mmw_features(mmw_ctx *ctx, float *feat, int32_t *owner, int32_t cap_rows, int32_t *n_rows);
+/* track.keypoints = frame_keypoints[i] (Tracking.py:733-734): kp[n_rows][57] fp32 dev. */
+int mmw_set_keypoints(mmw_ctx *ctx, const float *kp, const int32_t *owner, int32_t n_rows);
+
+/* Read-back (sync; host pointers).  Also surfaces per-scene errors recorded by
+ * the kernels (returns the first one and sets the message). */
+int mmw_check(mmw_ctx *ctx);
+int mmw_get_num_tracks(mmw_ctx *ctx, int32_t *n_tracks /*[S]*/);
+int mmw_get_tracks(mmw_ctx *ctx, mmw_track_record *out /*[S][cap]*/, int32_t cap);
+int mmw_get_batch_ring(mmw_ctx *ctx, int32_t *ring_len /*[S]*/, int32_t *ring_n /*[S][MMW_RING_MAX]*/);
+/* rows of frame k (oldest first) of track t of scene s: out[ring_rows][8]; *n_rows = stored rows */
+int mmw_get_track_ring_frame(mmw_ctx *ctx, int32_t scene, int32_t track, int32_t k, double *out, int32_t *n_rows);
+int mmw_get_batch_ring_frame(mmw_ctx *ctx, int32_t scene, int32_t k, double *out /*[max_pts][8]*/, int32_t *n_rows);
+
+/* Per-scene track table for the multi-GPU all-gather:
+ * table[S][slots] (dev), scene ids offset by scene_base.  Async. */
+int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32_t scene_base);
+
+/* Kernel timing with hipEvents on the context's stream (bench.py roofline).
+ * ids: 0 track, 1 dbscan, 2 features, 3 normalize, 4 table. */
+#define MMW_K_TRACK 0
+#define MMW_K_DBSCAN 1
+#define MMW_K_FEATURES 2
+#define MMW_K_NORMALIZE 3
+#define MMW_K_TABLE 4
+#define MMW_K_COUNT 5
+int mmw_profile_enable(mmw_ctx *ctx, int32_t on);
+int mmw_profile_reset(mmw_ctx *ctx);
+int mmw_profile_get(mmw_ctx *ctx, int32_t kernel_id, double *total_ms, int64_t *launches);   /* sync */
+const char *mmw_kernel_name(int32_t kernel_id);
+const char *mmw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMW_H */

@@ -1,0 +1,161 @@
+"""ctypes binding of libmmw_hip.so (C-ABI declared in include/mmw.h).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be
+loaded, importing the compute path raises.  `build()` compiles it in-tree with
+hipcc for gfx950 (no GPU needed to compile).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmw_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+RING_MAX = 4
+NKP = 57
+
+MMW_OK = 0
+E_ARG, E_SINGULAR, E_DIVZERO, E_CAPACITY, E_HIP, E_NODEVICE = -1, -2, -3, -4, -5, -6
+K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE = range(5)
+
+EXPORTS = [
+    "mmw_config_default", "mmw_create", "mmw_destroy", "mmw_last_error", "mmw_reset", "mmw_set_stream",
+    "mmw_synchronize", "mmw_get_dims", "mmw_dev_alloc", "mmw_dev_free", "mmw_memcpy_h2d", "mmw_memcpy_d2h",
+    "mmw_normalize", "mmw_step", "mmw_step_host", "mmw_dbscan", "mmw_features", "mmw_set_keypoints", "mmw_check",
+    "mmw_get_num_tracks", "mmw_get_tracks", "mmw_get_batch_ring", "mmw_get_track_ring_frame",
+    "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
+    "mmw_kernel_name", "mmw_version",
+]
+
+
+class MmwConfig(C.Structure):
+    """struct mmw_config (include/mmw.h) -- mirrors the reference constants.py."""
+    _fields_ = [
+        ("fb_frames_batch", C.c_int32), ("db_min_samples", C.c_int32), ("tr_max_tracks", C.c_int32),
+        ("kf_enable_est", C.c_int32), ("model_min_input", C.c_int32), ("dim_x", C.c_int32),
+        ("ring_rows", C.c_int32), ("track_cap", C.c_int32),
+        ("db_z_weight", C.c_double), ("db_range_weight", C.c_double), ("db_eps", C.c_double),
+        ("tr_lifetime_dynamic", C.c_double), ("tr_lifetime_static", C.c_double), ("tr_vel_thres", C.c_double),
+        ("tr_gate", C.c_double), ("kf_q_std", C.c_double), ("kf_p_init", C.c_double),
+        ("kf_group_disp_est_init", C.c_double), ("kf_a_n", C.c_double), ("kf_est_pointnum", C.c_double),
+        ("kf_spread_lim", C.c_double * 6), ("kf_a_spr", C.c_double), ("intensity_mu", C.c_double),
+        ("intensity_std", C.c_double), ("s_height", C.c_double), ("tilt_cos", C.c_double), ("tilt_sin", C.c_double),
+        ("default_posture", C.c_float * NKP),
+    ]
+
+
+TRACK_DTYPE = np.dtype(
+    [
+        ("x", "f8", (9,)), ("P", "f8", (9, 9)), ("centroid", "f8", (6,)), ("min_vals", "f8", (6,)),
+        ("max_vals", "f8", (6,)), ("spread_est", "f8", (6,)), ("group_disp_est", "f8", (6, 6)),
+        ("n_est", "f8"), ("lifetime", "f8"), ("point_num", "i4"), ("is_static", "i4"), ("ring_len", "i4"),
+        ("ring_n", "i4", (RING_MAX,)), ("keypoints", "f4", (NKP,)),
+    ],
+    align=True,
+)
+SUMMARY_DTYPE = np.dtype(
+    [("scene", "i4"), ("slot", "i4"), ("alive", "i4"), ("is_static", "i4"), ("point_num", "i4"),
+     ("lifetime", "f4"), ("x", "f4", (9,)), ("centroid", "f4", (6,)), ("keypoints", "f4", (NKP,))],
+    align=True,
+)
+
+_lib = None
+
+
+class MmwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmmw_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmw.h"))
+    newest = max(os.path.getmtime(p) for p in srcs)
+    if force or not os.path.isfile(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load libmmw_hip.so and declare every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  mmwave_msc_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+    i32, i32p, i64p = C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    f64p = C.POINTER(C.c_double)
+    cfgp = C.POINTER(MmwConfig)
+    sig = {
+        "mmw_config_default": (C.c_int, [cfgp]),
+        "mmw_create": (C.c_int, [cfgp, i32, i32, i32, vpp]),
+        "mmw_destroy": (C.c_int, [vp]),
+        "mmw_last_error": (C.c_char_p, [vp]),
+        "mmw_reset": (C.c_int, [vp]),
+        "mmw_set_stream": (C.c_int, [vp, vp]),
+        "mmw_synchronize": (C.c_int, [vp]),
+        "mmw_get_dims": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p]),
+        "mmw_dev_alloc": (C.c_int, [vp, C.c_size_t, vpp]),
+        "mmw_dev_free": (C.c_int, [vp, vp]),
+        "mmw_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "mmw_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "mmw_normalize": (C.c_int, [vp, vp, vp, vp, vp]),
+        "mmw_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+        "mmw_step_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+        "mmw_dbscan": (C.c_int, [vp, vp, vp, i32, C.c_double, i32, vp, vp]),
+        "mmw_features": (C.c_int, [vp, vp, vp, i32, i32p]),
+        "mmw_set_keypoints": (C.c_int, [vp, vp, vp, i32]),
+        "mmw_check": (C.c_int, [vp]),
+        "mmw_get_num_tracks": (C.c_int, [vp, vp]),
+        "mmw_get_tracks": (C.c_int, [vp, vp, i32]),
+        "mmw_get_batch_ring": (C.c_int, [vp, vp, vp]),
+        "mmw_get_track_ring_frame": (C.c_int, [vp, i32, i32, i32, vp, i32p]),
+        "mmw_get_batch_ring_frame": (C.c_int, [vp, i32, i32, vp, i32p]),
+        "mmw_track_table": (C.c_int, [vp, vp, i32, i32]),
+        "mmw_profile_enable": (C.c_int, [vp, i32]),
+        "mmw_profile_reset": (C.c_int, [vp]),
+        "mmw_profile_get": (C.c_int, [vp, i32, f64p, i64p]),
+        "mmw_kernel_name": (C.c_char_p, [i32]),
+        "mmw_version": (C.c_char_p, []),
+    }
+    assert sorted(sig) == sorted(EXPORTS)
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def default_config(**overrides) -> MmwConfig:
+    cfg = MmwConfig()
+    load().mmw_config_default(C.byref(cfg))
+    apply_overrides(cfg, overrides)
+    return cfg
+
+
+def apply_overrides(cfg: MmwConfig, overrides: dict):
+    for k, v in overrides.items():
+        if k == "kf_spread_lim":
+            for i in range(6):
+                cfg.kf_spread_lim[i] = float(v[i])
+        elif k == "default_posture":
+            for i in range(NKP):
+                cfg.default_posture[i] = float(v[i])
+        elif k == "s_tilt":
+            ang = np.radians(v)  # Utils.py:315
+            cfg.tilt_cos, cfg.tilt_sin = float(np.cos(ang)), float(np.sin(ang))
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError(f"mmw_config has no field {k!r}")
+            setattr(cfg, k, v)
+    return cfg

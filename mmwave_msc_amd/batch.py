@@ -1,0 +1,244 @@
+"""SceneBatch: S independent scenes (S reference `TrackBuffer`s + their global
+`BatchedData`) resident on one MI355X, stepped together through the C-ABI.
+
+This is the batched face of the hot path; `tracking.TrackBuffer` is the
+single-scene, reference-shaped face built on top of it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MmwError, RING_MAX, NKP, SUMMARY_DTYPE, TRACK_DTYPE
+
+
+class DevBuf:
+    """A device allocation owned by a context (hipMalloc through the C-ABI)."""
+
+    def __init__(self, batch: "SceneBatch", nbytes: int):
+        self.batch, self.nbytes = batch, int(nbytes)
+        p = C.c_void_p()
+        batch._chk(batch.L.mmw_dev_alloc(batch.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes, (a.nbytes, self.nbytes)
+        self.batch._chk(self.batch.L.mmw_memcpy_h2d(self.batch.h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
+        self.batch._chk(self.batch.L.mmw_memcpy_d2h(self.batch.h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self.batch.h:
+            self.batch.L.mmw_dev_free(self.batch.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class SceneBatch:
+    def __init__(self, cfg: "_lib.MmwConfig | None" = None, n_scenes: int = 1, max_pts: int = 512, device: int = 0):
+        self.L = _lib.load()
+        self.cfg = cfg if cfg is not None else _lib.default_config()
+        self.h = None
+        h = C.c_void_p()
+        rc = self.L.mmw_create(C.byref(self.cfg), int(n_scenes), int(max_pts), int(device), C.byref(h))
+        if rc != 0:
+            raise MmwError(rc, (self.L.mmw_last_error(None) or b"").decode())
+        self.h = h
+        self.S, self.max_pts, self.device = int(n_scenes), int(max_pts), int(device)
+        dims = [C.c_int32() for _ in range(5)]
+        self._chk(self.L.mmw_get_dims(self.h, *[C.byref(d) for d in dims]))
+        self.track_cap, self.ring, self.ring_rows = dims[2].value, dims[3].value, dims[4].value
+        self.UM = self.ring * self.max_pts
+        self._bufs = {}
+
+    # -- plumbing -------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise MmwError(rc, (self.L.mmw_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            for b in list(self._bufs.values()):
+                b.free()
+            self._bufs.clear()
+            self.L.mmw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def buf(self, name: str, nbytes: int) -> DevBuf:
+        b = self._bufs.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = DevBuf(self, nbytes)
+            self._bufs[name] = b
+        return b
+
+    def alloc(self, nbytes: int) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.mmw_set_stream(self.h, stream_ptr))
+
+    def synchronize(self):
+        self._chk(self.L.mmw_synchronize(self.h))
+
+    def reset(self):
+        self._chk(self.L.mmw_reset(self.h))
+
+    def check(self):
+        self._chk(self.L.mmw_check(self.h))
+
+    # -- hot path -------------------------------------------------------------
+    def step_dev(self, pts_ptr, n_ptr, dt_ptr, assoc_ptr=None, labels_ptr=None, dbn_ptr=None):
+        """TrackBuffer.track for all scenes; every argument is a device pointer (int)."""
+        self._chk(self.L.mmw_step(self.h, pts_ptr, n_ptr, dt_ptr, assoc_ptr, labels_ptr, dbn_ptr))
+
+    def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray):
+        """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S])."""
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        assert pts.shape == (self.S, self.max_pts, 8) and n.shape == (self.S,) and dt.shape == (self.S,)
+        assoc = np.full((self.S, self.max_pts), -1, dtype=np.int32)
+        labels = np.full((self.S, self.UM), -1, dtype=np.int32)
+        dbn = np.full(self.S, -1, dtype=np.int32)
+        self._chk(self.L.mmw_step_host(self.h, pts.ctypes.data, n.ctypes.data, dt.ctypes.data,
+                                       assoc.ctypes.data, labels.ctypes.data, dbn.ctypes.data))
+        return assoc, labels, dbn
+
+    def normalize_host(self, raw: np.ndarray, n_raw: np.ndarray):
+        """Utils.normalize_data for all scenes: raw[S,NP,5] -> (pts[S,NP,8], n_out[S])."""
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        n_raw = np.ascontiguousarray(n_raw, dtype=np.int32)
+        assert raw.shape == (self.S, self.max_pts, 5)
+        b_raw = self.buf("norm_raw", raw.nbytes).upload(raw)
+        b_n = self.buf("norm_n", n_raw.nbytes).upload(n_raw)
+        b_out = self.buf("norm_out", self.S * self.max_pts * 64)
+        b_no = self.buf("norm_no", self.S * 4)
+        self._chk(self.L.mmw_normalize(self.h, b_raw.ptr, b_n.ptr, b_out.ptr, b_no.ptr))
+        n_out = b_no.download((self.S,), np.int32)
+        pts = b_out.download((self.S, self.max_pts, 8), np.float64)
+        for s in range(self.S):
+            pts[s, n_out[s]:] = 0.0
+        return pts, n_out
+
+    def dbscan_host(self, pts: np.ndarray, n: np.ndarray, eps=None, min_samples=None):
+        """Utils.apply_DBscan labels for S clouds: pts[S,max_n,8] -> (labels[S,max_n], n_clusters[S])."""
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        max_n = pts.shape[1]
+        assert pts.shape == (self.S, max_n, 8)
+        b_p = self.buf("db_pts", pts.nbytes).upload(pts)
+        b_n = self.buf("db_n", n.nbytes).upload(n)
+        b_l = self.buf("db_lab", self.S * max_n * 4)
+        b_c = self.buf("db_ncl", self.S * 4)
+        self._chk(self.L.mmw_dbscan(self.h, b_p.ptr, b_n.ptr, max_n,
+                                    self.cfg.db_eps if eps is None else float(eps),
+                                    self.cfg.db_min_samples if min_samples is None else int(min_samples),
+                                    b_l.ptr, b_c.ptr))
+        labels = b_l.download((self.S, max_n), np.int32)
+        ncl = b_c.download((self.S,), np.int32)
+        for s in range(self.S):
+            labels[s, n[s]:] = -1
+        return labels, ncl
+
+    def features_dev(self, feat_ptr, owner_ptr, cap_rows: int) -> int:
+        nrows = C.c_int32(0)
+        self._chk(self.L.mmw_features(self.h, feat_ptr, owner_ptr, int(cap_rows), C.byref(nrows)))
+        return nrows.value
+
+    def features_host(self, cap_rows=None):
+        """Returns (feat[B,ring,8,8,5] float32 (or [B,8,8,5] when ring == 1), owner[B,2])."""
+        cap = int(cap_rows if cap_rows is not None else self.S * self.track_cap)
+        per = self.ring * 64 * 5
+        b_f = self.buf("feat", max(cap, 1) * per * 4)
+        b_o = self.buf("owner", max(cap, 1) * 8)
+        nrows = self.features_dev(b_f.ptr, b_o.ptr, cap)
+        shape = (nrows, self.ring, 8, 8, 5) if self.ring > 1 else (nrows, 8, 8, 5)
+        if nrows == 0:
+            return np.zeros(shape, np.float32), np.zeros((0, 2), np.int32)
+        feat = b_f.download((nrows, per), np.float32).reshape(shape)
+        owner = b_o.download((nrows, 2), np.int32)
+        return feat, owner
+
+    def set_keypoints_dev(self, kp_ptr, owner_ptr, n_rows: int):
+        self._chk(self.L.mmw_set_keypoints(self.h, kp_ptr, owner_ptr, int(n_rows)))
+
+    def set_keypoints_host(self, kp: np.ndarray, owner: np.ndarray):
+        kp = np.ascontiguousarray(kp, dtype=np.float32).reshape(-1, NKP)
+        owner = np.ascontiguousarray(owner, dtype=np.int32).reshape(-1, 2)
+        if len(owner) == 0:
+            return
+        b_k = self.buf("kp", kp.nbytes).upload(kp)
+        b_o = self.buf("kp_owner", owner.nbytes).upload(owner)
+        self.set_keypoints_dev(b_k.ptr, b_o.ptr, len(owner))
+
+    # -- read-back ------------------------------------------------------------
+    def num_tracks(self) -> np.ndarray:
+        out = np.zeros(self.S, dtype=np.int32)
+        self._chk(self.L.mmw_get_num_tracks(self.h, out.ctypes.data))
+        return out
+
+    def tracks(self, cap=None) -> np.ndarray:
+        """effective_tracks of every scene as a structured array [S, cap] (zero past n_tracks)."""
+        cap = int(cap if cap is not None else self.track_cap)
+        out = np.zeros((self.S, cap), dtype=TRACK_DTYPE)
+        self._chk(self.L.mmw_get_tracks(self.h, out.ctypes.data, cap))
+        return out
+
+    def batch_ring(self):
+        ln = np.zeros(self.S, dtype=np.int32)
+        rn = np.zeros((self.S, RING_MAX), dtype=np.int32)
+        self._chk(self.L.mmw_get_batch_ring(self.h, ln.ctypes.data, rn.ctypes.data))
+        return ln, rn
+
+    def track_ring_frame(self, scene: int, track: int, k: int) -> np.ndarray:
+        out = np.zeros((self.ring_rows, 8))
+        n = C.c_int32(0)
+        self._chk(self.L.mmw_get_track_ring_frame(self.h, scene, track, k, out.ctypes.data, C.byref(n)))
+        return out[: n.value].copy()
+
+    def batch_ring_frame(self, scene: int, k: int) -> np.ndarray:
+        out = np.zeros((self.max_pts, 8))
+        n = C.c_int32(0)
+        self._chk(self.L.mmw_get_batch_ring_frame(self.h, scene, k, out.ctypes.data, C.byref(n)))
+        return out[: n.value].copy()
+
+    def track_table_dev(self, table_ptr, slots: int, scene_base: int = 0):
+        self._chk(self.L.mmw_track_table(self.h, table_ptr, int(slots), int(scene_base)))
+
+    def track_table_host(self, slots: int, scene_base: int = 0) -> np.ndarray:
+        b = self.buf("table", self.S * slots * SUMMARY_DTYPE.itemsize)
+        self.track_table_dev(b.ptr, slots, scene_base)
+        return b.download((self.S, slots), SUMMARY_DTYPE)
+
+    # -- profiling ------------------------------------------------------------
+    def profile(self, on: bool):
+        self._chk(self.L.mmw_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.L.mmw_profile_reset(self.h))
+
+    def profile_get(self, kid: int):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._chk(self.L.mmw_profile_get(self.h, kid, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

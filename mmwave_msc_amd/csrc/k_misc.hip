@@ -1,0 +1,269 @@
+// k_misc.hip -- the streaming kernels either side of the tracker:
+//   k_normalize   Utils.normalize_data (Utils.py:294-434)        HBM-bound, ordered compaction
+//   k_feat_scan   row offsets of the per-track feature tensors   (scene, track) order
+//   k_features    relative_coordinates + format_single_frame     (Utils.py:437-520), one wave per 64-row frame
+//   k_set_kp      track.keypoints = model output                 (Tracking.py:733-734)
+//   k_export      flatten effective_tracks for read-back
+//   k_table       fixed-size track summaries for the RCCL all-gather
+#include "mmw_device.hpp"
+#include "mmw_math.hpp"
+
+namespace mmw {
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const double *__restrict__ raw, const int32_t *__restrict__ n_raw,
+                                                   double *__restrict__ out, int32_t *__restrict__ n_out)
+{
+    __shared__ int wcnt[4];
+    __shared__ int base_s;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NP = cfg.max_pts;
+    const int n = min(max(n_raw[s], 0), NP);
+    const double *in = raw + (size_t)s * NP * 5;
+    double *dst = out + (size_t)s * NP * 8;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        bool keep = false;
+        double o[8];
+        if (i < n) {
+            const double x = in[i * 5], y = in[i * 5 + 1], z = in[i * 5 + 2], dop = in[i * 5 + 3], pk = in[i * 5 + 4];
+            const double r = sqrt((x * x + y * y) + z * z);
+            double vx, vy, vz;
+            if (r == 0) { vx = 0; vy = dop; vz = 0; }           // Utils.py:387-390
+            else { vx = dop * x / r; vy = dop * y / r; vz = dop * z / r; }
+            o[0] = x;                                            // T . R_inv . [x,y,z,1]  (Utils.py:312-328)
+            o[1] = cfg.tilt_cos * y + (-cfg.tilt_sin) * z;
+            o[2] = (cfg.tilt_sin * y + cfg.tilt_cos * z) + cfg.s_height;
+            o[3] = vx;
+            o[4] = cfg.tilt_cos * vy + (-cfg.tilt_sin) * vz;
+            o[5] = cfg.tilt_sin * vy + cfg.tilt_cos * vz;
+            o[6] = dop;
+            o[7] = pk;
+            keep = o[2] <= 2.5 && o[2] > 0 && o[1] > 0;          // Utils.py:423-427
+        }
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wcnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; w++) off += wcnt[w];
+        if (keep) {
+            double *d = dst + (size_t)(off + __popcll(b & lanemask_lt())) * 8;
+#pragma unroll
+            for (int q = 0; q < 8; q++) d[q] = o[q];
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) n_out[s] = base_s;
+}
+
+// ---------------------------------------------------------------------------
+__device__ inline int eligible_tracks(const DevCfg &cfg, const DevState &st, int s)
+{
+    const SceneHdr *hdr = st.hdr + s;
+    const int32_t *order = st.order + (size_t)s * cfg.t_cap;
+    const TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+    int c = 0;
+    for (int j = 0; j < hdr->n_tracks; j++) {
+        const TrackRec *rec = trk + order[j];
+        int total = 0;
+        for (int k = 0; k < rec->ring_len; k++) total += rec->ring_n[k];
+        c += total > cfg.model_min_input ? 1 : 0;  // Tracking.py:721
+    }
+    return c;
+}
+
+// single workgroup: exclusive scan of eligible-track counts over scenes
+__global__ __launch_bounds__(1024) void k_feat_scan(DevCfg cfg, DevState st, int32_t *__restrict__ row_off /*[S+1]*/)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, S = cfg.n_scenes;
+    const int per = (S + 1023) / 1024;
+    const int s0 = tid * per, s1 = min(S, s0 + per);
+    int sum = 0;
+    for (int s = s0; s < s1; s++) sum += eligible_tracks(cfg, st, s);
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int s = s0; s < s1; s++) { row_off[s] = run; run += eligible_tracks(cfg, st, s); }
+    if (tid == 1023) row_off[S] = part[1023];
+}
+
+// One wave per (eligible track, ring frame): lane r owns row r of the 64-row frame.
+__global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const int32_t *__restrict__ row_off,
+                                                  float *__restrict__ feat, int32_t *__restrict__ owner, int cap_rows)
+{
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SceneHdr *hdr = st.hdr + s;
+    const int32_t *order = st.order + (size_t)s * cfg.t_cap;
+    const TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+    const int T = hdr->n_tracks, ring = cfg.ring;
+    int row = row_off[s];
+    for (int j = 0; j < T; j++) {
+        const int slot = order[j];
+        const TrackRec *rec = trk + slot;
+        int total = 0;
+        for (int k = 0; k < rec->ring_len; k++) total += rec->ring_n[k];
+        if (!(total > cfg.model_min_input)) continue;
+        if (row >= cap_rows) return;
+        if (tid == 0) { owner[row * 2] = s; owner[row * 2 + 1] = j; }
+        const double cx = rec->centroid[0], cy = rec->centroid[1];
+        for (int k = wave; k < ring; k += 4) {
+            float *dst = feat + (((size_t)row * ring + k) * 64) * 5;
+            double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+            if (k < rec->ring_len) {
+                const int m = min(rec->ring_n[k], 64);
+                if (lane < m) {
+                    const double *p = st.trk_ring + ((((size_t)s * cfg.t_cap + slot) * ring + rec->ring_slot[k]) * cfg.ring_rows + lane) * 8;
+                    v0 = p[0] - cx;                                     // relative_coordinates Utils.py:455-463
+                    v1 = p[1] - cy;
+                    v2 = p[2] - 0;
+                    v3 = p[6] - 0;
+                    v4 = ((p[7] - 0) - cfg.intensity_mu) / cfg.intensity_std;  // Utils.py:502
+                }
+            }
+            // np.argsort(padded[:, 0]) (Utils.py:513): bitonic network over the wave on (x, row) --
+            // ties ordered by row position.
+            double key = v0;
+            int src = lane;
+            for (int sz = 2; sz <= 64; sz <<= 1) {
+                for (int stride = sz >> 1; stride > 0; stride >>= 1) {
+                    const double ok = __shfl_xor(key, stride);
+                    const int os = __shfl_xor(src, stride);
+                    const bool up = (lane & sz) == 0;          // ascending block
+                    const bool lower = (lane & stride) == 0;   // this lane keeps the smaller of the pair
+                    const bool other_less = ok < key || (ok == key && os < src);
+                    const bool take = (up == lower) ? other_less : !other_less;
+                    if (take) { key = ok; src = os; }
+                }
+            }
+            const double s0 = __shfl(v0, src), s1 = __shfl(v1, src), s2 = __shfl(v2, src), s3 = __shfl(v3, src), s4 = __shfl(v4, src);
+            dst[lane * 5 + 0] = (float)s0;
+            dst[lane * 5 + 1] = (float)s1;
+            dst[lane * 5 + 2] = (float)s2;
+            dst[lane * 5 + 3] = (float)s3;
+            dst[lane * 5 + 4] = (float)s4;
+        }
+        row++;
+    }
+}
+
+__global__ void k_set_kp(DevCfg cfg, DevState st, const float *__restrict__ kp, const int32_t *__restrict__ owner, int n_rows)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = g / 64, e = g % 64;
+    if (row >= n_rows || e >= MMW_NKP) return;
+    const int s = owner[row * 2], j = owner[row * 2 + 1];
+    if (s < 0 || s >= cfg.n_scenes) return;
+    const SceneHdr *hdr = st.hdr + s;
+    if (j < 0 || j >= hdr->n_tracks) return;
+    TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + st.order[(size_t)s * cfg.t_cap + j];
+    rec->kp[e] = kp[(size_t)row * MMW_NKP + e];
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_export(DevCfg cfg, DevState st, mmw_track_record *__restrict__ out, int cap)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = g / cap, j = g % cap;
+    if (s >= cfg.n_scenes) return;
+    mmw_track_record *o = out + (size_t)s * cap + j;
+    const SceneHdr *hdr = st.hdr + s;
+    if (j >= hdr->n_tracks) return;  // caller zero-fills
+    const TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + st.order[(size_t)s * cfg.t_cap + j];
+    for (int e = 0; e < 9; e++) o->x[e] = e < cfg.dx ? rec->x[e] : 0.0;
+    for (int e = 0; e < 81; e++) o->P[e] = (e / 9 < cfg.dx && e % 9 < cfg.dx) ? rec->P[e] : 0.0;
+    for (int e = 0; e < 6; e++) {
+        o->centroid[e] = rec->centroid[e];
+        o->min_vals[e] = rec->minv[e];
+        o->max_vals[e] = rec->maxv[e];
+        o->spread_est[e] = rec->spread[e];
+    }
+    for (int e = 0; e < 36; e++) o->group_disp_est[e] = rec->gd[e];
+    o->n_est = rec->n_est;
+    o->lifetime = rec->lifetime;
+    o->point_num = rec->point_num;
+    o->is_static = rec->is_static;
+    o->ring_len = rec->ring_len;
+    for (int k = 0; k < MMW_RING_MAX; k++) o->ring_n[k] = k < rec->ring_len ? rec->ring_n[k] : 0;
+    for (int e = 0; e < MMW_NKP; e++) o->keypoints[e] = rec->kp[e];
+}
+
+__global__ void k_table(DevCfg cfg, DevState st, mmw_track_summary *__restrict__ out, int slots, int scene_base)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = g / slots, j = g % slots;
+    if (s >= cfg.n_scenes) return;
+    mmw_track_summary *o = out + (size_t)s * slots + j;
+    const SceneHdr *hdr = st.hdr + s;
+    o->scene = scene_base + s;
+    o->slot = j;
+    const bool alive = j < hdr->n_tracks;
+    o->alive = alive ? 1 : 0;
+    const TrackRec *rec = alive ? st.trk + (size_t)s * cfg.t_cap + st.order[(size_t)s * cfg.t_cap + j] : nullptr;
+    o->is_static = alive ? rec->is_static : 0;
+    o->point_num = alive ? rec->point_num : 0;
+    o->lifetime = alive ? (float)rec->lifetime : 0.f;
+    for (int e = 0; e < 9; e++) o->x[e] = (alive && e < cfg.dx) ? (float)rec->x[e] : 0.f;
+    for (int e = 0; e < 6; e++) o->centroid[e] = alive ? (float)rec->centroid[e] : 0.f;
+    for (int e = 0; e < MMW_NKP; e++) o->keypoints[e] = alive ? rec->kp[e] : 0.f;
+}
+
+__global__ void k_reset(DevCfg cfg, DevState st)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < cfg.n_scenes) {
+        SceneHdr *h = st.hdr + g;
+        h->n_tracks = 0;
+        h->g_len = 1;  // BatchedData() starts with ONE empty frame (Utils.py:35-41, Tracking.py:38-41)
+        for (int k = 0; k < MMW_RING_MAX; k++) { h->g_n[k] = 0; h->g_slot[k] = k; }
+        h->need_db = 0;
+        h->err = 0;
+        h->db_u = 0;
+    }
+    const size_t tot = (size_t)cfg.n_scenes * cfg.t_cap;
+    for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);
+}
+
+void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_normalize, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, raw, n_raw, out, n_out);
+}
+void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cfg, s, row_off);
+}
+void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_features, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, s, row_off, feat, owner, cap);
+}
+void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st)
+{
+    if (n_rows <= 0) return;
+    hipLaunchKernelGGL(k_set_kp, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, st, cfg, s, kp, owner, n_rows);
+}
+void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st)
+{
+    const int tot = cfg.n_scenes * cap;
+    hipLaunchKernelGGL(k_export, dim3((tot + 127) / 128), dim3(128), 0, st, cfg, s, out, cap);
+}
+void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st)
+{
+    const int tot = cfg.n_scenes * slots;
+    hipLaunchKernelGGL(k_table, dim3((tot + 127) / 128), dim3(128), 0, st, cfg, s, out, slots, base);
+}
+void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reset, dim3((cfg.n_scenes + 255) / 256 > 0 ? (cfg.n_scenes + 255) / 256 : 1), dim3(256), 0, st, cfg, s);
+}
+
+}  // namespace mmw

@@ -1,0 +1,612 @@
+// k_track.hip -- one workgroup (256 threads = 4 wave64) per scene: everything of
+// TrackBuffer.track (Tracking.py:664-703) up to and including batch.add_frame(unassigned):
+//   _predict_all -> _calc_dist_fun gating/association -> associate_pointcloud estimators
+//   -> _maintain_tracks -> _update_all -> global ring append; raises need_db for k_dbscan.
+//
+// Data movement per scene-frame: the frame's points are read ONCE from HBM
+// (coalesced 8-B lanes over the row-major [n][8] block) and transposed into an
+// LDS SoA tile (6 columns); track records (1.5 KB each) live in HBM/L2 and are
+// staged through per-wave LDS scratch for the 9x9 algebra.  All arithmetic fp64
+// with a fixed operation order (see mmw_math.hpp) -- the order is the one the
+// parity oracle restates from the reference.
+#include "mmw_device.hpp"
+#include "mmw_math.hpp"
+
+namespace mmw {
+
+struct TrackLds {
+    double *p6;      // [6][NP] point columns x,y,z,vx,vy,vz
+    double *gate;    // [kGateChunk][72]  (gating: Ci[36], logdet, hx[6]; update: SI[36], Rc[36])
+    double *wsc;     // [kWaves][288] per-wave scratch
+    double *cen;     // [t_cap][6] centroid of this frame's cloud per track
+    int *assoc;      // [NP]
+    int *perm;       // [NP] point indices grouped by class (0 = unassigned, j+1 = track j), input order kept
+    int *cnt;        // [NB][CLS]
+    int *cls_n;      // [CLS]
+    int *cls_off;    // [CLS+1]
+    int *slot;       // [t_cap]
+    int *slot2;      // [t_cap]
+    int *misc;       // [16]
+};
+
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
+{
+    const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
+    size_t off = 0;
+#define CARVE(field, type, count)                      \
+    if (L) L->field = (type *)(base + off);            \
+    off = align16(off + sizeof(type) * (size_t)(count));
+    CARVE(p6, double, 6 * NP)
+    CARVE(gate, double, kGateChunk * 72)
+    CARVE(wsc, double, kWaves * 288)
+    CARVE(cen, double, c.t_cap * 6)
+    CARVE(assoc, int, NP)
+    CARVE(perm, int, NP)
+    CARVE(cnt, int, NB *CLS)
+    CARVE(cls_n, int, CLS)
+    CARVE(cls_off, int, CLS + 1)
+    CARVE(slot, int, c.t_cap)
+    CARVE(slot2, int, c.t_cap)
+    CARVE(misc, int, 16)
+#undef CARVE
+    return off;
+}
+
+size_t track_lds_bytes(const DevCfg &c) { return track_lds_layout(c, nullptr, nullptr); }
+
+// CONST_ACC_MODEL.KF_F / CONST_VEL_MODEL.KF_F (constants.py:195-208, 227-237)
+__device__ inline double Fval(int i, int k, int dx, double dt, double h)
+{
+    if (i == k) return 1.0;
+    if (k == i + 3 && k < dx) return dt;
+    if (k == i + 6 && k < dx) return h;
+    return 0.0;
+}
+
+// numpy pairwise_sum_DOUBLE over elem(r), r in [0, n): the summation order of the
+// 1-D np.mean in ClusterTrack._get_D (Tracking.py:286).  `stk` is a per-thread LDS
+// stack (stride = blockDim) for the recursive halves (only used when n > 128).
+template <typename F>
+__device__ inline double np_pairwise_leaf(F elem, int off, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += elem(off + i);
+        return res;
+    }
+    double r0 = elem(off), r1 = elem(off + 1), r2 = elem(off + 2), r3 = elem(off + 3);
+    double r4 = elem(off + 4), r5 = elem(off + 5), r6 = elem(off + 6), r7 = elem(off + 7);
+    int i, lim = n - (n % 8);
+    for (i = 8; i < lim; i += 8) {
+        r0 += elem(off + i);
+        r1 += elem(off + i + 1);
+        r2 += elem(off + i + 2);
+        r3 += elem(off + i + 3);
+        r4 += elem(off + i + 4);
+        r5 += elem(off + i + 5);
+        r6 += elem(off + i + 6);
+        r7 += elem(off + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += elem(off + i);
+    return res;
+}
+
+template <typename F>
+__device__ inline double np_pairwise_sum(F elem, int n, double *stk, int stride)
+{
+    if (n <= 128) return np_pairwise_leaf(elem, 0, n);
+    // Iterative post-order walk of numpy's split tree.  Frame = (off, len) packed in
+    // an int pair kept in two small register arrays addressed through selects.
+    // Depth <= 5 for n <= 4096.
+    int foff[6], flen[6], fstate[6];
+    int d = 0;
+    foff[0] = 0; flen[0] = n; fstate[0] = 0;
+    double ret = 0.0;
+    while (d >= 0) {
+        int off = 0, len = 0, stt = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q == d) { off = foff[q]; len = flen[q]; stt = fstate[q]; }
+        if (len <= 128) {
+            ret = np_pairwise_leaf(elem, off, len);
+            d--;
+            continue;
+        }
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if (stt == 0) {  // descend left
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (q == d) fstate[q] = 1;
+                if (q == d + 1) { foff[q] = off; flen[q] = n2; fstate[q] = 0; }
+            }
+            d++;
+        } else if (stt == 1) {  // left done: stash, descend right
+            stk[d * stride] = ret;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (q == d) fstate[q] = 2;
+                if (q == d + 1) { foff[q] = off + n2; flen[q] = len - n2; fstate[q] = 0; }
+            }
+            d++;
+        } else {  // both done
+            ret = stk[d * stride] + ret;
+            d--;
+        }
+    }
+    return ret;
+}
+
+__global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+                                                    const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
+                                                    int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    TrackLds L;
+    track_lds_layout(cfg, lds_raw, &L);
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int NP = cfg.max_pts, dx = cfg.dx, CLS = cfg.t_cap + 1;
+    const int n = n_pts[s];
+    SceneHdr *hdr = st.hdr + s;
+    if (tid == 0 && db_n_out) db_n_out[s] = -1;
+    if (n <= 0 || n > NP) {  // offline_main.py:56: empty frames never reach track()
+        if (tid == 0) hdr->need_db = 0;
+        return;
+    }
+    const double dt = dt_all[s];
+    const double *pts = pts_all + (size_t)s * NP * 8;
+    int32_t *order = st.order + (size_t)s * cfg.t_cap;
+    TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+    int T = hdr->n_tracks;
+    int err = 0;
+
+    // ---- stage points: coalesced read of the row-major block, SoA in LDS ----
+    for (int e = tid; e < n * 8; e += kThreads) {
+        double v = pts[e];
+        int col = e & 7;
+        if (col < 6) L.p6[col * NP + (e >> 3)] = v;
+    }
+    for (int j = tid; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
+    __syncthreads();
+
+    // ---- _predict_all (Tracking.py:591-596; filterpy predict) ----
+    {
+        double *W = L.wsc + wave * 288;  // P[81] | A[81] | F[81] | x[9]
+        double *Pw = W, *Aw = W + 81, *Fw = W + 162, *xw = W + 243;
+        const int rounds = (T + kWaves - 1) / kWaves;
+        for (int r = 0; r < rounds; r++) {
+            const int j = r * kWaves + wave;
+            const bool act = j < T;
+            TrackRec *rec = act ? trk + L.slot[j] : nullptr;
+            double dtm = 0, h = 0;
+            if (act) {
+                dtm = rec->lifetime + dt;
+                h = 0.5 * (dtm * dtm);
+                for (int e = lane; e < 81; e += 64) {
+                    int i = e / 9, k = e % 9;
+                    Pw[e] = rec->P[e];
+                    Fw[e] = (i < dx && k < dx) ? Fval(i, k, dx, dtm, h) : 0.0;
+                }
+                if (lane < 9) xw[lane] = rec->x[lane];
+            }
+            __syncthreads();
+            if (act) {
+                for (int e = lane; e < 81; e += 64) {
+                    int i = e / 9, c = e % 9;
+                    if (i < dx && c < dx) {
+                        double a = Fw[i * 9] * Pw[c];
+                        for (int k = 1; k < dx; k++) a += Fw[i * 9 + k] * Pw[k * 9 + c];
+                        Aw[e] = a;
+                    }
+                }
+                if (lane < dx) {
+                    double a = Fw[lane * 9] * xw[0];
+                    for (int k = 1; k < dx; k++) a += Fw[lane * 9 + k] * xw[k];
+                    rec->x[lane] = a;
+                }
+            }
+            __syncthreads();
+            if (act) {
+                const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
+                for (int e = lane; e < 81; e += 64) {
+                    int i = e / 9, c = e % 9;
+                    if (i < dx && c < dx) {
+                        double b = Aw[i * 9] * Fw[c * 9];
+                        for (int k = 1; k < dx; k++) b += Aw[i * 9 + k] * Fw[c * 9 + k];
+                        double q = 0.0;
+                        if (i / 3 == c / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
+                            int qi = i % 3, qc = c % 3, sdeg = qi + qc;
+                            double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
+                                        : sdeg == 3 ? dtm : 1.0;
+                            q = base * cfg.kf_q_std;
+                        }
+                        rec->P[e] = b + q;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- _calc_dist_fun (Tracking.py:530-574) ----
+    double bestd[4];
+    int bestj[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { bestd[q] = 0.0; bestj[q] = -1; }
+    for (int c0 = 0; c0 < T; c0 += kGateChunk) {
+        const int tc = min(kGateChunk, T - c0);
+        // C_g = P[:6,:6] + diag((spread/2)^2) + group_disp_est   (Tracking.py:551)
+        for (int e = tid; e < tc * 36; e += kThreads) {
+            int jl = e / 36, a = (e % 36) / 6, b = e % 6;
+            const TrackRec *rec = trk + L.slot[c0 + jl];
+            double rm = 0.0;
+            if (a == b) { double hh = rec->spread[a] / 2; rm = hh * hh; }
+            L.gate[jl * 72 + a * 6 + b] = (rec->P[a * 9 + b] + rm) + rec->gd[a * 6 + b];
+        }
+        __syncthreads();
+        if (tid < tc) {
+            const TrackRec *rec = trk + L.slot[c0 + tid];
+            double inv[36], det;
+            bool ok = lu6_inverse(L.gate + tid * 72, 6, inv, det);
+            if (!ok) err |= ERR_SINGULAR;
+#pragma unroll
+            for (int e = 0; e < 36; e++) L.gate[tid * 72 + e] = inv[e];
+            L.gate[tid * 72 + 36] = dlog(fabs(det));
+#pragma unroll
+            for (int a = 0; a < 6; a++) L.gate[tid * 72 + 37 + a] = rec->x[a];
+        }
+        __syncthreads();
+        for (int jl = 0; jl < tc; jl++) {
+            const double *G = L.gate + jl * 72;
+            double Ci[36];
+#pragma unroll
+            for (int e = 0; e < 36; e++) Ci[e] = G[e];
+            const double ld = G[36];
+            double hx[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) hx[a] = G[37 + a];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = q * kThreads + tid;
+                if (i < n) {
+                    double y[6];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) y[a] = L.p6[a * NP + i] - hx[a];
+                    double quad = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        double v = y[0] * Ci[k];
+#pragma unroll
+                        for (int a = 1; a < 6; a++) v += y[a] * Ci[a * 6 + k];
+                        if (k == 0) quad = v * y[0]; else quad += v * y[k];
+                    }
+                    const double d = ld + quad;
+                    if (d < cfg.tr_gate) {
+                        if (bestj[q] < 0 || d < bestd[q]) { bestj[q] = c0 + jl; bestd[q] = d; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
+    {
+        const int NB = (n + 63) / 64;
+        unsigned long long mybal[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = q * kThreads + tid;
+            const int blk = q * kWaves + wave;
+            mybal[q] = 0;
+            if (blk < NB) {  // wave-uniform
+                const int cls = (i < n) ? bestj[q] + 1 : -1;
+                if (i < n) {
+                    L.assoc[i] = bestj[q];
+                    if (assoc_out) assoc_out[(size_t)s * NP + i] = bestj[q];
+                }
+                for (int c = 0; c <= T; c++) {
+                    unsigned long long b = __ballot(cls == c);
+                    if (cls == c) mybal[q] = b;
+                    if (lane == 0) L.cnt[blk * CLS + c] = __popcll(b);
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c <= T; c += kThreads) {
+            int run = 0;
+            for (int b = 0; b < NB; b++) { int t = L.cnt[b * CLS + c]; L.cnt[b * CLS + c] = run; run += t; }
+            L.cls_n[c] = run;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int c = 0; c <= T; c++) { L.cls_off[c] = run; run += L.cls_n[c]; }
+            L.cls_off[T + 1] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = q * kThreads + tid;
+            if (i < n) {
+                const int cls = bestj[q] + 1, blk = q * kWaves + wave;
+                L.perm[L.cls_off[cls] + L.cnt[blk * CLS + cls] + __popcll(mybal[q] & lanemask_lt())] = i;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, ring bookkeeping,
+    //      N_est, spread_est; one lane per (track, dimension) ----
+    for (int task = tid; task < T * 6; task += kThreads) {
+        const int j = task / 6, m = task % 6;
+        TrackRec *rec = trk + L.slot[j];
+        const int nj = L.cls_n[j + 1], off = L.cls_off[j + 1];
+        if (nj == 0) {
+            if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
+            continue;
+        }
+        const double *col = L.p6 + m * NP;
+        double sum = 0.0, mn = col[L.perm[off]], mx = mn;
+        for (int r = 0; r < nj; r++) {  // np.mean(axis=0): sequential in row order
+            double v = col[L.perm[off + r]];
+            sum += v;
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+        const double cen = sum / (double)nj;
+        L.cen[j * 6 + m] = cen;
+        rec->centroid[m] = cen;
+        rec->minv[m] = mn;
+        rec->maxv[m] = mx;
+        // _estimate_measurement_spread Tracking.py:246-268
+        double spread = mx - mn;
+        const double lim = cfg.kf_spread_lim[m], lim2 = 2 * lim;
+        if (nj != 1) spread = spread * (double)(nj + 1) / (double)(nj - 1);
+        spread = spread < lim2 ? spread : lim2;
+        spread = spread > lim ? spread : lim;
+        const double old = rec->spread[m];
+        rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
+        if (m == 0) {
+            rec->lifetime = 0.0;
+            rec->point_num = nj;
+            // _estimate_point_num Tracking.py:232-244
+            double ne = rec->n_est;
+            if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
+            else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
+            rec->n_est = ne;
+            // BatchedData.add_frame on the track ring (Tracking.py:43-51)
+            int len = rec->ring_len;
+            while (len >= cfg.ring) {  // pop_frame: the freed physical slot becomes the first free entry
+                const int first = rec->ring_slot[0];
+                for (int k = 1; k < len; k++) { rec->ring_slot[k - 1] = rec->ring_slot[k]; rec->ring_n[k - 1] = rec->ring_n[k]; }
+                rec->ring_slot[len - 1] = first;
+                len--;
+            }
+            rec->ring_n[len] = nj;
+            rec->ring_len = len + 1;
+        }
+    }
+    __syncthreads();
+    // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
+    for (int j = tid; j < T; j += kThreads) {
+        if (L.cls_n[j + 1] > 0) {
+            const double v3 = L.cen[j * 6 + 3], v4 = L.cen[j * 6 + 4], v5 = L.cen[j * 6 + 5];
+            trk[L.slot[j]].is_static = sqrt((v3 * v3 + v4 * v4) + v5 * v5) < cfg.tr_vel_thres ? 1 : 0;
+        }
+    }
+    // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track
+    {
+        double *stk = L.gate + tid;  // gate|wsc are idle here: 6 x 256 doubles of pairwise stack
+        for (int task = tid; task < T * 21; task += kThreads) {
+            const int j = task / 21;
+            int e = task % 21, a = 0;
+            while (e >= 6 - a) { e -= 6 - a; a++; }
+            const int b = a + e;
+            const int nj = L.cls_n[j + 1], off = L.cls_off[j + 1];
+            if (nj == 0) continue;
+            TrackRec *rec = trk + L.slot[j];
+            const double ca = L.cen[j * 6 + a], cb = L.cen[j * 6 + b];
+            const double *pa = L.p6 + a * NP, *pb = L.p6 + b * NP;
+            const int *pm = L.perm + off;
+            auto elem = [&](int r) { int i = pm[r]; return (pa[i] - ca) * (pb[i] - cb); };
+            const double D = np_pairwise_sum(elem, nj, stk, kThreads) / (double)nj;
+            const double ne = rec->n_est;
+            if (ne == 0.0) { err |= ERR_DIVZERO; continue; }
+            const double al = (double)nj / ne;
+            rec->gd[a * 6 + b] = (1 - al) * rec->gd[a * 6 + b] + al * D;
+            if (a != b) rec->gd[b * 6 + a] = (1 - al) * rec->gd[b * 6 + a] + al * D;
+        }
+    }
+    // track ring rows: first min(n_j, ring_rows) rows of the cloud, all 8 columns, from the input block
+    for (int j = 0; j < T; j++) {
+        const int nj = L.cls_n[j + 1];
+        if (nj == 0) continue;
+        const TrackRec *rec = trk + L.slot[j];
+        const int keep = min(nj, cfg.ring_rows), off = L.cls_off[j + 1];
+        const int phys = rec->ring_slot[rec->ring_len - 1];
+        double *dst = st.trk_ring + (((size_t)s * cfg.t_cap + L.slot[j]) * cfg.ring + phys) * (size_t)cfg.ring_rows * 8;
+        for (int e = tid; e < keep * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[off + (e >> 3)] * 8 + (e & 7)];
+    }
+    __syncthreads();
+
+    // ---- _maintain_tracks (Tracking.py:513-528) ----
+    if (wave == 0) {
+        const bool have = lane < T;
+        bool keep = false;
+        int sl = 0;
+        if (have) {
+            sl = L.slot[lane];
+            const TrackRec *rec = trk + sl;
+            const double lim = rec->is_static ? cfg.tr_lifetime_static : cfg.tr_lifetime_dynamic;
+            keep = !(rec->lifetime > lim);
+        }
+        const unsigned long long kb = __ballot(have && keep), db = __ballot(have && !keep);
+        const int nk = __popcll(kb);
+        if (have) {
+            const int pos = keep ? __popcll(kb & lanemask_lt()) : nk + __popcll(db & lanemask_lt());
+            L.slot2[pos] = sl;
+        }
+        if (lane == 0) L.misc[0] = nk;
+    }
+    __syncthreads();
+    {
+        const int Told = T;
+        T = L.misc[0];
+        for (int j = tid; j < Told; j += kThreads) { L.slot[j] = L.slot2[j]; order[j] = L.slot2[j]; }
+    }
+    __syncthreads();
+
+    // ---- _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy update ----
+    for (int c0 = 0; c0 < T; c0 += kGateChunk) {
+        const int tc = min(kGateChunk, T - c0);
+        if (tid < tc) {
+            const TrackRec *rec = trk + L.slot[c0 + tid];
+            double *G = L.gate + tid * 72;  // SI[36] | Rc[36]
+            const double N = (double)rec->point_num;
+            const double den = (rec->n_est - 1) * N;
+            if (den == 0.0) err |= ERR_DIVZERO;
+            const double coef = (rec->n_est - N) / den;
+            double SI[36], det;
+            for (int a = 0; a < 6; a++)
+                for (int b = 0; b < 6; b++) {
+                    double rm = 0.0;
+                    if (a == b) { double hh = rec->spread[a] / 2; rm = hh * hh; }
+                    const double rc = rm / N + coef * rec->gd[a * 6 + b];
+                    G[36 + a * 6 + b] = rc;
+                    G[a * 6 + b] = rec->P[a * 9 + b] + rc;  // S = H P H^T + R
+                }
+            if (!lu6_inverse(G, 6, SI, det)) err |= ERR_SINGULAR;
+#pragma unroll
+            for (int e = 0; e < 36; e++) G[e] = SI[e];
+        }
+        __syncthreads();
+        const int rounds = (tc + kWaves - 1) / kWaves;
+        for (int r = 0; r < rounds; r++) {
+            const int jl = r * kWaves + wave;
+            const bool act = jl < tc;
+            double *W = L.wsc + wave * 288;  // P[81] | A[81] | K[54] | C1[54] | x[9] | y[6]
+            double *Pw = W, *Aw = W + 81, *Kw = W + 162, *C1 = W + 216, *xw = W + 270, *yw = W + 279;
+            TrackRec *rec = act ? trk + L.slot[c0 + jl] : nullptr;
+            const double *SI = L.gate + jl * 72, *Rc = SI + 36;
+            if (act) {
+                for (int e = lane; e < 81; e += 64) Pw[e] = rec->P[e];
+                if (lane < 9) xw[lane] = rec->x[lane];
+                if (lane < 6) yw[lane] = rec->centroid[lane] - rec->x[lane];
+            }
+            __syncthreads();
+            if (act && lane < 54) {  // K = P H^T S^-1
+                const int i = lane / 6, c = lane % 6;
+                if (i < dx) {
+                    double a = Pw[i * 9] * SI[c];
+                    for (int k = 1; k < 6; k++) a += Pw[i * 9 + k] * SI[k * 6 + c];
+                    Kw[lane] = a;
+                }
+            }
+            __syncthreads();
+            double xnew = 0.0;
+            if (act) {
+                if (lane < dx) {  // x = x + K y
+                    double a = Kw[lane * 6] * yw[0];
+                    for (int k = 1; k < 6; k++) a += Kw[lane * 6 + k] * yw[k];
+                    xnew = xw[lane] + a;
+                }
+                for (int e = lane; e < 81; e += 64) {  // A = (I - K H) P
+                    const int i = e / 9, c = e % 9;
+                    if (i < dx && c < dx) {
+                        double a = 0.0;
+                        for (int k = 0; k < dx; k++) {
+                            const double d = (i == k) ? 1.0 : 0.0;
+                            const double ikh = k < 6 ? d - Kw[i * 6 + k] : d;
+                            a = (k == 0) ? ikh * Pw[c] : a + ikh * Pw[k * 9 + c];
+                        }
+                        Aw[e] = a;
+                    }
+                }
+                if (lane < 54) {  // C1 = K R
+                    const int i = lane / 6, c = lane % 6;
+                    if (i < dx) {
+                        double a = Kw[i * 6] * Rc[c];
+                        for (int k = 1; k < 6; k++) a += Kw[i * 6 + k] * Rc[k * 6 + c];
+                        C1[lane] = a;
+                    }
+                }
+            }
+            __syncthreads();
+            if (act) {
+                for (int e = lane; e < 81; e += 64) {  // P = A (I-KH)^T + C1 K^T
+                    const int i = e / 9, c = e % 9;
+                    if (i < dx && c < dx) {
+                        double b = 0.0;
+                        for (int k = 0; k < dx; k++) {
+                            const double d = (c == k) ? 1.0 : 0.0;
+                            const double ikh = k < 6 ? d - Kw[c * 6 + k] : d;
+                            b = (k == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + k] * ikh;
+                        }
+                        double c2 = C1[i * 6] * Kw[c * 6];
+                        for (int k = 1; k < 6; k++) c2 += C1[i * 6 + k] * Kw[c * 6 + k];
+                        rec->P[e] = b + c2;
+                    }
+                }
+                if (lane < dx) {
+                    if (lane == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
+                        const double var = rec->centroid[0] - xnew;
+                        if (!(var == 0.0) && rec->lifetime == 0.0) xnew += var * 0.4;
+                    }
+                    rec->x[lane] = xnew;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- batch.add_frame(unassigned) on the global ring + DBSCAN trigger (Tracking.py:689-697) ----
+    const int nun = L.cls_n[0];
+    if (tid == 0) {
+        int len = hdr->g_len;
+        int gs[MMW_RING_MAX], gn[MMW_RING_MAX];
+        for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
+        while (len >= cfg.ring) {
+            const int first = gs[0];
+            for (int k = 1; k < len; k++) { gs[k - 1] = gs[k]; gn[k - 1] = gn[k]; }
+            gs[len - 1] = first;
+            len--;
+        }
+        gn[len] = nun;
+        L.misc[1] = gs[len];
+        len++;
+        int U = 0;
+        for (int k = 0; k < len; k++) U += gn[k];
+        for (int k = 0; k < MMW_RING_MAX; k++) { hdr->g_slot[k] = gs[k]; hdr->g_n[k] = k < len ? gn[k] : 0; }
+        hdr->g_len = len;
+        hdr->n_tracks = T;
+        hdr->db_u = U;
+        hdr->need_db = (U > 0 && T < cfg.tr_max_tracks) ? 1 : 0;
+    }
+    __syncthreads();
+    {
+        double *dst = st.g_ring + ((size_t)s * cfg.ring + L.misc[1]) * (size_t)NP * 8;
+        for (int e = tid; e < nun * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[e >> 3] * 8 + (e & 7)];
+    }
+    if (err) atomicOr(&hdr->err, err);
+}
+
+void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+                  int32_t *assoc, int32_t *db_n, hipStream_t stream)
+{
+    const size_t lds = track_lds_bytes(cfg);
+    hipLaunchKernelGGL(k_track, dim3(cfg.n_scenes), dim3(kThreads), lds, stream, cfg, st, pts, n_pts, dt, assoc, db_n);
+}
+
+hipError_t prepare_track(const DevCfg &cfg)
+{
+    return hipFuncSetAttribute((const void *)k_track, hipFuncAttributeMaxDynamicSharedMemorySize, (int)track_lds_bytes(cfg));
+}
+
+}  // namespace mmw

@@ -1,0 +1,527 @@
+// mmw_api.hip -- the C-ABI (include/mmw.h) over the HIP kernels.  No CPU path:
+// if HIP cannot give us a gfx950-class device, creation fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mmw_device.hpp"
+
+namespace mmw {
+size_t track_lds_bytes(const DevCfg &c);
+hipError_t prepare_track(const DevCfg &cfg);
+void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+                  int32_t *assoc, int32_t *db_n, hipStream_t stream);
+size_t dbscan_lds_bytes(int UM, int CL);
+hipError_t prepare_dbscan(int UM, int CL);
+void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int CL, int32_t *labels, int32_t *db_n, hipStream_t stream);
+void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
+                        int32_t *labels, int32_t *ncl, hipStream_t stream);
+void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
+void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
+void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st);
+void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st);
+void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
+void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
+void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st);
+}  // namespace mmw
+
+using namespace mmw;
+
+static thread_local std::string g_last_error;
+
+struct EventPair { hipEvent_t a, b; int kid; };
+
+struct mmw_ctx {
+    mmw_config cfg;
+    DevCfg dc;
+    DevState st;
+    int device;
+    int UM;                      // ring * max_pts
+    hipStream_t own_stream, stream;
+    std::string err;
+    // internal scratch
+    int32_t *d_row_off = nullptr;     // [S+1]
+    float *d_posture = nullptr;
+    // host-convenience staging (lazy)
+    double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;
+    int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr;
+    mmw_track_record *d_export = nullptr; int export_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> pool;
+    double tot_ms[MMW_K_COUNT] = {0};
+    int64_t launches[MMW_K_COUNT] = {0};
+};
+
+static int fail(mmw_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(ctx, MMW_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static void prof_begin(mmw_ctx *c, int kid, EventPair &ep)
+{
+    if (!c->prof) return;
+    if (!c->pool.empty()) { ep = c->pool.back(); c->pool.pop_back(); }
+    else { hipEventCreate(&ep.a); hipEventCreate(&ep.b); }
+    ep.kid = kid;
+    hipEventRecord(ep.a, c->stream);
+}
+static void prof_fold(mmw_ctx *c)
+{
+    for (auto &ep : c->pending) {
+        hipEventSynchronize(ep.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) { c->tot_ms[ep.kid] += ms; c->launches[ep.kid]++; }
+        c->pool.push_back(ep);
+    }
+    c->pending.clear();
+}
+static void prof_end(mmw_ctx *c, EventPair &ep)
+{
+    if (!c->prof) return;
+    hipEventRecord(ep.b, c->stream);
+    c->pending.push_back(ep);
+    if (c->pending.size() >= 2048) prof_fold(c);
+}
+
+extern "C" {
+
+const char *mmw_version(void) { return "mmw-hip 0.1 (gfx950)"; }
+
+const char *mmw_kernel_name(int32_t k)
+{
+    static const char *names[MMW_K_COUNT] = {"k_track", "k_dbscan_spawn", "k_features", "k_normalize", "k_table"};
+    return (k >= 0 && k < MMW_K_COUNT) ? names[k] : "?";
+}
+
+int mmw_config_default(mmw_config *c)
+{
+    if (!c) return MMW_E_ARG;
+    static const double lim[6] = {0.2, 0.2, 2, 1.2, 1.2, 0.2};
+    static const float posture[MMW_NKP] = {
+        0.0000f, -0.0007f, -0.0006f, -0.0038f, -0.1820f, -0.2540f, -0.2579f, 0.1830f, 0.2957f, 0.2940f,
+        -0.0805f, -0.1141f, -0.1232f, -0.1358f, 0.0796f, 0.1436f, 0.1558f, 0.1720f, -0.0007f, 0.7699f,
+        1.0906f, 1.4020f, 1.5513f, 1.2893f, 1.0360f, 0.7994f, 1.2865f, 1.0483f, 0.8117f, 0.7670f,
+        0.3428f, 0.0000f, -0.0746f, 0.7713f, 0.3706f, -0.0128f, -0.0796f, 1.3255f, 0.0752f, 0.0533f,
+        0.0203f, 0.0000f, 0.0496f, 0.1350f, 0.1303f, 0.0345f, 0.1277f, 0.1050f, 0.0392f, 0.0533f,
+        0.0786f, -0.0056f, 0.0346f, -0.0007f, 0.0683f, -0.0082f, 0.0312f};
+    memset(c, 0, sizeof(*c));
+    c->fb_frames_batch = 2; c->db_min_samples = 35; c->tr_max_tracks = 4; c->kf_enable_est = 0;
+    c->model_min_input = 0; c->dim_x = 9; c->ring_rows = 64; c->track_cap = 0;
+    c->db_z_weight = 0.4; c->db_range_weight = 0.03; c->db_eps = 0.3;
+    c->tr_lifetime_dynamic = 3; c->tr_lifetime_static = 7; c->tr_vel_thres = 0.12; c->tr_gate = 4.5;
+    c->kf_q_std = 1; c->kf_p_init = 0.1; c->kf_group_disp_est_init = 0.1; c->kf_a_n = 0.9; c->kf_est_pointnum = 10;
+    memcpy(c->kf_spread_lim, lim, sizeof(lim));
+    c->kf_a_spr = 0.9; c->intensity_mu = 27.0187; c->intensity_std = 70.351; c->s_height = 1.8;
+    c->tilt_cos = 0.99619469809174555;   /* cos(radians(-5)) */
+    c->tilt_sin = -0.087155742747658166; /* sin(radians(-5)) */
+    memcpy(c->default_posture, posture, sizeof(posture));
+    return MMW_OK;
+}
+
+const char *mmw_last_error(const mmw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t device, mmw_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, MMW_E_ARG, "mmw_create: null argument");
+    *out = nullptr;
+    if (n_scenes < 1 || max_pts < 1 || max_pts > MMW_MAX_PTS_LIMIT) return fail(nullptr, MMW_E_ARG, "mmw_create: n_scenes=%d max_pts=%d out of range (max_pts <= %d)", n_scenes, max_pts, MMW_MAX_PTS_LIMIT);
+    if (cfg->fb_frames_batch < 0 || cfg->fb_frames_batch + 1 > MMW_RING_MAX) return fail(nullptr, MMW_E_ARG, "FB_FRAMES_BATCH must be in [0,%d]", MMW_RING_MAX - 1);
+    if (cfg->dim_x != 9 && cfg->dim_x != 6) return fail(nullptr, MMW_E_ARG, "dim_x must be 9 (CONST_ACC_MODEL) or 6 (CONST_VEL_MODEL)");
+    const int ring = cfg->fb_frames_batch + 1;
+    if (ring * max_pts > 30 * 64) return fail(nullptr, MMW_E_ARG, "ring*max_pts = %d exceeds 1920 (BallTree emulation holds <= 32 leaves)", ring * max_pts);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MMW_E_NODEVICE, "no HIP device visible: libmmw_hip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(nullptr, MMW_E_NODEVICE, "device %d not available (%d visible)", device, ndev);
+    mmw_ctx *c = new (std::nothrow) mmw_ctx();
+    if (!c) return fail(nullptr, MMW_E_ARG, "out of host memory");
+    c->cfg = *cfg;
+    c->device = device;
+    HIPCHK(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return fail(nullptr, MMW_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName); }
+    DevCfg &d = c->dc;
+    memset(&d, 0, sizeof(d));
+    d.ring = ring; d.db_min_samples = cfg->db_min_samples; d.tr_max_tracks = cfg->tr_max_tracks;
+    d.kf_enable_est = cfg->kf_enable_est; d.model_min_input = cfg->model_min_input; d.dx = cfg->dim_x;
+    d.ring_rows = cfg->ring_rows < 64 ? 64 : cfg->ring_rows;
+    int cap = cfg->track_cap;
+    if (cap <= 0) {
+        const int ms = cfg->db_min_samples > 0 ? cfg->db_min_samples : 1;
+        cap = (cfg->tr_max_tracks > 0 ? cfg->tr_max_tracks - 1 : 0) + (ring * max_pts) / ms + 1;
+    }
+    if (cap > MMW_TRACK_CAP_LIMIT) cap = MMW_TRACK_CAP_LIMIT;
+    if (cap < 1) cap = 1;
+    d.t_cap = cap; d.max_pts = max_pts; d.n_scenes = n_scenes;
+    d.db_z_weight = cfg->db_z_weight; d.db_range_weight = cfg->db_range_weight; d.db_eps = cfg->db_eps;
+    d.tr_lifetime_dynamic = cfg->tr_lifetime_dynamic; d.tr_lifetime_static = cfg->tr_lifetime_static;
+    d.tr_vel_thres = cfg->tr_vel_thres; d.tr_gate = cfg->tr_gate; d.kf_q_std = cfg->kf_q_std; d.kf_p_init = cfg->kf_p_init;
+    d.kf_group_disp_est_init = cfg->kf_group_disp_est_init; d.kf_a_n = cfg->kf_a_n; d.kf_est_pointnum = cfg->kf_est_pointnum;
+    for (int i = 0; i < 6; i++) d.kf_spread_lim[i] = cfg->kf_spread_lim[i];
+    d.kf_a_spr = cfg->kf_a_spr; d.intensity_mu = cfg->intensity_mu; d.intensity_std = cfg->intensity_std;
+    d.s_height = cfg->s_height; d.tilt_cos = cfg->tilt_cos; d.tilt_sin = cfg->tilt_sin;
+    c->UM = ring * max_pts;
+
+#define ALLOC(ptr, bytes)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                                \
+        if (e_ != hipSuccess) { int rc = fail(nullptr, MMW_E_HIP, "hipMalloc(%zu) -> %s", (size_t)(bytes), hipGetErrorString(e_)); mmw_destroy(c); return rc; } \
+    } while (0)
+    const size_t S = (size_t)n_scenes;
+    ALLOC(c->st.hdr, S * sizeof(SceneHdr));
+    ALLOC(c->st.order, S * cap * sizeof(int32_t));
+    ALLOC(c->st.trk, S * cap * sizeof(TrackRec));
+    ALLOC(c->st.trk_ring, S * cap * (size_t)ring * d.ring_rows * 8 * sizeof(double));
+    ALLOC(c->st.g_ring, S * (size_t)ring * max_pts * 8 * sizeof(double));
+    ALLOC(c->d_posture, MMW_NKP * sizeof(float));
+    ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
+#undef ALLOC
+    c->st.default_posture = c->d_posture;
+    if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
+    c->stream = c->own_stream;
+    const size_t lds_a = track_lds_bytes(d), lds_b = dbscan_lds_bytes(c->UM, cap);
+    if (lds_a > 160 * 1024 || lds_b > 160 * 1024) { mmw_destroy(c); return fail(nullptr, MMW_E_ARG, "LDS demand too large (track %zu B, dbscan %zu B > 160 KiB)", lds_a, lds_b); }
+    hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap);
+    if (e1 != hipSuccess || e2 != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
+    launch_reset(d, c->st, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "reset kernel failed: %s", hipGetErrorString(hipGetLastError())); }
+    *out = c;
+    return MMW_OK;
+}
+
+int mmw_destroy(mmw_ctx *c)
+{
+    if (!c) return MMW_OK;
+    hipSetDevice(c->device);
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    prof_fold(c);
+    for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_pts, c->d_n,
+                    c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return MMW_OK;
+}
+
+int mmw_reset(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_reset(c->dc, c->st, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_set_stream(mmw_ctx *c, void *s)
+{
+    if (!c) return MMW_E_ARG;
+    hipStreamSynchronize(c->stream);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MMW_OK;
+}
+
+int mmw_synchronize(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+
+int mmw_get_dims(const mmw_ctx *c, int32_t *n_scenes, int32_t *max_pts, int32_t *track_cap, int32_t *ring, int32_t *ring_rows)
+{
+    if (!c) return MMW_E_ARG;
+    if (n_scenes) *n_scenes = c->dc.n_scenes;
+    if (max_pts) *max_pts = c->dc.max_pts;
+    if (track_cap) *track_cap = c->dc.t_cap;
+    if (ring) *ring = c->dc.ring;
+    if (ring_rows) *ring_rows = c->dc.ring_rows;
+    return MMW_OK;
+}
+
+int mmw_dev_alloc(mmw_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(dptr, bytes ? bytes : 8));
+    return MMW_OK;
+}
+int mmw_dev_free(mmw_ctx *c, void *p)
+{
+    if (!c) return MMW_E_ARG;
+    if (p) HIPCHK(c, hipFree(p));
+    return MMW_OK;
+}
+int mmw_memcpy_h2d(mmw_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+int mmw_memcpy_d2h(mmw_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+
+int mmw_normalize(mmw_ctx *c, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out)
+{
+    if (!c || !raw || !n_raw || !pts || !n_out) return fail(c, MMW_E_ARG, "mmw_normalize: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    EventPair ep;
+    prof_begin(c, MMW_K_NORMALIZE, ep);
+    launch_normalize(c->dc, raw, n_raw, pts, n_out, c->stream);
+    prof_end(c, ep);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
+{
+    if (!c || !pts || !n_pts || !dt) return fail(c, MMW_E_ARG, "mmw_step: null input pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    EventPair ep;
+    prof_begin(c, MMW_K_TRACK, ep);
+    launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, c->stream);
+    prof_end(c, ep);
+    prof_begin(c, MMW_K_DBSCAN, ep);
+    launch_dbscan_spawn(c->dc, c->st, c->UM, c->dc.t_cap, db_labels, db_n, c->stream);
+    prof_end(c, ep);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+static int ensure_host_staging(mmw_ctx *c)
+{
+    if (c->d_pts) return MMW_OK;
+    const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
+    HIPCHK(c, hipMalloc((void **)&c->d_pts, S * NP * 8 * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_n, S * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_dt, S * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_assoc, S * NP * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_labels, S * (size_t)c->UM * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_dbn, S * sizeof(int32_t)));
+    return MMW_OK;
+}
+
+int mmw_step_host(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
+{
+    if (!c || !pts || !n_pts || !dt) return fail(c, MMW_E_ARG, "mmw_step_host: null input pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_host_staging(c);
+    if (rc) return rc;
+    const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
+    HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, S * NP * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_n, n_pts, S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_dt, dt, S * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    rc = mmw_step(c, c->d_pts, c->d_n, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
+    if (rc) return rc;
+    if (assoc) HIPCHK(c, hipMemcpyAsync(assoc, c->d_assoc, S * NP * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (db_labels) HIPCHK(c, hipMemcpyAsync(db_labels, c->d_labels, S * (size_t)c->UM * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (db_n) HIPCHK(c, hipMemcpyAsync(db_n, c->d_dbn, S * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return mmw_check(c);
+}
+
+int mmw_dbscan(mmw_ctx *c, const double *pts, const int32_t *n, int32_t max_n, double eps, int32_t min_samples, int32_t *labels, int32_t *n_clusters)
+{
+    if (!c || !pts || !n || !labels) return fail(c, MMW_E_ARG, "mmw_dbscan: null pointer");
+    if (max_n < 1 || max_n > c->UM) return fail(c, MMW_E_ARG, "mmw_dbscan: max_n=%d must be in [1, ring*max_pts=%d]", max_n, c->UM);
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_dbscan_only(c->dc, c->UM, pts, n, max_n, eps, min_samples, labels, n_clusters, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_features(mmw_ctx *c, float *feat, int32_t *owner, int32_t cap_rows, int32_t *n_rows)
+{
+    if (!c || !feat || !owner || !n_rows || cap_rows < 0) return fail(c, MMW_E_ARG, "mmw_features: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    EventPair ep;
+    launch_feat_scan(c->dc, c->st, c->d_row_off, c->stream);
+    prof_begin(c, MMW_K_FEATURES, ep);
+    launch_features(c->dc, c->st, c->d_row_off, feat, owner, cap_rows, c->stream);
+    prof_end(c, ep);
+    HIPCHK(c, hipGetLastError());
+    int32_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_row_off + c->dc.n_scenes, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_rows = total < cap_rows ? total : cap_rows;
+    if (total > cap_rows) return fail(c, MMW_E_CAPACITY, "mmw_features: %d eligible tracks but cap_rows=%d", total, cap_rows);
+    return MMW_OK;
+}
+
+int mmw_set_keypoints(mmw_ctx *c, const float *kp, const int32_t *owner, int32_t n_rows)
+{
+    if (!c || (n_rows > 0 && (!kp || !owner)) || n_rows < 0) return fail(c, MMW_E_ARG, "mmw_set_keypoints: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_set_kp(c->dc, c->st, kp, owner, n_rows, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+static int read_headers(mmw_ctx *c, std::vector<SceneHdr> &h)
+{
+    h.resize(c->dc.n_scenes);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->st.hdr, h.size() * sizeof(SceneHdr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+
+int mmw_check(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    std::vector<SceneHdr> h;
+    int rc = read_headers(c, h);
+    if (rc) return rc;
+    for (size_t s = 0; s < h.size(); s++) {
+        const int e = h[s].err;
+        if (!e) continue;
+        if (e & ERR_CAPACITY) return fail(c, MMW_E_CAPACITY, "scene %zu: more tracks than track_cap=%d", s, c->dc.t_cap);
+        if (e & ERR_SINGULAR) return fail(c, MMW_E_SINGULAR, "scene %zu: singular 6x6 gate/innovation matrix", s);
+        if (e & ERR_DIVZERO) return fail(c, MMW_E_DIVZERO, "scene %zu: (N_est-1)*N == 0 in _get_Rc / N_est == 0", s);
+    }
+    return MMW_OK;
+}
+
+int mmw_get_num_tracks(mmw_ctx *c, int32_t *n_tracks)
+{
+    if (!c || !n_tracks) return MMW_E_ARG;
+    std::vector<SceneHdr> h;
+    int rc = read_headers(c, h);
+    if (rc) return rc;
+    for (size_t s = 0; s < h.size(); s++) n_tracks[s] = h[s].n_tracks;
+    return MMW_OK;
+}
+
+int mmw_get_batch_ring(mmw_ctx *c, int32_t *ring_len, int32_t *ring_n)
+{
+    if (!c || !ring_len || !ring_n) return MMW_E_ARG;
+    std::vector<SceneHdr> h;
+    int rc = read_headers(c, h);
+    if (rc) return rc;
+    for (size_t s = 0; s < h.size(); s++) {
+        ring_len[s] = h[s].g_len;
+        for (int k = 0; k < MMW_RING_MAX; k++) ring_n[s * MMW_RING_MAX + k] = k < h[s].g_len ? h[s].g_n[k] : 0;
+    }
+    return MMW_OK;
+}
+
+int mmw_get_tracks(mmw_ctx *c, mmw_track_record *out, int32_t cap)
+{
+    if (!c || !out || cap < 1) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->dc.n_scenes * cap * sizeof(mmw_track_record);
+    if (c->export_cap < cap) {
+        if (c->d_export) hipFree(c->d_export);
+        c->d_export = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->d_export, bytes));
+        c->export_cap = cap;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_export, 0, bytes, c->stream));
+    launch_export(c->dc, c->st, c->d_export, cap, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_export, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+
+int mmw_get_track_ring_frame(mmw_ctx *c, int32_t scene, int32_t track, int32_t k, double *out, int32_t *n_rows)
+{
+    if (!c || !out || !n_rows || scene < 0 || scene >= c->dc.n_scenes) return MMW_E_ARG;
+    SceneHdr h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (track < 0 || track >= h.n_tracks) return fail(c, MMW_E_ARG, "track %d out of range (%d tracks)", track, h.n_tracks);
+    int32_t slot = 0;
+    HIPCHK(c, hipMemcpyAsync(&slot, c->st.order + (size_t)scene * c->dc.t_cap + track, sizeof(slot), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    TrackRec rec;
+    HIPCHK(c, hipMemcpyAsync(&rec, c->st.trk + (size_t)scene * c->dc.t_cap + slot, sizeof(rec), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (k < 0 || k >= rec.ring_len) return fail(c, MMW_E_ARG, "frame %d out of range (ring_len %d)", k, rec.ring_len);
+    const int keep = rec.ring_n[k] < c->dc.ring_rows ? rec.ring_n[k] : c->dc.ring_rows;
+    const double *src = c->st.trk_ring + ((((size_t)scene * c->dc.t_cap + slot) * c->dc.ring + rec.ring_slot[k]) * c->dc.ring_rows) * 8;
+    HIPCHK(c, hipMemcpyAsync(out, src, (size_t)keep * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_rows = keep;
+    return MMW_OK;
+}
+
+int mmw_get_batch_ring_frame(mmw_ctx *c, int32_t scene, int32_t k, double *out, int32_t *n_rows)
+{
+    if (!c || !out || !n_rows || scene < 0 || scene >= c->dc.n_scenes) return MMW_E_ARG;
+    SceneHdr h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (k < 0 || k >= h.g_len) return fail(c, MMW_E_ARG, "frame %d out of range (ring_len %d)", k, h.g_len);
+    const double *src = c->st.g_ring + ((size_t)scene * c->dc.ring + h.g_slot[k]) * (size_t)c->dc.max_pts * 8;
+    HIPCHK(c, hipMemcpyAsync(out, src, (size_t)h.g_n[k] * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_rows = h.g_n[k];
+    return MMW_OK;
+}
+
+int mmw_track_table(mmw_ctx *c, mmw_track_summary *table, int32_t slots, int32_t scene_base)
+{
+    if (!c || !table || slots < 1) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    EventPair ep;
+    prof_begin(c, MMW_K_TABLE, ep);
+    launch_table(c->dc, c->st, table, slots, scene_base, c->stream);
+    prof_end(c, ep);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_profile_enable(mmw_ctx *c, int32_t on)
+{
+    if (!c) return MMW_E_ARG;
+    if (!on) { hipStreamSynchronize(c->stream); prof_fold(c); }
+    c->prof = on != 0;
+    return MMW_OK;
+}
+int mmw_profile_reset(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    hipStreamSynchronize(c->stream);
+    prof_fold(c);
+    for (int k = 0; k < MMW_K_COUNT; k++) { c->tot_ms[k] = 0; c->launches[k] = 0; }
+    return MMW_OK;
+}
+int mmw_profile_get(mmw_ctx *c, int32_t k, double *total_ms, int64_t *launches)
+{
+    if (!c || k < 0 || k >= MMW_K_COUNT) return MMW_E_ARG;
+    hipStreamSynchronize(c->stream);
+    prof_fold(c);
+    if (total_ms) *total_ms = c->tot_ms[k];
+    if (launches) *launches = c->launches[k];
+    return MMW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// mmw_device.hpp -- device-side data layout shared by the HIP kernels and the C-ABI glue.
+// gfx950 only (wave64, 160 KiB LDS/CU).  fp64 everywhere a decision is taken.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmw.h"
+
+namespace mmw {
+
+constexpr int kThreads = 256;       // 4 waves per workgroup, one workgroup per scene
+constexpr int kWaves = kThreads / 64;
+constexpr int kGateChunk = 16;      // tracks whose 6x6 inverses are staged in LDS at once
+constexpr int kLeafSize = 30;       // sklearn BallTree default leaf_size (DBSCAN passes it through)
+constexpr int kMaxLeaves = 32;      // n <= 1920 -> <= 63 nodes -> <= 32 leaves
+constexpr int kMaxNodes = 63;
+
+// per-scene error bits (sticky until mmw_reset)
+enum : int { ERR_SINGULAR = 1, ERR_DIVZERO = 2, ERR_CAPACITY = 4 };
+
+struct DevCfg {
+    int32_t ring;            // FB_FRAMES_BATCH + 1
+    int32_t db_min_samples;
+    int32_t tr_max_tracks;
+    int32_t kf_enable_est;
+    int32_t model_min_input;
+    int32_t dx;              // 9 / 6
+    int32_t ring_rows;
+    int32_t t_cap;
+    int32_t max_pts;
+    int32_t n_scenes;
+    double db_z_weight, db_range_weight, db_eps;
+    double tr_lifetime_dynamic, tr_lifetime_static, tr_vel_thres, tr_gate;
+    double kf_q_std, kf_p_init, kf_group_disp_est_init, kf_a_n, kf_est_pointnum;
+    double kf_spread_lim[6];
+    double kf_a_spr;
+    double intensity_mu, intensity_std;
+    double s_height, tilt_cos, tilt_sin;
+};
+
+// 64 B header per scene
+struct SceneHdr {
+    int32_t n_tracks;
+    int32_t g_len;                 // frames in the global BatchedData ring
+    int32_t g_n[MMW_RING_MAX];     // rows per frame, oldest first
+    int32_t g_slot[MMW_RING_MAX];  // permutation: physical slot of the k-th oldest frame
+    int32_t need_db;               // set by the track kernel: run apply_DBscan this frame
+    int32_t err;
+    int32_t db_u;
+    int32_t pad[3];
+};
+static_assert(sizeof(SceneHdr) == 64, "SceneHdr");
+
+// One ClusterTrack.  187 doubles = 1496 B.
+struct TrackRec {
+    double x[9];
+    double P[81];
+    double centroid[6];
+    double minv[6];
+    double maxv[6];
+    double spread[6];
+    double gd[36];
+    double n_est;
+    double lifetime;
+    int32_t point_num;
+    int32_t is_static;
+    int32_t ring_len;
+    int32_t pad0;
+    int32_t ring_n[MMW_RING_MAX];
+    int32_t ring_slot[MMW_RING_MAX];
+    float kp[MMW_NKP];
+    float pad1;
+};
+static_assert(sizeof(TrackRec) == 187 * 8, "TrackRec");
+
+struct DevState {
+    SceneHdr *hdr;        // [S]
+    int32_t *order;       // [S][t_cap]  effective_tracks position -> physical record (always a permutation)
+    TrackRec *trk;        // [S][t_cap]
+    double *trk_ring;     // [S][t_cap][ring][ring_rows][8]
+    double *g_ring;       // [S][ring][max_pts][8]
+    const float *default_posture;  // [57]
+};
+
+__host__ __device__ inline size_t trk_ring_stride_track(const DevCfg &c) { return (size_t)c.ring * c.ring_rows * 8; }
+
+}  // namespace mmw

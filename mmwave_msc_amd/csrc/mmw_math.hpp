@@ -1,0 +1,132 @@
+// mmw_math.hpp -- small fp64 device helpers with a FIXED operation order.
+// Build with -ffp-contract=off: every a*b+c below is two roundings, on purpose
+// (bit-reproducibility against the CPU restatement used by the parity tests).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmw {
+
+// log() with the fdlibm/musl reduction + polynomial (Tracking.py:558 uses np.log;
+// device libm and host libm differ in the last bit, so the kernels carry their own).
+__device__ inline double dlog(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x < 0.0) return __longlong_as_double(0x7ff8000000000000LL);
+    if (x == 0.0) return __longlong_as_double(0xfff0000000000000LL);
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    if (u == 0x7ff0000000000000ULL) return x;
+    int k = 0;
+    if ((u >> 52) == 0) {
+        x *= 18014398509481984.0;
+        k -= 54;
+        u = (unsigned long long)__double_as_longlong(x);
+    }
+    unsigned int hx = (unsigned int)(u >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((unsigned long long)hx << 32) | (u & 0xffffffffULL);
+    x = __longlong_as_double((long long)u);
+    double f = x - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+// 6x6 LU with partial pivoting (first max), determinant and inverse, entirely in
+// registers (all indices static after unrolling).  M is read with stride `ld`.
+// Returns false when a pivot is exactly zero (numpy: LinAlgError).
+__device__ inline bool lu6_inverse(const double *M, int ld, double *inv /*[36]*/, double &det)
+{
+    double A[36];
+    int perm[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        perm[r] = r;
+#pragma unroll
+        for (int c = 0; c < 6; c++) A[r * 6 + c] = M[r * ld + c];
+    }
+    bool neg = false, ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        double best = fabs(A[k * 6 + k]);
+#pragma unroll
+        for (int r = k + 1; r < 6; r++) {
+            double v = fabs(A[r * 6 + k]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (!(best > 0.0)) ok = false;
+#pragma unroll
+        for (int r = k + 1; r < 6; r++) {
+            if (p == r) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) { double t = A[k * 6 + c]; A[k * 6 + c] = A[r * 6 + c]; A[r * 6 + c] = t; }
+                int tp = perm[k]; perm[k] = perm[r]; perm[r] = tp;
+                neg = !neg;
+            }
+        }
+#pragma unroll
+        for (int r = k + 1; r < 6; r++) {
+            double l = A[r * 6 + k] / A[k * 6 + k];
+            A[r * 6 + k] = l;
+#pragma unroll
+            for (int c = k + 1; c < 6; c++) A[r * 6 + c] = A[r * 6 + c] - l * A[k * 6 + c];
+        }
+    }
+    double d = A[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) d = d * A[k * 6 + k];
+    det = neg ? -d : d;
+#pragma unroll
+    for (int col = 0; col < 6; col++) {
+        double y[6], xs[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double s = (perm[r] == col) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; k++) s = s - A[r * 6 + k] * y[k];
+            y[r] = s;
+        }
+#pragma unroll
+        for (int r = 5; r >= 0; r--) {
+            double s = y[r];
+#pragma unroll
+            for (int k = r + 1; k < 6; k++) s = s - A[r * 6 + k] * xs[k];
+            xs[r] = s / A[r * 6 + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) inv[r * 6 + col] = xs[r];
+    }
+    return ok;
+}
+
+// altered_EuclideanDist (Utils.py:242-247), operation order kept.
+__device__ inline double alt_dist(double ax, double ay, double az, double bx, double by, double bz,
+                                  double range_w, double z_w)
+{
+    double w = 1 - ((ay + by) / 2) * range_w;
+    double dx = ax - bx, dy = ay - by, dz = az - bz;
+    return w * ((dx * dx + dy * dy) + z_w * (dz * dz));
+}
+
+__device__ inline unsigned long long lanemask_lt()
+{
+    unsigned lane = __lane_id();
+    return lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+}
+
+}  // namespace mmw

@@ -1,0 +1,150 @@
+"""GPU parity: the HIP path (through the C-ABI) against (a) the golden vectors
+recorded from the reference and (b) the CPU oracle on the same inputs.
+
+(a) ints bit-exact, fp64 within tests/_golden.py's stated tolerance.
+(b) everything bit-exact: the oracle and the kernels share one fixed operation order.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_scenario,
+                           overrides_to_cfg_kwargs, scenario_names)
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n_scenes, max_pts, **kw):
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    return SceneBatch(_lib.default_config(**kw), n_scenes, max_pts)
+
+
+@pytest.mark.parametrize("name", scenario_names())
+def test_golden_scenario(name):
+    from oracle import c_oracle as co
+    g = load_scenario(name)
+    kw = overrides_to_cfg_kwargs(g["overrides"])
+    n = g["pts"].shape[1]
+    sb = _mk(1, n, **kw)
+    orc = co.OracleScene(co.default_config(**kw), n)
+    for f in range(g["pts"].shape[0]):
+        c = int(g["cnt"][f])
+        pts = np.zeros((1, n, 8))
+        pts[0, :c] = g["pts"][f, :c]
+        assoc, labels, dbn = sb.step_host(pts, np.array([c], np.int32), np.array([g["dt"][f]]))
+        if c == 0:
+            assert dbn[0] == -1
+            assert sb.num_tracks()[0] == g["n_tracks"][f]
+            continue
+        o_assoc, o_lab = orc.track(pts[0, :c], float(g["dt"][f]))
+        # (a) golden
+        assert np.array_equal(assoc[0, :c], g["assoc"][f, :c]), f"{name} f{f}: association vs golden"
+        assert dbn[0] == g["db_n"][f], f"{name} f{f}: db_n {dbn[0]} vs {g['db_n'][f]}"
+        if dbn[0] >= 0:
+            assert np.array_equal(labels[0, : dbn[0]], g["labels"][f, : dbn[0]]), f"{name} f{f}: labels vs golden"
+        nt = int(g["n_tracks"][f])
+        assert sb.num_tracks()[0] == nt
+        trk = sb.tracks(cap=max(nt, 1))[0, :nt]
+        assert_tracks_match(trk, g["tracks"][f, :nt], ctx=f"{name} f{f} vs golden")
+        ln, rn = sb.batch_ring()
+        assert ln[0] == g["ring_len"][f] and np.array_equal(rn[0, : ln[0]], g["ring_n"][f, : ln[0]])
+        # (b) oracle, bit-exact
+        assert np.array_equal(assoc[0, :c], o_assoc)
+        assert (o_lab is None) == (dbn[0] < 0)
+        if o_lab is not None:
+            assert np.array_equal(labels[0, : dbn[0]], o_lab)
+        assert_tracks_match(trk, orc.tracks(), ctx=f"{name} f{f} vs oracle", exact=True)
+        feat, owner = sb.features_host()
+        nf = int(g["n_feat"][f])
+        assert len(owner) == nf
+        if nf:
+            assert np.array_equal(owner[:, 1], g["owner"][f, :nf]) and np.all(owner[:, 0] == 0)
+            assert_feat_equal(feat, g["feat"][f, :nf], ctx=f"{name} f{f}")
+            o_feat, o_own = orc.features()
+            assert np.array_equal(feat, o_feat), f"{name} f{f}: features vs oracle"
+    sb.close()
+
+
+def test_multi_scene_vs_oracle():
+    """32 scenes with different target counts stepped together; every scene must equal
+    its own oracle run bit for bit (ints, fp64 state, ring contents, features)."""
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    S, N, F = 32, 256, 14
+    kw = dict(tr_max_tracks=4)
+    sb = _mk(S, N, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    pts = np.zeros((F, S, N, 8), np.float32)
+    cnt = np.zeros((F, S), np.int32)
+    dts = np.zeros((F, S))
+    for s in range(S):
+        p, c, d = make_batch([700 + s], F, N, 1 + s % 5, ragged=(s % 3 == 0))
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=8)
+        feat, owner = sb.features_host()
+        row = 0
+        for s in range(S):
+            c = cnt[f, s]
+            oa, ol = scenes[s].track(pts[f, s, :c].astype(np.float64), dts[f, s])
+            assert np.array_equal(assoc[s, :c], oa), (f, s)
+            assert (ol is None) == (dbn[s] < 0), (f, s)
+            if ol is not None:
+                assert np.array_equal(labels[s, : dbn[s]], ol), (f, s)
+            assert ntr[s] == scenes[s].n_tracks
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
+            of, oo = scenes[s].features()
+            k = len(oo)
+            assert np.all(owner[row: row + k, 0] == s) and np.array_equal(owner[row: row + k, 1], oo)
+            if k:
+                assert np.array_equal(feat[row: row + k], of), (f, s)
+            row += k
+        assert row == len(owner)
+    # ring contents of one scene
+    s = 5
+    for t in range(scenes[s].n_tracks):
+        rec = scenes[s].tracks()[t]
+        for k in range(rec["ring_len"]):
+            assert np.array_equal(sb.track_ring_frame(s, t, k), scenes[s].track_ring_frame(t, k))
+    sb.close()
+
+
+def test_normalize_golden_and_oracle():
+    from oracle import c_oracle as co
+    z = np.load(os.path.join(GOLDEN, "normalize.npz"))
+    raw = z["raw"]
+    n = raw.shape[0]
+    sb = _mk(2, n)
+    rawb = np.zeros((2, n, 5))
+    rawb[0] = raw
+    rawb[1, : n // 2] = raw[n // 2: n // 2 * 2]
+    pts, n_out = sb.normalize_host(rawb, np.array([n, n // 2], np.int32))
+    assert n_out[0] == z["out"].shape[0]
+    assert np.allclose(pts[0, : n_out[0]], z["out"], rtol=0, atol=1e-12)
+    cfg = co.default_config()
+    assert np.array_equal(pts[0, : n_out[0]], co.normalize(cfg, raw))
+    assert np.array_equal(pts[1, : n_out[1]], co.normalize(cfg, raw[n // 2: n // 2 * 2]))
+    sb.close()
+
+
+def test_dbscan_golden():
+    z = np.load(os.path.join(GOLDEN, "dbscan.npz"))
+    sizes = [int(v) for v in z["sizes"]]
+    mx = max(sizes)
+    sb = _mk(len(sizes), 512)  # ring*max_pts = 1536 >= every size
+    pts = np.zeros((len(sizes), mx, 8))
+    n = np.array(sizes, np.int32)
+    for i, sz in enumerate(sizes):
+        pts[i, :sz] = z[f"pts_{sz}"]
+    for ms in (35, 8):
+        labels, ncl = sb.dbscan_host(pts, n, min_samples=ms)
+        for i, sz in enumerate(sizes):
+            want = z[f"labels_{sz}_{ms}"]
+            assert np.array_equal(labels[i, :sz], want), f"n={sz} min_samples={ms}"
+            assert ncl[i] == want.max() + 1
+    sb.close()
