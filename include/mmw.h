@@ -96,6 +96,7 @@ typedef struct mmw_track_record {
     int32_t is_static;              /* cluster.status: STATIC=True (Tracking.py:17,132-136) */
     int32_t ring_len;               /* len(track.batch.buffer) */
     int32_t ring_n[MMW_RING_MAX];   /* rows per frame, oldest first */
+    int32_t uid;                    /* creation ordinal in its scene (TrackBuffer.next_track_id, Tracking.py:588) */
     float keypoints[MMW_NKP];
 } mmw_track_record;
 
@@ -167,6 +168,11 @@ int mmw_dbscan(mmw_ctx *ctx, const double *pts, const int32_t *n, int32_t max_n,
  *   owner[cap_rows][2] int32 (dev) = (scene, track index)
  *   *n_rows (host) = rows written (sync).  MMW_E_CAPACITY if cap_rows is too small. */
 int mmw_features(mmw_ctx *ctx, float *feat, int32_t *owner, int32_t cap_rows, int32_t *n_rows);
+/* Utils.relative_coordinates + Utils.format_single_frame (Utils.py:437-520) on caller
+ * frames: frames[B][ring][64][8] fp64 (only rows [:64] matter, Utils.py:505-510),
+ * counts[B][ring] valid rows (<= 0 rows: frame stays zero, Utils.py:493), ref[B][2] = (x, y)
+ * subtracted from columns 0,1 -> feat[B][ring][8][8][5] fp32.  All dev pointers. */
+int mmw_format_frames(mmw_ctx *ctx, const double *frames, const int32_t *counts, const double *ref, float *feat, int32_t n_items);
 /* track.keypoints = frame_keypoints[i] (Tracking.py:733-734): kp[n_rows][57] fp32 dev. */
 int mmw_set_keypoints(mmw_ctx *ctx, const float *kp, const int32_t *owner, int32_t n_rows);
 
@@ -192,6 +198,12 @@ int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32
 #define MMW_K_NORMALIZE 3
 #define MMW_K_TABLE 4
 #define MMW_K_COUNT 5
+/* Work counters accumulated by the kernels since the last reset (sync):
+ * [0] k_track algorithmic bytes  [1] k_dbscan algorithmic bytes  [2] scene-frames stepped
+ * [3] apply_DBscan calls  [4] sum of U over those calls  [5] sum of tracks entering track()
+ * [6] gate evaluations (points x tracks)  [7] clusters found.  Definitions: DESIGN.md §4. */
+int mmw_stats_get(mmw_ctx *ctx, uint64_t *out /*[8]*/);
+int mmw_stats_reset(mmw_ctx *ctx);
 int mmw_profile_enable(mmw_ctx *ctx, int32_t on);
 int mmw_profile_reset(mmw_ctx *ctx);
 int mmw_profile_get(mmw_ctx *ctx, int32_t kernel_id, double *total_ms, int64_t *launches);   /* sync */

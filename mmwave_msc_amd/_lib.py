@@ -28,7 +28,7 @@ EXPORTS = [
     "mmw_normalize", "mmw_step", "mmw_step_host", "mmw_dbscan", "mmw_features", "mmw_set_keypoints", "mmw_check",
     "mmw_get_num_tracks", "mmw_get_tracks", "mmw_get_batch_ring", "mmw_get_track_ring_frame",
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
-    "mmw_kernel_name", "mmw_version",
+    "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames",
 ]
 
 
@@ -53,7 +53,7 @@ TRACK_DTYPE = np.dtype(
         ("x", "f8", (9,)), ("P", "f8", (9, 9)), ("centroid", "f8", (6,)), ("min_vals", "f8", (6,)),
         ("max_vals", "f8", (6,)), ("spread_est", "f8", (6,)), ("group_disp_est", "f8", (6, 6)),
         ("n_est", "f8"), ("lifetime", "f8"), ("point_num", "i4"), ("is_static", "i4"), ("ring_len", "i4"),
-        ("ring_n", "i4", (RING_MAX,)), ("keypoints", "f4", (NKP,)),
+        ("ring_n", "i4", (RING_MAX,)), ("uid", "i4"), ("keypoints", "f4", (NKP,)),
     ],
     align=True,
 )
@@ -82,11 +82,34 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's, different file).
+    Two HIP runtimes in one process cannot both own the GPU ("No HIP GPUs are available" in
+    whichever comes second), so when torch is installed we bind to ITS runtime up front --
+    without importing torch -- and torch later finds the same object already mapped."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(libdir, name)
+        if os.path.isfile(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libmmw_hip.so and declare every prototype.  Raises if it is absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_hip_runtime()
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -127,6 +150,9 @@ def load():
         "mmw_profile_get": (C.c_int, [vp, i32, f64p, i64p]),
         "mmw_kernel_name": (C.c_char_p, [i32]),
         "mmw_version": (C.c_char_p, []),
+        "mmw_stats_get": (C.c_int, [vp, vp]),
+        "mmw_stats_reset": (C.c_int, [vp]),
+        "mmw_format_frames": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

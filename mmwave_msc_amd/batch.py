@@ -232,6 +232,14 @@ class SceneBatch:
         return b.download((self.S, slots), SUMMARY_DTYPE)
 
     # -- profiling ------------------------------------------------------------
+    def stats(self) -> np.ndarray:
+        out = np.zeros(8, dtype=np.uint64)
+        self._chk(self.L.mmw_stats_get(self.h, out.ctypes.data))
+        return out
+
+    def stats_reset(self):
+        self._chk(self.L.mmw_stats_reset(self.h))
+
     def profile(self, on: bool):
         self._chk(self.L.mmw_profile_enable(self.h, 1 if on else 0))
 

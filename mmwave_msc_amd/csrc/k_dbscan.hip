@@ -444,6 +444,12 @@ __global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevStat
     if (tid == 0) {
         if (db_n_out) db_n_out[s] = U;
         hdr->need_db = 0;
+        if (st.stats) {  // algorithmic bytes: ring rows in, labels out, new track records + ring rows out
+            atomicAdd(&st.stats[1], (unsigned long long)(64 * U + 4 * U) + (unsigned long long)ncl * (sizeof(TrackRec) + 64ULL * 64ULL));
+            atomicAdd(&st.stats[3], 1ULL);
+            atomicAdd(&st.stats[4], (unsigned long long)U);
+            atomicAdd(&st.stats[7], (unsigned long long)ncl);
+        }
     }
     if (ncl == 0) return;
 
@@ -457,6 +463,8 @@ __global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevStat
         hdr->g_len = 0;
         for (int k = 0; k < MMW_RING_MAX; k++) hdr->g_n[k] = 0;
         hdr->n_tracks = T0 + nspawn;
+        L.misc[4] = hdr->next_uid;
+        hdr->next_uid += nspawn;
         if (err) atomicOr(&hdr->err, err);
     }
     // members of every cluster in ascending point index (rows keep input order, Utils.py:285-287)
@@ -536,6 +544,7 @@ __global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevStat
             rec->n_est = 0.0;
             rec->lifetime = 0.0;
             rec->ring_len = 1;
+            rec->uid = L.misc[4] + c;
             for (int k = 0; k < MMW_RING_MAX; k++) { rec->ring_slot[k] = k; rec->ring_n[k] = 0; }
             rec->ring_n[0] = n;
         }

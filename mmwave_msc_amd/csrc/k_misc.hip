@@ -98,6 +98,31 @@ __global__ __launch_bounds__(1024) void k_feat_scan(DevCfg cfg, DevState st, int
     if (tid == 1023) row_off[S] = part[1023];
 }
 
+// np.argsort(padded[:, 0]) (Utils.py:513) + the gather it drives: a bitonic network over
+// the wave on (x, row) -- ties ordered by row position -- then 5 fp32 stores per lane.
+__device__ inline void sort_rows_store(int lane, double v0, double v1, double v2, double v3, double v4, float *dst)
+{
+    double key = v0;
+    int src = lane;
+    for (int sz = 2; sz <= 64; sz <<= 1) {
+        for (int stride = sz >> 1; stride > 0; stride >>= 1) {
+            const double ok = __shfl_xor(key, stride);
+            const int os = __shfl_xor(src, stride);
+            const bool up = (lane & sz) == 0;          // ascending block
+            const bool lower = (lane & stride) == 0;   // this lane keeps the smaller of the pair
+            const bool other_less = ok < key || (ok == key && os < src);
+            const bool take = (up == lower) ? other_less : !other_less;
+            if (take) { key = ok; src = os; }
+        }
+    }
+    const double s0 = __shfl(v0, src), s1 = __shfl(v1, src), s2 = __shfl(v2, src), s3 = __shfl(v3, src), s4 = __shfl(v4, src);
+    dst[lane * 5 + 0] = (float)s0;
+    dst[lane * 5 + 1] = (float)s1;
+    dst[lane * 5 + 2] = (float)s2;
+    dst[lane * 5 + 3] = (float)s3;
+    dst[lane * 5 + 4] = (float)s4;
+}
+
 // One wave per (eligible track, ring frame): lane r owns row r of the 64-row frame.
 __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const int32_t *__restrict__ row_off,
                                                   float *__restrict__ feat, int32_t *__restrict__ owner, int cap_rows)
@@ -131,30 +156,32 @@ __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const
                     v4 = ((p[7] - 0) - cfg.intensity_mu) / cfg.intensity_std;  // Utils.py:502
                 }
             }
-            // np.argsort(padded[:, 0]) (Utils.py:513): bitonic network over the wave on (x, row) --
-            // ties ordered by row position.
-            double key = v0;
-            int src = lane;
-            for (int sz = 2; sz <= 64; sz <<= 1) {
-                for (int stride = sz >> 1; stride > 0; stride >>= 1) {
-                    const double ok = __shfl_xor(key, stride);
-                    const int os = __shfl_xor(src, stride);
-                    const bool up = (lane & sz) == 0;          // ascending block
-                    const bool lower = (lane & stride) == 0;   // this lane keeps the smaller of the pair
-                    const bool other_less = ok < key || (ok == key && os < src);
-                    const bool take = (up == lower) ? other_less : !other_less;
-                    if (take) { key = ok; src = os; }
-                }
-            }
-            const double s0 = __shfl(v0, src), s1 = __shfl(v1, src), s2 = __shfl(v2, src), s3 = __shfl(v3, src), s4 = __shfl(v4, src);
-            dst[lane * 5 + 0] = (float)s0;
-            dst[lane * 5 + 1] = (float)s1;
-            dst[lane * 5 + 2] = (float)s2;
-            dst[lane * 5 + 3] = (float)s3;
-            dst[lane * 5 + 4] = (float)s4;
+            sort_rows_store(lane, v0, v1, v2, v3, v4, dst);
         }
         row++;
     }
+}
+
+// Utils.format_single_frame (+ relative_coordinates) on caller-provided frames:
+// frames[B][ring][64][8] fp64, counts[B][ring] (rows valid, <0 = frame absent), ref[B][2].
+__global__ __launch_bounds__(256) void k_format_frames(DevCfg cfg, const double *__restrict__ frames, const int32_t *__restrict__ counts,
+                                                       const double *__restrict__ ref, float *__restrict__ feat, int B)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ring = cfg.ring;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= B * ring) return;
+    const int b = item / ring;
+    const int m = min(counts[item], 64);
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+    if (lane < m) {
+        const double *p = frames + ((size_t)item * 64 + lane) * 8;
+        v0 = p[0] - ref[b * 2];
+        v1 = p[1] - ref[b * 2 + 1];
+        v2 = p[2] - 0;
+        v3 = p[6] - 0;
+        v4 = ((p[7] - 0) - cfg.intensity_mu) / cfg.intensity_std;
+    }
+    sort_rows_store(lane, v0, v1, v2, v3, v4, feat + (size_t)item * 64 * 5);
 }
 
 __global__ void k_set_kp(DevCfg cfg, DevState st, const float *__restrict__ kp, const int32_t *__restrict__ owner, int n_rows)
@@ -194,6 +221,7 @@ __global__ void k_export(DevCfg cfg, DevState st, mmw_track_record *__restrict__
     o->point_num = rec->point_num;
     o->is_static = rec->is_static;
     o->ring_len = rec->ring_len;
+    o->uid = rec->uid;
     for (int k = 0; k < MMW_RING_MAX; k++) o->ring_n[k] = k < rec->ring_len ? rec->ring_n[k] : 0;
     for (int e = 0; e < MMW_NKP; e++) o->keypoints[e] = rec->kp[e];
 }
@@ -229,6 +257,7 @@ __global__ void k_reset(DevCfg cfg, DevState st)
         h->need_db = 0;
         h->err = 0;
         h->db_u = 0;
+        h->next_uid = 0;
     }
     const size_t tot = (size_t)cfg.n_scenes * cfg.t_cap;
     for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);
@@ -245,6 +274,11 @@ void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hi
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st)
 {
     hipLaunchKernelGGL(k_features, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, s, row_off, feat, owner, cap);
+}
+void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t *counts, const double *ref, float *feat, int B, hipStream_t st)
+{
+    if (B <= 0) return;
+    hipLaunchKernelGGL(k_format_frames, dim3((B * cfg.ring + 3) / 4), dim3(256), 0, st, cfg, frames, counts, ref, feat, B);
 }
 void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st)
 {

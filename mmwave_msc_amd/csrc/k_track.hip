@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
     TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
     int T = hdr->n_tracks;
     int err = 0;
+    if (tid == 0) L.misc[2] = T;
 
     // ---- stage points: coalesced read of the row-major block, SoA in LDS ----
     for (int e = tid; e < n * 8; e += kThreads) {
@@ -595,6 +596,15 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         for (int e = tid; e < nun * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[e >> 3] * 8 + (e & 7)];
     }
     if (err) atomicOr(&hdr->err, err);
+    if (tid == 0 && st.stats) {
+        // algorithmic bytes of this scene-frame: points in, assoc out,
+        // track records read+written, unassigned rows appended to the ring
+        const int Tin = L.misc[2];
+        atomicAdd(&st.stats[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun));
+        atomicAdd(&st.stats[2], 1ULL);
+        atomicAdd(&st.stats[5], (unsigned long long)Tin);
+        atomicAdd(&st.stats[6], (unsigned long long)n * (unsigned long long)Tin);
+    }
 }
 
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,

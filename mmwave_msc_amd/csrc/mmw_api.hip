@@ -24,6 +24,7 @@ void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int3
 void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st);
+void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t *counts, const double *ref, float *feat, int B, hipStream_t st);
 void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st);
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
@@ -47,6 +48,7 @@ struct mmw_ctx {
     // internal scratch
     int32_t *d_row_off = nullptr;     // [S+1]
     float *d_posture = nullptr;
+    unsigned long long *d_stats = nullptr;
     // host-convenience staging (lazy)
     double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;
     int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr;
@@ -195,9 +197,12 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.g_ring, S * (size_t)ring * max_pts * 8 * sizeof(double));
     ALLOC(c->d_posture, MMW_NKP * sizeof(float));
     ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
+    ALLOC(c->d_stats, 8 * sizeof(unsigned long long));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
+    c->st.stats = c->d_stats;
     if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
@@ -218,7 +223,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -376,6 +381,15 @@ int mmw_features(mmw_ctx *c, float *feat, int32_t *owner, int32_t cap_rows, int3
     return MMW_OK;
 }
 
+int mmw_format_frames(mmw_ctx *c, const double *frames, const int32_t *counts, const double *ref, float *feat, int32_t n_items)
+{
+    if (!c || n_items < 0 || (n_items > 0 && (!frames || !counts || !ref || !feat))) return fail(c, MMW_E_ARG, "mmw_format_frames: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_format_frames(c->dc, frames, counts, ref, feat, n_items, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
 int mmw_set_keypoints(mmw_ctx *c, const float *kp, const int32_t *owner, int32_t n_rows)
 {
     if (!c || (n_rows > 0 && (!kp || !owner)) || n_rows < 0) return fail(c, MMW_E_ARG, "mmw_set_keypoints: bad argument");
@@ -496,6 +510,20 @@ int mmw_track_table(mmw_ctx *c, mmw_track_summary *table, int32_t slots, int32_t
     launch_table(c->dc, c->st, table, slots, scene_base, c->stream);
     prof_end(c, ep);
     HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_stats_get(mmw_ctx *c, uint64_t *out)
+{
+    if (!c || !out) return MMW_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+int mmw_stats_reset(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(uint64_t), c->stream));
     return MMW_OK;
 }
 

@@ -48,7 +48,8 @@ struct SceneHdr {
     int32_t need_db;               // set by the track kernel: run apply_DBscan this frame
     int32_t err;
     int32_t db_u;
-    int32_t pad[3];
+    int32_t next_uid;              // TrackBuffer.next_track_id (Tracking.py:509,588)
+    int32_t pad[2];
 };
 static_assert(sizeof(SceneHdr) == 64, "SceneHdr");
 
@@ -66,7 +67,7 @@ struct TrackRec {
     int32_t point_num;
     int32_t is_static;
     int32_t ring_len;
-    int32_t pad0;
+    int32_t uid;                   // creation ordinal inside the scene (stable identity for views)
     int32_t ring_n[MMW_RING_MAX];
     int32_t ring_slot[MMW_RING_MAX];
     float kp[MMW_NKP];
@@ -81,6 +82,7 @@ struct DevState {
     double *trk_ring;     // [S][t_cap][ring][ring_rows][8]
     double *g_ring;       // [S][ring][max_pts][8]
     const float *default_posture;  // [57]
+    unsigned long long *stats;     // [8] algorithmic-byte / work counters (see mmw_stats_get)
 };
 
 __host__ __device__ inline size_t trk_ring_stride_track(const DevCfg &c) { return (size_t)c.ring * c.ring_rows * 8; }

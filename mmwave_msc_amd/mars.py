@@ -1,0 +1,123 @@
+"""MARS 19-keypoint regressor on PyTorch-ROCm (inference).
+
+Architecture = the reference's Keras models (src/train.py): `define_CNN_3D`
+(71-106) for 3-frame inputs (B,3,8,8,5) -- the variant `estimate_posture` feeds
+(Tracking.py:718-734, Utils.py:517-520) -- and `define_CNN` (33-68) for
+(B,8,8,5) when FB_FRAMES_BATCH == 0.  Dropout layers are identity at inference;
+BatchNormalization uses Keras' default epsilon 1e-3.
+
+Weights use Keras conventions on disk (dict / .npz, keys below) and are laid out
+for the GPU at load time: conv kernels (kd,kh,kw,in,out) -> (out,in,kd,kh,kw);
+Dense-1 rows are re-ordered from Keras' channels-last flatten (d,h,w,c) to the
+channels-first flatten (c,d,h,w) so no activation transpose is needed, and both
+BatchNorms are folded into the following Dense layer (exact in real arithmetic,
+~1e-6 in fp32).  The reference's MARS.h5 is not in its repo; `.npz` files with the
+same tensors drop in (see INTEGRATION.md for the h5 -> npz one-liner).
+
+Keys: conv1_w conv1_b conv2_w conv2_b bn1_gamma bn1_beta bn1_mean bn1_var
+      dense1_w dense1_b bn2_gamma bn2_beta bn2_mean bn2_var dense2_w dense2_b
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+BN_EPS = 1e-3
+N_KEYPOINTS = 57
+
+
+def random_keras_weights(seed: int = 0, frames: int = 3) -> dict:
+    """Seeded random weights with Keras shapes (Glorot-like scales, non-trivial BN stats)."""
+    rng = np.random.default_rng(seed)
+    three_d = frames > 1
+    k = (3, 3, 3) if three_d else (3, 3)
+    flat = (frames if three_d else 1) * 64 * 32
+    hidden = 512 * (3 if three_d else 1)
+
+    def glorot(shape, fan_in, fan_out):
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    rf = int(np.prod(k))
+    w = {
+        "conv1_w": glorot(k + (5, 16), rf * 5, rf * 16), "conv1_b": rng.normal(0, 0.05, 16).astype(np.float32),
+        "conv2_w": glorot(k + (16, 32), rf * 16, rf * 32), "conv2_b": rng.normal(0, 0.05, 32).astype(np.float32),
+        "bn1_gamma": rng.uniform(0.5, 1.5, 32).astype(np.float32), "bn1_beta": rng.normal(0, 0.1, 32).astype(np.float32),
+        "bn1_mean": rng.normal(0.2, 0.1, 32).astype(np.float32), "bn1_var": rng.uniform(0.05, 0.5, 32).astype(np.float32),
+        "dense1_w": glorot((flat, hidden), flat, hidden), "dense1_b": rng.normal(0, 0.05, hidden).astype(np.float32),
+        "bn2_gamma": rng.uniform(0.5, 1.5, hidden).astype(np.float32), "bn2_beta": rng.normal(0, 0.1, hidden).astype(np.float32),
+        "bn2_mean": rng.normal(0.2, 0.1, hidden).astype(np.float32), "bn2_var": rng.uniform(0.05, 0.5, hidden).astype(np.float32),
+        "dense2_w": glorot((hidden, N_KEYPOINTS), hidden, N_KEYPOINTS), "dense2_b": rng.normal(0, 0.05, N_KEYPOINTS).astype(np.float32),
+    }
+    return w
+
+
+class MarsCNN(nn.Module):
+    def __init__(self, frames: int = 3):
+        super().__init__()
+        self.frames = int(frames)
+        self.three_d = self.frames > 1
+        conv = nn.Conv3d if self.three_d else nn.Conv2d
+        self.conv1 = conv(5, 16, 3, padding=1)
+        self.conv2 = conv(16, 32, 3, padding=1)
+        flat = (self.frames if self.three_d else 1) * 64 * 32
+        hidden = 512 * (3 if self.three_d else 1)
+        self.dense1 = nn.Linear(flat, hidden)   # BN1 folded in
+        self.dense2 = nn.Linear(hidden, N_KEYPOINTS)  # BN2 folded in
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @classmethod
+    def from_keras_weights(cls, w: dict) -> "MarsCNN":
+        three_d = np.asarray(w["conv1_w"]).ndim == 5
+        flat = np.asarray(w["dense1_w"]).shape[0]
+        frames = flat // (64 * 32) if three_d else 1
+        m = cls(frames if three_d else 1)
+        f64 = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
+        perm = (4, 3, 0, 1, 2) if three_d else (3, 2, 0, 1)
+        m.conv1.weight.copy_(torch.from_numpy(f64["conv1_w"].transpose(perm).copy()).float())
+        m.conv1.bias.copy_(torch.from_numpy(f64["conv1_b"]).float())
+        m.conv2.weight.copy_(torch.from_numpy(f64["conv2_w"].transpose(perm).copy()).float())
+        m.conv2.bias.copy_(torch.from_numpy(f64["conv2_b"]).float())
+        # BN1 (per channel c) folded into dense1, rows re-ordered (d,h,w,c) -> (c,d,h,w)
+        a1 = f64["bn1_gamma"] / np.sqrt(f64["bn1_var"] + BN_EPS)
+        c1 = f64["bn1_beta"] - a1 * f64["bn1_mean"]
+        spatial = flat // 32
+        w1 = f64["dense1_w"].reshape(spatial, 32, -1)            # [s, c, out]
+        b1 = f64["dense1_b"] + np.einsum("c,sco->o", c1, w1)
+        w1 = (w1 * a1[None, :, None]).transpose(1, 0, 2).reshape(flat, -1)  # [(c,s), out]
+        m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
+        m.dense1.bias.copy_(torch.from_numpy(b1).float())
+        a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
+        c2 = f64["bn2_beta"] - a2 * f64["bn2_mean"]
+        w2 = f64["dense2_w"]
+        m.dense2.weight.copy_(torch.from_numpy((w2 * a2[:, None]).T.copy()).float())
+        m.dense2.bias.copy_(torch.from_numpy(f64["dense2_b"] + c2 @ w2).float())
+        return m
+
+    @classmethod
+    def from_npz(cls, path: str) -> "MarsCNN":
+        z = np.load(path)
+        return cls.from_keras_weights({k: z[k] for k in z.files})
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""
+        if self.three_d:
+            h = x.permute(0, 4, 1, 2, 3)
+        else:
+            h = x.permute(0, 3, 1, 2)
+        h = F.relu(self.conv1(h))
+        h = F.relu(self.conv2(h))
+        h = F.relu(self.dense1(h.flatten(1)))
+        return self.dense2(h)
+
+    @torch.no_grad()
+    def predict_numpy(self, feat: np.ndarray) -> np.ndarray:
+        dev = next(self.parameters()).device
+        x = torch.from_numpy(np.ascontiguousarray(feat, dtype=np.float32)).to(dev)
+        return self(x).float().cpu().numpy()
+
+    def predict(self, feat, verbose=0):  # Keras-style entry used by estimate_posture (Tracking.py:732)
+        return self.predict_numpy(np.asarray(feat))

@@ -1,0 +1,197 @@
+"""Reference-shaped point-cloud utilities (`src/Utils.py` hot subset) on the GPU:
+
+    normalize_data(detObj)            Utils.py:342-434   -> mmw_normalize
+    apply_DBscan(pointcloud, ...)     Utils.py:250-291   -> mmw_dbscan (BallTree-faithful)
+    format_single_frame(track_cloud)  Utils.py:468-520   -> mmw_format_frames
+    relative_coordinates(...)         Utils.py:437-465   (host glue: a subtraction per frame)
+    OfflineManager                    Utils.py:53-177    (CSV frame iterator incl. its 40-frame quirk)
+    RingBuffer                        Utils.py:10-50
+
+The numeric functions need libmmw_hip and a gfx950 device; there is no CPU path.
+"""
+from __future__ import annotations
+
+import csv
+import os
+from collections import deque
+
+import numpy as np
+
+from . import constants as const
+from .batch import SceneBatch
+
+_UTIL_MAX_PTS = 960   # with ring 2: DBSCAN clouds up to 1920 points (the BallTree emulation's limit)
+_ctx_cache = {}
+
+
+def _util_ctx(**cfg_over) -> SceneBatch:
+    """A 1-scene context used by the stateless helpers (cached per config)."""
+    key = tuple(sorted(cfg_over.items()))
+    sb = _ctx_cache.get(key)
+    if sb is None:
+        kw = dict(fb_frames_batch=1)
+        kw.update(cfg_over)
+        ring = kw["fb_frames_batch"] + 1
+        sb = SceneBatch(const.to_config(**kw), 1, min(_UTIL_MAX_PTS, 1920 // ring))
+        _ctx_cache[key] = sb
+    return sb
+
+
+class RingBuffer:
+    """Fixed-size FIFO (reference Utils.py:10-50)."""
+
+    def __init__(self, size, init_val=None):
+        self.size = size
+        self.buffer = deque(maxlen=size)
+        self.append(0 if init_val is None else init_val)
+
+    def append(self, item):
+        self.buffer.append(item)
+
+    def get_max(self):
+        return np.max(self.buffer)
+
+    def get_mean(self):
+        return np.mean(self.buffer)
+
+
+class OfflineManager:
+    """Frame iterator over logged CSV shards `<path>/<k>.csv` (k = 1, 2, ...), one row
+    per detected point: frame, x, y, z, doppler, peakVal, posix_ms (DataLogging.py:60-82).
+
+    Behaviour kept from the reference (Utils.py:86-166), including its refill quirk: a
+    refill stops right after the FIRST row of the FB_READ_BUFFER_SIZE-th new frame, so that
+    frame (40, 79, 118, ...) is delivered with a single point and the rest of its rows are
+    parsed into a dict entry nobody asks for.
+    """
+
+    _KEYS = ("x", "y", "z", "doppler", "peakVal", "posix")
+
+    def __init__(self, experiment_path):
+        self.experiment_path = experiment_path
+        self.frame_count = 0
+        self.pointer = [0, 1]   # [rows already consumed in the current shard, shard number]
+        self.read_next_frames()
+
+    def read_next_frames(self):
+        self.pointclouds = {}
+        self.last_frame = None
+        want = const.FB_READ_BUFFER_SIZE
+        while len(self.pointclouds) < want:
+            path = os.path.join(self.experiment_path, f"{self.pointer[1]}.csv")
+            if not os.path.isfile(path):
+                return
+            stopped_inside = False
+            with open(path, "r") as fh:
+                for row_no, row in enumerate(csv.reader(fh)):
+                    if row_no < self.pointer[0]:
+                        continue
+                    frame = int(row[0])
+                    vals = [float(row[1]), float(row[2]), float(row[3]), float(row[4]), float(row[5]), int(row[6])]
+                    slot = self.pointclouds.get(frame)
+                    if slot is None:
+                        self.pointclouds[frame] = {k: [v] for k, v in zip(self._KEYS, vals)}
+                    else:
+                        for k, v in zip(self._KEYS, vals):
+                            slot[k].append(v)
+                    self.last_frame = frame
+                    if len(self.pointclouds) >= want:
+                        self.pointer[0] = row_no + 1
+                        stopped_inside = True
+                        break
+            if not stopped_inside:
+                self.pointer = [0, self.pointer[1] + 1]
+
+    def get_data(self):
+        self.frame_count += 1
+        if self.frame_count > self.last_frame:
+            self.read_next_frames()
+        data = self.pointclouds.get(self.frame_count)
+        return (data is not None), self.frame_count, data
+
+    def is_finished(self):
+        return self.last_frame is None
+
+
+def altered_EuclideanDist(p1, p2):
+    """The clustering metric (Utils.py:222-247); the GPU kernels evaluate the same
+    expression in the same order (csrc/mmw_math.hpp: alt_dist)."""
+    w = 1 - ((p1[1] + p2[1]) / 2) * const.DB_RANGE_WEIGHT
+    return w * ((p1[0] - p2[0]) ** 2 + (p1[1] - p2[1]) ** 2 + const.DB_Z_WEIGHT * ((p1[2] - p2[2]) ** 2))
+
+
+def dbscan_labels(pointcloud, eps=None, min_samples=None) -> np.ndarray:
+    """sklearn-compatible labels of the reference's DBSCAN call (Utils.py:272-278)."""
+    pc = np.asarray(pointcloud, dtype=np.float64).reshape(-1, 8)
+    n = pc.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int32)
+    sb = _util_ctx()
+    if n > sb.UM:
+        raise ValueError(f"apply_DBscan on {n} points: the GPU BallTree emulation holds at most {sb.UM}")
+    pts = np.zeros((1, n, 8))
+    pts[0] = pc
+    labels, _ = sb.dbscan_host(pts, np.array([n], np.int32),
+                               eps=const.DB_EPS if eps is None else eps,
+                               min_samples=const.DB_MIN_SAMPLES_MIN if min_samples is None else min_samples)
+    return labels[0, :n].copy()
+
+
+def apply_DBscan(pointcloud, eps=None, min_samples=None):
+    """List of clusters (ascending label, rows in input order), noise dropped (Utils.py:281-291)."""
+    pc = np.asarray(pointcloud)
+    labels = dbscan_labels(pc, eps, min_samples)
+    return [[pc[i] for i in np.nonzero(labels == k)[0]] for k in range(int(labels.max()) + 1 if len(labels) else 0)]
+
+
+def normalize_data(detObj) -> np.ndarray:
+    """Sensor frame -> room frame + scene filter (Utils.py:342-434): dict of equal-length
+    lists x,y,z,doppler,peakVal -> (N', 8) float64 [x,y,z,vx,vy,vz,doppler,peakVal]."""
+    raw = np.vstack((detObj["x"], detObj["y"], detObj["z"], detObj["doppler"], detObj["peakVal"])).T.astype(np.float64)
+    n = raw.shape[0]
+    if n == 0:
+        return np.empty((0, 8), dtype="float")
+    sb = _util_ctx()
+    if n > sb.max_pts:
+        raise ValueError(f"normalize_data on {n} points (limit {sb.max_pts})")
+    buf = np.zeros((1, sb.max_pts, 5))
+    buf[0, :n] = raw
+    pts, n_out = sb.normalize_host(buf, np.array([n], np.int32))
+    return pts[0, : n_out[0]].copy()
+
+
+def relative_coordinates(absolute_coords, reference):
+    """x,y relative to `reference` for every frame (Utils.py:437-465).  Host glue."""
+    shift = np.zeros(8)
+    shift[0], shift[1] = reference[0], reference[1]
+    return [np.asarray(frame, dtype=np.float64) - shift for frame in absolute_coords]
+
+
+def format_single_frame(track_cloud, mean=None, std_dev=None) -> np.ndarray:
+    """MARS feature map of one track (Utils.py:468-520): per frame take columns
+    (x,y,z,doppler,intensity), normalise intensity, pad/cut to 64 rows, sort by x,
+    reshape to (FB_FRAMES_BATCH+1, 8, 8, 5) -- (8, 8, 5) when FB_FRAMES_BATCH == 0."""
+    ring = const.FB_FRAMES_BATCH + 1
+    frames = list(track_cloud)
+    if len(frames) > ring:
+        raise IndexError(f"{len(frames)} frames for a feature map of {ring}")
+    over = dict(fb_frames_batch=const.FB_FRAMES_BATCH)
+    if mean is not None:
+        over["intensity_mu"] = float(mean)
+    if std_dev is not None:
+        over["intensity_std"] = float(std_dev)
+    sb = _util_ctx(**over)
+    rows = np.zeros((1, ring, 64, 8))
+    counts = np.zeros((1, ring), dtype=np.int32)
+    for k, fr in enumerate(frames):
+        fr = np.asarray(fr, dtype=np.float64).reshape(-1, 8)
+        m = min(64, fr.shape[0])
+        rows[0, k, :m] = fr[:m]
+        counts[0, k] = m
+    b_rows = sb.buf("ff_rows", rows.nbytes).upload(rows)
+    b_cnt = sb.buf("ff_cnt", counts.nbytes).upload(counts)
+    b_ref = sb.buf("ff_ref", 16).upload(np.zeros(2))
+    b_out = sb.buf("ff_out", ring * 64 * 5 * 4)
+    sb._chk(sb.L.mmw_format_frames(sb.h, b_rows.ptr, b_cnt.ptr, b_ref.ptr, b_out.ptr, 1))
+    out = b_out.download((ring, 8, 8, 5), np.float32)
+    return out[0] if ring == 1 else out

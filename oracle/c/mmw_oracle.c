@@ -901,6 +901,43 @@ int orc_max_threads(void)
 #endif
 }
 
+int orc_batch_run_f32(orc_scene **scenes, int n_scenes, int max_pts, int n_frames, const float *pts,
+                      const int32_t *n, const double *dt, int n_threads)
+{
+    int err = 0;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : omp_get_max_threads())
+#endif
+    {
+        double *buf = (double *)malloc(sizeof(double) * 8 * (size_t)max_pts);
+        int32_t *assoc = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_pts);
+        int32_t *labels = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_pts * ORC_RING_MAX);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int s = 0; s < n_scenes; s++) {
+            for (int f = 0; f < n_frames; f++) {
+                const float *src = pts + ((size_t)f * n_scenes + s) * (size_t)max_pts * 8;
+                const int cnt = n[(size_t)f * n_scenes + s];
+                int32_t dbn;
+                int rc;
+                if (cnt <= 0) continue; /* offline_main.py:56 */
+                for (int e = 0; e < cnt * 8; e++) buf[e] = (double)src[e];
+                rc = orc_track_frame(scenes[s], buf, cnt, dt[(size_t)f * n_scenes + s], assoc, labels, &dbn);
+                if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+                    err = rc;
+                }
+            }
+        }
+        free(buf); free(assoc); free(labels);
+    }
+    return err;
+}
+
 int orc_batch_track(orc_scene **scenes, int n_scenes, int max_pts, const double *pts,
                     const int32_t *n, const double *dt, int32_t *assoc, int32_t *db_labels,
                     int32_t *db_n, int n_threads)

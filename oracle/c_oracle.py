@@ -122,6 +122,7 @@ def lib():
     L.orc_np_pairwise_sum.restype = C.c_double
     L.orc_batch_track.argtypes = [C.POINTER(vp), C.c_int, C.c_int, f64p, i32p, f64p, i32p, i32p, i32p, C.c_int]
     L.orc_max_threads.restype = C.c_int
+    L.orc_batch_run_f32.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, f32p, i32p, f64p, C.c_int]
     _lib = L
     return L
 
@@ -289,6 +290,19 @@ class OracleBatch:
         if rc:
             raise RuntimeError(f"orc_batch_track failed rc={rc}")
         return self.assoc, self.labels, self.db_n
+
+
+def batch_run_f32(batch: "OracleBatch", pts: np.ndarray, n: np.ndarray, dt: np.ndarray, threads: int = 0):
+    """All frames of all scenes, scene-major (each thread owns whole scenes).  pts[F,S,N,8] float32."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    dt = np.ascontiguousarray(dt, dtype=np.float64)
+    F, S = pts.shape[0], pts.shape[1]
+    assert S == batch.S and pts.shape[2] == batch.max_pts and n.shape == (F, S) and dt.shape == (F, S)
+    rc = batch.L.orc_batch_run_f32(batch.handles, S, batch.max_pts, F, _p(pts, C.c_float), _p(n, C.c_int32),
+                                   _p(dt, C.c_double), int(threads))
+    if rc:
+        raise RuntimeError(f"orc_batch_run_f32 failed rc={rc}")
 
 
 def max_threads() -> int:

@@ -1,0 +1,58 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol
+include/mmw.h declares (no compute call is made here)."""
+import ctypes as C
+import os
+import re
+
+from mmwave_msc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mmw.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmw_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_is_built_and_exports_every_declared_symbol():
+    assert os.path.isfile(_lib.LIB_PATH), "libmmw_hip.so missing: run __graft_entry__.build()"
+    L = C.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/mmw.h but not exported"
+    assert sorted(declared) == sorted(_lib.EXPORTS), "python binding and header disagree"
+
+
+def test_config_struct_matches_header_layout():
+    L = _lib.load()
+    cfg = _lib.default_config()
+    # defaults = reference constants.py
+    assert (cfg.fb_frames_batch, cfg.db_min_samples, cfg.tr_max_tracks, cfg.dim_x) == (2, 35, 4, 9)
+    assert (cfg.db_eps, cfg.db_z_weight, cfg.db_range_weight, cfg.tr_gate) == (0.3, 0.4, 0.03, 4.5)
+    assert list(cfg.kf_spread_lim) == [0.2, 0.2, 2, 1.2, 1.2, 0.2]
+    assert abs(cfg.default_posture[22] - 1.5513) < 1e-6 and abs(cfg.default_posture[56] - 0.0312) < 1e-6
+    import numpy as np
+    assert cfg.tilt_cos == float(np.cos(np.radians(-5))) and cfg.tilt_sin == float(np.sin(np.radians(-5)))
+    assert L.mmw_version().startswith(b"mmw-hip")
+    assert C.sizeof(_lib.MmwConfig) == 8 * 4 + 24 * 8 + 57 * 4 + 4  # 8 ints, 24 doubles, 57 floats, tail pad
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_args():
+    import torch
+    L = _lib.load()
+    cfg = _lib.default_config()
+    h = C.c_void_p()
+    assert L.mmw_create(C.byref(cfg), 1, 4096, 0, C.byref(h)) == _lib.E_ARG  # max_pts limit
+    assert L.mmw_create(C.byref(cfg), 1, 1000, 0, C.byref(h)) == _lib.E_ARG  # ring*max_pts > 1920
+    if not torch.cuda.is_available():
+        rc = L.mmw_create(C.byref(cfg), 1, 256, 0, C.byref(h))
+        assert rc in (_lib.E_NODEVICE, _lib.E_HIP) and not h.value
+        assert L.mmw_last_error(None)
+
+
+def test_track_record_dtype_matches_c_struct():
+    # x9 P81 c6 mn6 mx6 sp6 gd36 n_est lifetime = 152 doubles; 8 ints; 57 floats (+pad to 8)
+    assert _lib.TRACK_DTYPE.itemsize == 152 * 8 + 8 * 4 + 57 * 4 + 4
+    assert _lib.SUMMARY_DTYPE.itemsize == 5 * 4 + 4 + (9 + 6 + 57) * 4

@@ -1,0 +1,129 @@
+"""GPU tests of the reference-shaped host surface: TrackBuffer/BatchedData views, the
+headless offline loop, the Utils helpers, and the MARS CNN (keypoints vs the fp64
+numpy oracle within 1e-4 m, the tolerance stated in SURVEY.md §8c)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests._golden import GOLDEN, assert_feat_equal, close64, load_scenario
+
+pytestmark = pytest.mark.gpu
+KP_TOL = 1e-4
+
+
+def test_trackbuffer_dropin_matches_golden():
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    g = load_scenario("n200_k2")
+    tb, batch = TrackBuffer(max_pts=256), BatchedData()
+    assert tb.effective_tracks == [] and len(batch.effective_data) == 0
+    for f in range(16):
+        c = int(g["cnt"][f])
+        tb.dt = float(g["dt"][f])
+        tb.track(g["pts"][f, :c].astype(np.float64), batch)
+        assert np.array_equal(tb.last_assoc, g["assoc"][f, :c])
+        nt = int(g["n_tracks"][f])
+        tracks = tb.effective_tracks
+        assert len(tracks) == nt
+        for j, t in enumerate(tracks):
+            w = g["tracks"][f, j]
+            assert t.state.x.shape == (9, 1) and close64(t.state.x[:, 0], w["x"]) and close64(t.state.P, w["P"])
+            assert np.array_equal(t.cluster.centroid, w["centroid"]) and t.cluster.point_num == w["point_num"]
+            assert t.cluster.status == bool(w["is_static"]) and t.lifetime == w["lifetime"]
+            assert len(t.batch.buffer) == w["ring_len"]
+            assert t.batch.effective_data.shape == (int(w["ring_n"].sum()), 8)
+            assert t.color.shape == (3,)
+        assert len(batch.effective_data) == int(g["ring_n"][f].sum())
+        assert [len(fr) for fr in batch.buffer] == list(g["ring_n"][f, : g["ring_len"][f]])
+    # full-fidelity rings in the single-scene face: first spawned track keeps every cluster row
+    assert tb.effective_tracks[0].batch.effective_data.shape[0] > 64
+    tb.close()
+
+
+def test_offline_loop_matches_reference_run(tmp_path):
+    from mmwave_msc_amd.offline_main import offline_main
+    z = np.load(os.path.join(GOLDEN, "offline.npz"))
+    (tmp_path / "1.csv").write_text(str(z["csv1"]))
+    (tmp_path / "2.csv").write_text(str(z["csv2"]))
+    ntr, dts = [], []
+    tb = offline_main(str(tmp_path), on_frame=lambda t, det, k: (ntr.append(len(t.effective_tracks)), dts.append(t.dt)), max_pts=64)
+    assert np.array_equal(np.array(ntr), z["n_tracks"])
+    assert np.allclose(np.array(dts), z["dt"], rtol=0, atol=0)
+    tb.close()
+
+
+def test_utils_helpers_against_golden_and_oracle():
+    from mmwave_msc_amd import utils
+    from oracle import c_oracle as co
+    z = np.load(os.path.join(GOLDEN, "dbscan.npz"))
+    for n in (61, 241, 700, 1536):
+        pts = z[f"pts_{n}"].astype(np.float64)
+        clusters = utils.apply_DBscan(pts)
+        assert [len(c) for c in clusters] == list(z[f"sizes_{n}"])
+        lab = utils.dbscan_labels(pts, min_samples=8)
+        assert np.array_equal(lab, z[f"labels_{n}_8"])
+        if clusters:
+            first = np.nonzero(z[f"labels_{n}_35"] == 0)[0]
+            assert np.array_equal(np.array(clusters[0]), pts[first])
+    zn = np.load(os.path.join(GOLDEN, "normalize.npz"))
+    raw = zn["raw"]
+    det = {"x": list(raw[:, 0]), "y": list(raw[:, 1]), "z": list(raw[:, 2]), "doppler": list(raw[:, 3]), "peakVal": list(raw[:, 4])}
+    out = utils.normalize_data(det)
+    assert out.shape == zn["out"].shape and np.allclose(out, zn["out"], rtol=0, atol=1e-12)
+    # format_single_frame(relative_coordinates(...)) vs the oracle's feature map of a live track
+    g = load_scenario("n256_k4")
+    sc = co.OracleScene(co.default_config(), 256)
+    for f in range(6):
+        sc.track(g["pts"][f, : g["cnt"][f]].astype(np.float64), float(g["dt"][f]))
+    feat, owner = sc.features()
+    rec = sc.tracks()[0]
+    frames = [sc.track_ring_frame(0, k) for k in range(rec["ring_len"])]
+    mine = utils.format_single_frame(utils.relative_coordinates(frames, rec["centroid"][:2]))
+    assert mine.shape == (3, 8, 8, 5)
+    assert_feat_equal(mine[None], feat[:1])
+
+
+@pytest.mark.parametrize("frames", [3, 1])
+def test_mars_cnn_keypoints_vs_fp64_oracle(frames):
+    import torch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from oracle.mars_np import mars_forward_np
+    w = random_keras_weights(seed=3, frames=frames)
+    model = MarsCNN.from_keras_weights(w).to("cuda:0")
+    rng = np.random.default_rng(1)
+    shape = (257, 3, 8, 8, 5) if frames == 3 else (257, 8, 8, 5)
+    x = rng.normal(0, 0.4, size=shape).astype(np.float32)
+    x[:, ..., 40:, :] = 0 if frames == 1 else x[:, ..., 40:, :]
+    with torch.no_grad():
+        y = model(torch.from_numpy(x).to("cuda:0")).float().cpu().numpy()
+    ref = mars_forward_np(w, x)
+    assert y.shape == (257, 57)
+    assert np.abs(y - ref).max() <= KP_TOL, np.abs(y - ref).max()
+    assert np.abs(y - ref).max() <= KP_TOL * max(1.0, np.abs(ref).max())
+
+
+def test_estimate_posture_end_to_end():
+    """track -> features (GPU) -> CNN (GPU) -> track.keypoints, against oracle features + fp64 CNN."""
+    import torch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    from oracle import c_oracle as co
+    from oracle.mars_np import mars_forward_np
+    g = load_scenario("n256_k4")
+    w = random_keras_weights(seed=5, frames=3)
+    model = MarsCNN.from_keras_weights(w).to("cuda:0")
+    tb, batch = TrackBuffer(max_pts=256), BatchedData()
+    sc = co.OracleScene(co.default_config(), 256)
+    for f in range(8):
+        c = int(g["cnt"][f])
+        tb.dt = float(g["dt"][f])
+        tb.track(g["pts"][f, :c].astype(np.float64), batch)
+        tb.estimate_posture(model)
+        sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
+        feat, owner = sc.features()
+        ref = mars_forward_np(w, feat)
+        tracks = tb.effective_tracks
+        assert len(tracks) == len(owner)
+        for i, j in enumerate(owner):
+            assert np.abs(tracks[j].keypoints - ref[i]).max() <= KP_TOL
+    tb.close()

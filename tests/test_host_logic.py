@@ -1,0 +1,86 @@
+"""Host-side logic that needs no GPU: the CSV frame iterator (incl. the reference's
+refill quirk), the config surface, scene sharding, the synthetic generator."""
+import os
+
+import numpy as np
+
+from tests._golden import GOLDEN
+
+
+def test_offline_manager_matches_reference_sequence(tmp_path):
+    from mmwave_msc_amd import constants as const
+    from mmwave_msc_amd.utils import OfflineManager
+    z = np.load(os.path.join(GOLDEN, "offline.npz"))
+    (tmp_path / "1.csv").write_text(str(z["csv1"]))
+    (tmp_path / "2.csv").write_text(str(z["csv2"]))
+    assert const.FB_READ_BUFFER_SIZE == 40
+    man = OfflineManager(str(tmp_path))
+    seq = []
+    while not man.is_finished():
+        ok, fc, det = man.get_data()
+        seq.append((1, fc, len(det["x"]), det["posix"][0]) if ok else (0, fc, 0, 0))
+    want = z["seq"]
+    assert len(seq) == len(want)
+    assert np.array_equal(np.array(seq, dtype=np.int64), want)
+    # the quirk: frames 40, 79, 118 arrive with exactly one point
+    assert [s[1] for s in seq if s[0] and s[2] == 1] == [40, 79, 118]
+
+
+def test_constants_surface_and_motion_models():
+    from mmwave_msc_amd import constants as const
+    for name in ("FB_FRAMES_BATCH", "DB_EPS", "DB_Z_WEIGHT", "DB_RANGE_WEIGHT", "DB_MIN_SAMPLES_MIN", "TR_MAX_TRACKS",
+                 "TR_LIFETIME_DYNAMIC", "TR_LIFETIME_STATIC", "TR_VEL_THRES", "TR_GATE", "KF_Q_STD", "KF_P_INIT",
+                 "KF_GROUP_DISP_EST_INIT", "KF_ENABLE_EST", "KF_A_N", "KF_EST_POINTNUM", "KF_SPREAD_LIM", "KF_A_SPR",
+                 "INTENSITY_MU", "INTENSITY_STD", "MODEL_MIN_INPUT", "MODEL_DEFAULT_POSTURE", "MOTION_MODEL",
+                 "S_HEIGHT", "S_TILT", "P_MODEL_PATH", "FB_READ_BUFFER_SIZE"):
+        assert hasattr(const, name), name
+    assert const.MODEL_DEFAULT_POSTURE.shape == (57,)
+    f = const.CONST_ACC_MODEL.KF_F(0.1)
+    assert f.shape == (9, 9) and f[0, 3] == 0.1 and f[0, 6] == 0.5 * 0.1**2 and f[3, 6] == 0.1 and f[6, 6] == 1
+    q = const.CONST_ACC_MODEL.KF_Q_DISCR(0.1)
+    assert q.shape == (9, 9) and q[0, 1] == 0.5 * 0.1**3 and q[0, 3] == 0 and q[8, 8] == 1
+    assert const.CONST_VEL_MODEL.KF_F(0.2)[2, 5] == 0.2 and const.CONST_VEL_MODEL.KF_Q_DISCR(0.2).shape == (6, 6)
+    cfg = const.to_config(tr_max_tracks=8)
+    assert cfg.tr_max_tracks == 8 and cfg.dim_x == 9 and cfg.fb_frames_batch == 2
+
+
+def test_constants_match_reference_values():
+    """Container-only cross-check against the real constants.py."""
+    import pytest
+    from oracle.ref_import import have_reference, load_reference
+    if not have_reference():
+        pytest.skip("reference not present")
+    from mmwave_msc_amd import constants as mine
+    ref, _, _ = load_reference()
+    for name in dir(ref):
+        if name.isupper() and name not in ("MOTION_MODEL", "CONST_ACC_MODEL", "CONST_VEL_MODEL", "SCREEN_CONNECTED"):
+            a, b = getattr(ref, name), getattr(mine, name)
+            assert np.array_equal(np.asarray(a), np.asarray(b)), name
+    for dt in (0.1, 0.37, 1.2):
+        for m in ("CONST_ACC_MODEL", "CONST_VEL_MODEL"):
+            assert np.array_equal(getattr(ref, m).KF_F(dt), getattr(mine, m).KF_F(dt))
+            assert np.array_equal(getattr(ref, m).KF_Q_DISCR(dt), getattr(mine, m).KF_Q_DISCR(dt))
+            assert np.array_equal(getattr(ref, m).KF_H, getattr(mine, m).KF_H)
+
+
+def test_shard_range_partitions_scenes():
+    from mmwave_msc_amd.dist import shard_range
+    for total, world in [(4096, 8), (10, 3), (7, 8), (256, 1)]:
+        blocks = [shard_range(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == total
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+        sizes = [b[1] - b[0] for b in blocks]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_synth_is_deterministic_and_fp32_exact():
+    from mmwave_msc_amd.synth import make_batch, make_scene
+    a, ca, da = make_scene(11, 5, 128, 3)
+    b, cb, db = make_scene(11, 5, 128, 3)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and a.shape == (5, 128, 8)
+    assert np.all(a[..., 2] > 0) and np.all(a[..., 2] <= 2.5) and np.all(a[..., 1] > 0)
+    p, c, d = make_batch([1, 2, 3], 4, 64, 2, ragged=True)
+    assert p.shape == (4, 3, 64, 8) and c.shape == (4, 3) and np.all(c <= 64) and np.all(c >= 32)
+    for f in range(4):
+        for s in range(3):
+            assert np.all(p[f, s, c[f, s]:] == 0)
