@@ -11,20 +11,26 @@
 // centroids/radii, and the per-node PRUNE / ALL / leaf-TEST decision of
 // BinaryTree._query_radius_single (sklearn/neighbors/_binary_tree.pxi.tp:1903-1980).
 //
-// Layout: x,y,z of the <= ring*max_pts candidate points sit in LDS as fp64 SoA
-// (indexed by point index); `idx` maps tree position -> point index so every node
-// is a contiguous position range.  A query leaves a 2-bit state per leaf (64-bit
-// mask per point) that the labelling phase re-uses instead of an adjacency matrix
-// (1536^2 bits would not fit next to the points).
+// Layout: x,y,z of the candidate points sit in LDS as fp64 SoA (indexed by point
+// index); `idx` maps tree position -> point index so every node is a contiguous
+// position range.  A query leaves a 2-bit state per leaf (64-bit mask per point)
+// that the labelling phase re-uses instead of an adjacency matrix.
+//
+// Size classes: the cloud is the concatenation of <= ring frames of UNASSIGNED points, so
+// its size U varies from a few dozen (steady state: clutter only) to ring*max_pts.  LDS is
+// carved per class so that small clouds do not pay for the largest one:
+//   class 0: U <= 256   one wave64 per scene, all 8 columns staged in LDS (no re-reads)
+//   class 1: U <= 768   256 threads
+//   class 2: U <= 1920  256 threads
+// k_track appends every scene that must cluster to the work list of its class.
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 
 namespace mmw {
 
-constexpr int kDbThreads = 256;
-
 struct DbLds {
     double *X, *Y, *Z;             // [UM] by point index
+    double *F8;                    // [5][UM] columns 3..7 by point index (class 0 only)
     double *key;                   // [UM] split value by position (build) ...
     unsigned long long *mask;      // ... aliased: per-position leaf-state mask (query/label)
     int *idx;                      // [UM] position -> point index
@@ -34,33 +40,45 @@ struct DbLds {
     int *next;                     // [UM]
     unsigned char *core;           // [UM]
     unsigned char *leafpos;        // [UM] leaf number of a position
-    int *nstart, *nend;            // [64]
-    double *nsum;                  // [63][3]
-    double *ncen;                  // [63][3]
-    unsigned long long *nrad;      // [63] radius as raw bits (>= 0 so bit order == value order)
-    unsigned long long *mm;        // [32][8][2] sortable min/max keys of the nodes of one level
-    int *sdim;                     // [32]
-    int *lbase;                    // [64] left-count scan value at node start
+    int *nstart, *nend;            // [nodes+1]
+    double *nsum;                  // [nodes][3]
+    double *ncen;                  // [nodes][3]
+    unsigned long long *nrad;      // [nodes] radius as raw bits (>= 0 so bit order == value order)
+    unsigned long long *mm;        // [leaves/2][8][2] sortable min/max keys of the nodes of one level
+    int *sdim;                     // [leaves/2]
+    int *lbase;                    // [leaves/2] left-count scan value at node start
     int *blk;                      // [UM/64 + 1] block counts / prefixes
     int *misc;                     // [16]
-    int *cnt;                      // [NB][CL] cluster member counting (spawn)
-    int *cl_n, *cl_off;            // [CL+1]
-    double *ccen;                  // [CL][6]
+    int *cnt;                      // [NB][CL+1] cluster member counting (spawn)
+    int *cl_n, *cl_off;            // [CL+2]
+    double *ccen;                  // [CL+1][6]
 };
 
 __host__ __device__ inline size_t db_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t db_lds_layout(int UM, int CL, char *base, DbLds *L)
+__host__ __device__ inline int db_levels(int U)
+{
+    // BinaryTree.__init__: n_levels = int(log2(max(1,(n-1)/leaf_size)) + 1)  (_binary_tree.pxi.tp:876-878)
+    int n_levels = 1;
+    while ((U - 1) >= kLeafSize * (1 << n_levels)) n_levels++;
+    return n_levels;
+}
+
+// WRITE=false only sizes the layout (see k_track.hip: no null test on the private struct).
+template <bool WRITE>
+__host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool all8, char *base, DbLds *L)
 {
     const int NB = (UM + 63) / 64;
+    const int levels = db_levels(UM), nodes = (1 << levels) - 1, half = (1 << (levels - 1)) / 2 > 0 ? (1 << (levels - 1)) / 2 : 1;
     size_t off = 0;
 #define CARVE(field, type, count)                       \
-    if (L) L->field = (type *)(base + off);             \
+    if constexpr (WRITE) L->field = (type *)(base + off);  \
     off = db_align16(off + sizeof(type) * (size_t)(count));
     CARVE(X, double, UM)
     CARVE(Y, double, UM)
     CARVE(Z, double, UM)
-    if (L) L->mask = (unsigned long long *)(base + off);
+    CARVE(F8, double, all8 ? 5 * UM : 0)
+    if constexpr (WRITE) L->mask = (unsigned long long *)(base + off);
     CARVE(key, double, UM)
     CARVE(idx, int, UM)
     CARVE(idx2, int, UM)
@@ -69,25 +87,23 @@ __host__ __device__ inline size_t db_lds_layout(int UM, int CL, char *base, DbLd
     CARVE(next, int, UM)
     CARVE(core, unsigned char, UM)
     CARVE(leafpos, unsigned char, UM)
-    CARVE(nstart, int, 64)
-    CARVE(nend, int, 64)
-    CARVE(nsum, double, 63 * 3)
-    CARVE(ncen, double, 63 * 3)
-    CARVE(nrad, unsigned long long, 64)
-    CARVE(mm, unsigned long long, 32 * 16)
-    CARVE(sdim, int, 32)
-    CARVE(lbase, int, 64)
+    CARVE(nstart, int, nodes + 1)
+    CARVE(nend, int, nodes + 1)
+    CARVE(nsum, double, nodes * 3)
+    CARVE(ncen, double, nodes * 3)
+    CARVE(nrad, unsigned long long, nodes + 1)
+    CARVE(mm, unsigned long long, half * 16)
+    CARVE(sdim, int, half)
+    CARVE(lbase, int, half)
     CARVE(blk, int, NB + 1)
     CARVE(misc, int, 16)
     CARVE(cnt, int, NB *(CL + 1))
-    CARVE(cl_n, int, CL + 1)
+    CARVE(cl_n, int, CL + 2)
     CARVE(cl_off, int, CL + 2)
     CARVE(ccen, double, (CL + 1) * 6)
 #undef CARVE
     return off;
 }
-
-size_t dbscan_lds_bytes(int UM, int CL) { return db_lds_layout(UM, CL, nullptr, nullptr); }
 
 __device__ inline unsigned long long sortable(double v)
 {
@@ -113,21 +129,26 @@ __device__ inline double wave_max_d(double v)
 
 // Row source: the candidate cloud is either the concatenation (oldest first) of the
 // scene's global ring frames (Tracking.py:51) or a caller-provided [n][8] block.
+// Pure arithmetic on scalars, passed by value: a struct of four base pointers picked by
+// comparisons gets turned into an indexed load from a private (scratch) copy by the compiler.
 struct RowSrc {
-    const double *base[MMW_RING_MAX];
-    int cum[MMW_RING_MAX + 1];
-    int nfr;
-    __device__ inline const double *row(int i) const
+    const double *gb;     // base of the scene's ring storage (or of the caller's block)
+    size_t stride;        // doubles per physical frame slot
+    unsigned slots;       // physical slot of frame k in byte k
+    int c1, c2, c3;       // first point index of frames 1..3 (INT_MAX when absent)
+    __device__ __forceinline__ const double *row(int i) const
     {
-        int k = 0;
-#pragma unroll
-        for (int q = 1; q < MMW_RING_MAX; q++)
-            if (q < nfr && i >= cum[q]) k = q;
-        return base[k] + (size_t)(i - cum[k]) * 8;
+        const int k = (i >= c1 ? 1 : 0) + (i >= c2 ? 1 : 0) + (i >= c3 ? 1 : 0);
+        int c = 0;
+        c = i >= c1 ? c1 : c;
+        c = i >= c2 ? c2 : c;
+        c = i >= c3 ? c3 : c;
+        const unsigned slot = (slots >> (8 * k)) & 255u;
+        return gb + (size_t)slot * stride + (size_t)(i - c) * 8;
     }
 };
 
-__device__ inline int node_of(const DbLds &L, int p, int level)
+__device__ __forceinline__ int node_of(const DbLds &L, int p, int level)
 {
     int node = 0;
     for (int t = 0; t < level; t++) {
@@ -140,24 +161,43 @@ __device__ inline int node_of(const DbLds &L, int p, int level)
 
 // The whole of DBSCAN.fit_predict for one cloud.  On return L.idx2[i] = label of
 // point i (-1 noise) and the number of clusters is returned (uniform).
-__device__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc &src, int U, double eps, int min_samples)
+template <int NT, bool ALL8>
+__device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc src, int U, int UMc, double eps, int min_samples)
 {
-    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const double rw = cfg.db_range_weight, zw = cfg.db_z_weight;
 
-    // ---- stage x,y,z; identity order ----
-    for (int i = tid; i < U; i += NT) {
-        const double *r = src.row(i);
-        L.X[i] = r[0]; L.Y[i] = r[1]; L.Z[i] = r[2];
-        L.idx[i] = i;
-        L.lab[i] = -1;
+    // ---- stage x,y,z (and the other five columns for small clouds); identity order ----
+    if (ALL8) {
+        for (int e = tid; e < U * 8; e += NT) {
+            const int i = e >> 3, f = e & 7;
+            const double v = src.row(i)[f];
+            if (f == 0) L.X[i] = v;
+            else if (f == 1) L.Y[i] = v;
+            else if (f == 2) L.Z[i] = v;
+            else L.F8[(f - 3) * UMc + i] = v;
+        }
+        for (int i = tid; i < U; i += NT) { L.idx[i] = i; L.lab[i] = -1; }
+    } else {
+        for (int i = tid; i < U; i += NT) {
+            const double *r = src.row(i);
+            L.X[i] = r[0]; L.Y[i] = r[1]; L.Z[i] = r[2];
+            L.idx[i] = i;
+            L.lab[i] = -1;
+        }
     }
-    // BinaryTree.__init__: n_levels = int(log2(max(1,(n-1)/leaf_size)) + 1)  (_binary_tree.pxi.tp:876-878)
-    int n_levels = 1;
-    while ((U - 1) >= kLeafSize * (1 << n_levels)) n_levels++;
+    const int n_levels = db_levels(U);
     const int n_nodes = (1 << n_levels) - 1;
     if (tid == 0) { L.nstart[0] = 0; L.nend[0] = U; }
     __syncthreads();
+
+    auto feature = [&](int i, int f) -> double {
+        if (f == 0) return L.X[i];
+        if (f == 1) return L.Y[i];
+        if (f == 2) return L.Z[i];
+        if (ALL8) return L.F8[(f - 3) * UMc + i];
+        return src.row(i)[f];
+    };
 
     // ---- _recursive_build, level by level (_binary_tree.pxi.tp:1040-1084) ----
     int *idx = L.idx, *idx2 = L.idx2;
@@ -172,10 +212,12 @@ __device__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc &src,
             const int node = act ? node_of(L, p, level) : -1;
             const int nfirst = __builtin_amdgcn_readfirstlane(node);
             const bool uniform = __all(node == nfirst) != 0;  // wave-uniform
-            const double *r = act ? src.row(idx[p]) : nullptr;
+            const int i = act ? idx[p] : 0;
+            const double *r = (!ALL8 && act) ? src.row(i) : nullptr;
 #pragma unroll
             for (int f = 0; f < 8; f++) {
-                const double v = act ? r[f] : 0.0;
+                double v = 0.0;
+                if (act) v = ALL8 ? feature(i, f) : r[f];
                 if (uniform) {
                     if (nfirst >= 0) {
                         const double mn = wave_min_d(v), mx = wave_max_d(v);
@@ -203,7 +245,7 @@ __device__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc &src,
         __syncthreads();
         for (int p = tid; p < U; p += NT) {
             const int node = node_of(L, p, level);
-            L.key[p] = src.row(idx[p])[L.sdim[node - first]];
+            L.key[p] = feature(idx[p], L.sdim[node - first]);
         }
         __syncthreads();
         // partition_node_indices: the n_mid smallest under (value, index) go left
@@ -370,7 +412,7 @@ __device__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc &src,
         const int seedkey = L.misc[0];
         if (seedkey == 0x7fffffff) break;
         __syncthreads();
-        if (tid == 0) { const int sp = seedkey & 4095; L.lab[sp] = n_clusters; front[0] = sp; L.misc[1] = 1; L.misc[2] = 0; }
+        if (tid == 0) { const int sp = seedkey & 4095; L.lab[sp] = n_clusters; front[0] = sp; L.misc[2] = 0; }
         __syncthreads();
         int fcount = 1;
         while (fcount > 0) {
@@ -414,33 +456,37 @@ __device__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc &src,
     return n_clusters;
 }
 
-// Tracking.py:697-703 for one scene: apply_DBscan on the global ring, batch.clear(), _add_tracks.
-__global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevState st, int UM, int CL,
-                                                            int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+// Tracking.py:697-703 for the scenes of one size class: apply_DBscan on the global ring,
+// batch.clear(), _add_tracks.
+template <int NT, bool ALL8>
+__global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int cls,
+                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     DbLds L;
-    db_lds_layout(UM, CL, lds_raw, &L);
-    const int s = blockIdx.x, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
+    db_lds_layout<true>(UMc, CL, ALL8, lds_raw, &L);
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x >= st.db_count[parity * 4 + cls]) return;
+    const int s = st.db_list[(size_t)cls * cfg.n_scenes + blockIdx.x];
     SceneHdr *hdr = st.hdr + s;
-    if (!hdr->need_db) return;
     const int U = hdr->db_u, NP = cfg.max_pts;
     RowSrc src;
-    src.nfr = hdr->g_len;
     {
-        int run = 0;
-        for (int k = 0; k < MMW_RING_MAX; k++) {
-            src.cum[k] = run;
-            src.base[k] = st.g_ring + ((size_t)s * cfg.ring + hdr->g_slot[k]) * (size_t)NP * 8;
-            if (k < src.nfr) run += hdr->g_n[k];
-        }
-        src.cum[MMW_RING_MAX] = run;
+        const int nfr = hdr->g_len;
+        const int big = 0x7fffffff;
+        src.gb = st.g_ring + (size_t)s * cfg.ring * (size_t)NP * 8;
+        src.stride = (size_t)NP * 8;
+        src.slots = (unsigned)hdr->g_slot[0] | ((unsigned)hdr->g_slot[1] << 8) | ((unsigned)hdr->g_slot[2] << 16) | ((unsigned)hdr->g_slot[3] << 24);
+        const int n0 = hdr->g_n[0], n1 = hdr->g_n[1], n2 = hdr->g_n[2];
+        src.c1 = nfr > 1 ? n0 : big;
+        src.c2 = nfr > 2 ? n0 + n1 : big;
+        src.c3 = nfr > 3 ? n0 + n1 + n2 : big;
     }
     __syncthreads();  // every thread has read the header before anyone rewrites it below
-    const int ncl = dbscan_core(cfg, L, src, U, cfg.db_eps, cfg.db_min_samples);
+    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples);
     const int *labi = L.idx2;
     if (labels_out)
-        for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM + i] = labi[i];
+        for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM_out + i] = labi[i];
     if (tid == 0) {
         if (db_n_out) db_n_out[s] = U;
         hdr->need_db = 0;
@@ -471,13 +517,13 @@ __global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevStat
     const int NB = (U + 63) / 64, CLS = CL + 1;
     for (int i0 = 0; i0 < U; i0 += NT) {
         const int i = i0 + tid;
-        const int cls = (i < U) ? labi[i] : -1;
+        const int cls_i = (i < U) ? labi[i] : -1;
         const int b = i >> 6;
         if (i0 + (tid & ~63) < U) {
             unsigned long long mine = 0;
             for (int c = 0; c < nspawn; c++) {
-                const unsigned long long bal = __ballot(cls == c);
-                if (cls == c) mine = bal;
+                const unsigned long long bal = __ballot(cls_i == c);
+                if (cls_i == c) mine = bal;
                 if (lane == 0) L.cnt[b * CLS + c] = __popcll(bal);
             }
             if (i < U) L.lab[i] = __popcll(mine & lanemask_lt());  // rank inside its 64-block
@@ -512,7 +558,11 @@ __global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevStat
         double sum = 0.0, mn = 0.0, mx = 0.0;
         for (int r = 0; r < n; r++) {
             const int i = memb[off + r];
-            const double v = m == 0 ? L.X[i] : m == 1 ? L.Y[i] : m == 2 ? L.Z[i] : src.row(i)[m];
+            double v;
+            if (m == 0) v = L.X[i];
+            else if (m == 1) v = L.Y[i];
+            else if (m == 2) v = L.Z[i];
+            else v = ALL8 ? L.F8[(m - 3) * UMc + i] : src.row(i)[m];
             sum += v;
             mn = (r == 0 || v < mn) ? v : mn;
             mx = (r == 0 || v > mx) ? v : mx;
@@ -555,42 +605,73 @@ __global__ __launch_bounds__(kDbThreads) void k_dbscan_spawn(DevCfg cfg, DevStat
 }
 
 // Utils.apply_DBscan on caller-provided clouds: pts[S][max_n][8]
-__global__ __launch_bounds__(kDbThreads) void k_dbscan_only(DevCfg cfg, int UM, const double *__restrict__ pts,
-                                                           const int32_t *__restrict__ n_all, int max_n, double eps,
-                                                           int min_samples, int32_t *__restrict__ labels_out,
-                                                           int32_t *__restrict__ ncl_out)
+__global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const double *__restrict__ pts,
+                                                    const int32_t *__restrict__ n_all, int max_n, double eps,
+                                                    int min_samples, int32_t *__restrict__ labels_out,
+                                                    int32_t *__restrict__ ncl_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     DbLds L;
-    db_lds_layout(UM, 0, lds_raw, &L);
-    const int s = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    db_lds_layout<true>(UM, 0, false, lds_raw, &L);
+    const int s = blockIdx.x, tid = threadIdx.x;
     const int U = n_all[s];
     if (U <= 0 || U > UM) { if (tid == 0 && ncl_out) ncl_out[s] = 0; return; }
     RowSrc src;
-    src.nfr = 1;
-    for (int k = 0; k <= MMW_RING_MAX; k++) src.cum[k] = 0;
-    for (int k = 0; k < MMW_RING_MAX; k++) src.base[k] = pts + (size_t)s * max_n * 8;
-    const int ncl = dbscan_core(cfg, L, src, U, eps, min_samples);
-    for (int i = tid; i < U; i += NT) labels_out[(size_t)s * max_n + i] = L.idx2[i];
+    src.gb = pts + (size_t)s * max_n * 8;
+    src.stride = 0;
+    src.slots = 0;
+    src.c1 = src.c2 = src.c3 = 0x7fffffff;
+    const int ncl = dbscan_core<256, false>(cfg, L, src, U, UM, eps, min_samples);
+    for (int i = tid; i < U; i += 256) labels_out[(size_t)s * max_n + i] = L.idx2[i];
     if (tid == 0 && ncl_out) ncl_out[s] = ncl;
 }
 
-hipError_t prepare_dbscan(int UM, int CL)
+// ---- host side ---------------------------------------------------------------------------
+static const int kClassUM[3] = {256, 768, 1920};
+
+int dbscan_class_um(int cls, int UM) { return kClassUM[cls] < UM ? kClassUM[cls] : UM; }
+int dbscan_class_cl(int cls, int UM, int t_cap, int min_samples)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_dbscan_spawn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_lds_bytes(UM, CL));
+    const int um = dbscan_class_um(cls, UM);
+    int cl = um / (min_samples > 0 ? min_samples : 1) + 1;
+    return cl < t_cap ? cl : t_cap;
+}
+size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples)
+{
+    return db_lds_layout<false>(dbscan_class_um(cls, UM), dbscan_class_cl(cls, UM, t_cap, min_samples), cls == 0, nullptr, nullptr);
+}
+size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false, nullptr, nullptr); }
+
+hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_dbscan_spawn<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dbscan_lds_bytes(0, UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_lds_bytes(UM, 0));
+    size_t big = dbscan_lds_bytes(1, UM, t_cap, min_samples);
+    if (dbscan_lds_bytes(2, UM, t_cap, min_samples) > big) big = dbscan_lds_bytes(2, UM, t_cap, min_samples);
+    e = hipFuncSetAttribute((const void *)k_dbscan_spawn<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
 }
 
-void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int CL, int32_t *labels, int32_t *db_n, hipStream_t stream)
+// One launch per size class that can occur (class c exists when its lower bound < UM).
+void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_dbscan_spawn, dim3(cfg.n_scenes), dim3(kDbThreads), dbscan_lds_bytes(UM, CL), stream, cfg, st, UM, CL, labels, db_n);
+    for (int cls = 0; cls < 3; cls++) {
+        if (cls > 0 && kClassUM[cls - 1] >= UM) break;
+        const int umc = dbscan_class_um(cls, UM), cl = dbscan_class_cl(cls, UM, cfg.t_cap, cfg.db_min_samples);
+        const size_t lds = dbscan_lds_bytes(cls, UM, cfg.t_cap, cfg.db_min_samples);
+        if (cls == 0)
+            hipLaunchKernelGGL((k_dbscan_spawn<64, true>), dim3(cfg.n_scenes), dim3(64), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
+        else
+            hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(cfg.n_scenes), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
+    }
 }
 
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_dbscan_only, dim3(cfg.n_scenes), dim3(kDbThreads), dbscan_lds_bytes(UM, 0), stream, cfg, UM, pts, n, max_n, eps,
+    hipLaunchKernelGGL(k_dbscan_only, dim3(cfg.n_scenes), dim3(256), dbscan_only_lds_bytes(UM), stream, cfg, UM, pts, n, max_n, eps,
                        min_samples, labels, ncl);
 }
 

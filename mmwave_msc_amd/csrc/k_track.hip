@@ -31,12 +31,15 @@ struct TrackLds {
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
+// WRITE=false only sizes the layout.  (No `if (L)` null test: in the private address space a
+// null check on an alloca cannot be folded and would pin the struct in scratch memory.)
+template <bool WRITE>
+__host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
 {
     const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
     size_t off = 0;
 #define CARVE(field, type, count)                      \
-    if (L) L->field = (type *)(base + off);            \
+    if constexpr (WRITE) L->field = (type *)(base + off); \
     off = align16(off + sizeof(type) * (size_t)(count));
     CARVE(p6, double, 6 * NP)
     CARVE(gate, double, kGateChunk * 72)
@@ -54,7 +57,7 @@ __host__ __device__ inline size_t track_lds_layout(const DevCfg &c, char *base, 
     return off;
 }
 
-size_t track_lds_bytes(const DevCfg &c) { return track_lds_layout(c, nullptr, nullptr); }
+size_t track_lds_bytes(const DevCfg &c) { return track_lds_layout<false>(c, nullptr, nullptr); }
 
 // CONST_ACC_MODEL.KF_F / CONST_VEL_MODEL.KF_F (constants.py:195-208, 227-237)
 __device__ inline double Fval(int i, int k, int dx, double dt, double h)
@@ -142,11 +145,11 @@ __device__ inline double np_pairwise_sum(F elem, int n, double *stk, int stride)
 
 __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
-                                                    int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out)
+                                                    int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out, int parity)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     TrackLds L;
-    track_lds_layout(cfg, lds_raw, &L);
+    track_lds_layout<true>(cfg, lds_raw, &L);
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
     const int n = n_pts[s];
     SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
+    if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (n <= 0 || n > NP) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) hdr->need_db = 0;
         return;
@@ -588,7 +592,13 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         hdr->g_len = len;
         hdr->n_tracks = T;
         hdr->db_u = U;
-        hdr->need_db = (U > 0 && T < cfg.tr_max_tracks) ? 1 : 0;
+        const bool need = U > 0 && T < cfg.tr_max_tracks;
+        hdr->need_db = need ? 1 : 0;
+        if (need) {  // work list of the cloud's size class (k_dbscan.hip)
+            const int cls = U <= 256 ? 0 : (U <= 768 ? 1 : 2);
+            const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
+            st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
+        }
     }
     __syncthreads();
     {
@@ -600,7 +610,9 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         // algorithmic bytes of this scene-frame: points in, assoc out,
         // track records read+written, unassigned rows appended to the ring
         const int Tin = L.misc[2];
-        atomicAdd(&st.stats[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun));
+        int ring_rows = 0;  // rows appended to per-track rings (kept for the feature map)
+        for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
+        atomicAdd(&st.stats[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun + 64 * ring_rows));
         atomicAdd(&st.stats[2], 1ULL);
         atomicAdd(&st.stats[5], (unsigned long long)Tin);
         atomicAdd(&st.stats[6], (unsigned long long)n * (unsigned long long)Tin);
@@ -608,10 +620,10 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
 }
 
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
-                  int32_t *assoc, int32_t *db_n, hipStream_t stream)
+                  int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream)
 {
     const size_t lds = track_lds_bytes(cfg);
-    hipLaunchKernelGGL(k_track, dim3(cfg.n_scenes), dim3(kThreads), lds, stream, cfg, st, pts, n_pts, dt, assoc, db_n);
+    hipLaunchKernelGGL(k_track, dim3(cfg.n_scenes), dim3(kThreads), lds, stream, cfg, st, pts, n_pts, dt, assoc, db_n, parity);
 }
 
 hipError_t prepare_track(const DevCfg &cfg)

@@ -15,10 +15,11 @@ namespace mmw {
 size_t track_lds_bytes(const DevCfg &c);
 hipError_t prepare_track(const DevCfg &cfg);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
-                  int32_t *assoc, int32_t *db_n, hipStream_t stream);
-size_t dbscan_lds_bytes(int UM, int CL);
-hipError_t prepare_dbscan(int UM, int CL);
-void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int CL, int32_t *labels, int32_t *db_n, hipStream_t stream);
+                  int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream);
+size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
+size_t dbscan_only_lds_bytes(int UM);
+hipError_t prepare_dbscan(int UM, int t_cap, int min_samples);
+void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
 void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
@@ -49,6 +50,8 @@ struct mmw_ctx {
     int32_t *d_row_off = nullptr;     // [S+1]
     float *d_posture = nullptr;
     unsigned long long *d_stats = nullptr;
+    int32_t *d_db_list = nullptr, *d_db_count = nullptr;
+    int step_parity = 0;
     // host-convenience staging (lazy)
     double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;
     int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr;
@@ -198,17 +201,24 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_posture, MMW_NKP * sizeof(float));
     ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
     ALLOC(c->d_stats, 8 * sizeof(unsigned long long));
+    ALLOC(c->d_db_list, 3 * S * sizeof(int32_t));
+    ALLOC(c->d_db_count, 8 * sizeof(int32_t));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
     c->st.stats = c->d_stats;
+    c->st.db_list = c->d_db_list;
+    c->st.db_count = c->d_db_count;
     if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
-    const size_t lds_a = track_lds_bytes(d), lds_b = dbscan_lds_bytes(c->UM, cap);
+    size_t lds_b = dbscan_only_lds_bytes(c->UM);
+    for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
+    const size_t lds_a = track_lds_bytes(d);
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) { mmw_destroy(c); return fail(nullptr, MMW_E_ARG, "LDS demand too large (track %zu B, dbscan %zu B > 160 KiB)", lds_a, lds_b); }
-    hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap);
+    hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap, cfg->db_min_samples);
     if (e1 != hipSuccess || e2 != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
     launch_reset(d, c->st, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "reset kernel failed: %s", hipGetErrorString(hipGetLastError())); }
@@ -223,7 +233,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -312,11 +322,12 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
     prof_begin(c, MMW_K_TRACK, ep);
-    launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, c->stream);
+    launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, c->step_parity, c->stream);
     prof_end(c, ep);
     prof_begin(c, MMW_K_DBSCAN, ep);
-    launch_dbscan_spawn(c->dc, c->st, c->UM, c->dc.t_cap, db_labels, db_n, c->stream);
+    launch_dbscan_spawn(c->dc, c->st, c->UM, c->step_parity, db_labels, db_n, c->stream);
     prof_end(c, ep);
+    c->step_parity ^= 1;
     HIPCHK(c, hipGetLastError());
     return MMW_OK;
 }

@@ -83,6 +83,8 @@ struct DevState {
     double *g_ring;       // [S][ring][max_pts][8]
     const float *default_posture;  // [57]
     unsigned long long *stats;     // [8] algorithmic-byte / work counters (see mmw_stats_get)
+    int32_t *db_list;              // [3][S] scenes that must run apply_DBscan this step, per size class
+    int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
 };
 
 __host__ __device__ inline size_t trk_ring_stride_track(const DevCfg &c) { return (size_t)c.ring * c.ring_rows * 8; }
