@@ -28,6 +28,22 @@
 
 namespace mmw {
 
+// Diagnostic build only (make STAMPS=1): per-phase cycle sums of lane 0 into stats[20 + phase].
+#ifdef MMW_STAMPS
+#define DSTAMP(k)                                                                            \
+    do {                                                                                     \
+        if (threadIdx.x == 0 && dbg) {                                                       \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();                  \
+            atomicAdd(&dbg[20 + (k)], t_now - t_prev);                                       \
+            t_prev = t_now;                                                                  \
+        }                                                                                    \
+    } while (0)
+#define DSTAMP_INIT unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#else
+#define DSTAMP(k)
+#define DSTAMP_INIT
+#endif
+
 struct DbLds {
     double *X, *Y, *Z;             // [UM] by point index
     double *F8;                    // [5][UM] columns 3..7 by point index (class 0 only)
@@ -162,8 +178,11 @@ __device__ __forceinline__ int node_of(const DbLds &L, int p, int level)
 // The whole of DBSCAN.fit_predict for one cloud.  On return L.idx2[i] = label of
 // point i (-1 noise) and the number of clusters is returned (uniform).
 template <int NT, bool ALL8>
-__device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc src, int U, int UMc, double eps, int min_samples)
+__device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc src, int U, int UMc, double eps, int min_samples,
+                                           unsigned long long *dbg)
 {
+    DSTAMP_INIT
+    (void)dbg;
     const int tid = threadIdx.x, lane = tid & 63;
     const double rw = cfg.db_range_weight, zw = cfg.db_z_weight;
 
@@ -199,6 +218,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         return src.row(i)[f];
     };
 
+    DSTAMP(0);
     // ---- _recursive_build, level by level (_binary_tree.pxi.tp:1040-1084) ----
     int *idx = L.idx, *idx2 = L.idx2;
     for (int level = 0; level + 1 < n_levels; level++) {
@@ -301,6 +321,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         __syncthreads();
     }
 
+    DSTAMP(1);
     // ---- init_node: centroids (leaf sums in ascending index order, parents = left + right)
     //      and radii (_ball_tree.pyx.tp:84-144) ----
     const int leaf0 = (1 << (n_levels - 1)) - 1, n_leaves = 1 << (n_levels - 1);
@@ -352,6 +373,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     }
     __syncthreads();
 
+    DSTAMP(2);
     // ---- BallTree.query_radius(X, eps) for every point (_binary_tree.pxi.tp:1903-1980) ----
     const int lbits = n_levels - 1;
     for (int p = tid; p < U; p += NT) {
@@ -394,6 +416,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     }
     __syncthreads();
 
+    DSTAMP(3);
     // ---- dbscan_inner (sklearn/cluster/_dbscan_inner.pyx): clusters seeded in ascending
     //      point index; frontier expansion instead of the DFS stack (same labels) ----
     int n_clusters = 0;
@@ -444,6 +467,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         }
         n_clusters++;
     }
+    DSTAMP(4);
     // labels by point index: scatter into whichever of the two index buffers is free,
     // the caller always finds them in L.idx2
     int *labi = (idx == L.idx) ? L.idx2 : L.idx;
@@ -483,7 +507,7 @@ __global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, in
         src.c3 = nfr > 3 ? n0 + n1 + n2 : big;
     }
     __syncthreads();  // every thread has read the header before anyone rewrites it below
-    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples);
+    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, st.stats);
     const int *labi = L.idx2;
     if (labels_out)
         for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM_out + i] = labi[i];
@@ -621,13 +645,14 @@ __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const d
     src.stride = 0;
     src.slots = 0;
     src.c1 = src.c2 = src.c3 = 0x7fffffff;
-    const int ncl = dbscan_core<256, false>(cfg, L, src, U, UM, eps, min_samples);
+    const int ncl = dbscan_core<256, false>(cfg, L, src, U, UM, eps, min_samples, nullptr);
     for (int i = tid; i < U; i += 256) labels_out[(size_t)s * max_n + i] = L.idx2[i];
     if (tid == 0 && ncl_out) ncl_out[s] = ncl;
 }
 
 // ---- host side ---------------------------------------------------------------------------
 static const int kClassUM[3] = {256, 768, 1920};
+constexpr int kClass0Threads = 256;
 
 int dbscan_class_um(int cls, int UM) { return kClassUM[cls] < UM ? kClassUM[cls] : UM; }
 int dbscan_class_cl(int cls, int UM, int t_cap, int min_samples)
@@ -644,7 +669,7 @@ size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false,
 
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_dbscan_spawn<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void *)k_dbscan_spawn<kClass0Threads, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)dbscan_lds_bytes(0, UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
     size_t big = dbscan_lds_bytes(1, UM, t_cap, min_samples);
@@ -662,7 +687,7 @@ void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int pari
         const int umc = dbscan_class_um(cls, UM), cl = dbscan_class_cl(cls, UM, cfg.t_cap, cfg.db_min_samples);
         const size_t lds = dbscan_lds_bytes(cls, UM, cfg.t_cap, cfg.db_min_samples);
         if (cls == 0)
-            hipLaunchKernelGGL((k_dbscan_spawn<64, true>), dim3(cfg.n_scenes), dim3(64), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
+            hipLaunchKernelGGL((k_dbscan_spawn<kClass0Threads, true>), dim3(cfg.n_scenes), dim3(kClass0Threads), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
         else
             hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(cfg.n_scenes), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
     }

@@ -1,25 +1,43 @@
 // k_track.hip -- one workgroup (256 threads = 4 wave64) per scene: everything of
 // TrackBuffer.track (Tracking.py:664-703) up to and including batch.add_frame(unassigned):
 //   _predict_all -> _calc_dist_fun gating/association -> associate_pointcloud estimators
-//   -> _maintain_tracks -> _update_all -> global ring append; raises need_db for k_dbscan.
+//   -> _maintain_tracks -> _update_all -> global ring append; queues the scene for k_dbscan.
 //
-// Data movement per scene-frame: the frame's points are read ONCE from HBM
-// (coalesced 8-B lanes over the row-major [n][8] block) and transposed into an
-// LDS SoA tile (6 columns); track records (1.5 KB each) live in HBM/L2 and are
-// staged through per-wave LDS scratch for the 9x9 algebra.  All arithmetic fp64
-// with a fixed operation order (see mmw_math.hpp) -- the order is the one the
-// parity oracle restates from the reference.
+// Data movement per scene-frame: the frame's points are read ONCE from HBM (coalesced 8-B
+// lanes over the row-major [n][8] block) and transposed into an LDS SoA tile (6 columns);
+// track records (1.5 KB each) live in HBM/L2.  Per-track algebra (9x9 predict, 6x6 LU, Joseph
+// update) runs one wave per track with wave-local ordering only -- the four waves of the
+// workgroup work on four tracks independently and meet at workgroup barriers only around the
+// phases that touch all points.  All arithmetic fp64 with a fixed operation order (see
+// mmw_math.hpp) -- the order the parity oracle restates from the reference.
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 
 namespace mmw {
 
+// Diagnostic build only (make STAMPS=1 -> libmmw_hip_stamps.so): per-phase cycle sums of wave 0,
+// accumulated into stats[8 + phase].  Never compiled into the product library.
+#ifdef MMW_STAMPS
+#define STAMP(k)                                                                              \
+    do {                                                                                      \
+        if (tid == 0) {                                                                       \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();                   \
+            atomicAdd(&st.stats[8 + (k)], t_now - t_prev);                                    \
+            t_prev = t_now;                                                                   \
+        }                                                                                     \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
+constexpr int kGateStride = 44;   // per track: Ci[36] | logdet | hx[6] | pad
+constexpr int kWaveScratch = 360; // per wave: P[81] A[81] K[54] C1[54] SI[36] Rc[36] x[9] y[6] (+pad)
+constexpr int kPwStackDepth = 4;  // numpy pairwise-sum recursion depth for n <= 2048
+
 struct TrackLds {
     double *p6;      // [6][NP] point columns x,y,z,vx,vy,vz
-    double *gate;    // [kGateChunk][72]  (gating: Ci[36], logdet, hx[6]; update: SI[36], Rc[36])
-    double *wsc;     // [kWaves][288] per-wave scratch
+    double *work;    // union: gate[kGateChunk][44] + per-wave scratch | pairwise stack [4][256]
     double *cen;     // [t_cap][6] centroid of this frame's cloud per track
-    int *assoc;      // [NP]
     int *perm;       // [NP] point indices grouped by class (0 = unassigned, j+1 = track j), input order kept
     int *cnt;        // [NB][CLS]
     int *cls_n;      // [CLS]
@@ -37,15 +55,14 @@ template <bool WRITE>
 __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
 {
     const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
+    const int work_a = kGateChunk * kGateStride + kWaves * kWaveScratch, work_b = kPwStackDepth * kThreads;
     size_t off = 0;
-#define CARVE(field, type, count)                      \
-    if constexpr (WRITE) L->field = (type *)(base + off); \
+#define CARVE(field, type, count)                            \
+    if constexpr (WRITE) L->field = (type *)(base + off);    \
     off = align16(off + sizeof(type) * (size_t)(count));
     CARVE(p6, double, 6 * NP)
-    CARVE(gate, double, kGateChunk * 72)
-    CARVE(wsc, double, kWaves * 288)
+    CARVE(work, double, work_a > work_b ? work_a : work_b)
     CARVE(cen, double, c.t_cap * 6)
-    CARVE(assoc, int, NP)
     CARVE(perm, int, NP)
     CARVE(cnt, int, NB *CLS)
     CARVE(cls_n, int, CLS)
@@ -59,20 +76,10 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
 
 size_t track_lds_bytes(const DevCfg &c) { return track_lds_layout<false>(c, nullptr, nullptr); }
 
-// CONST_ACC_MODEL.KF_F / CONST_VEL_MODEL.KF_F (constants.py:195-208, 227-237)
-__device__ inline double Fval(int i, int k, int dx, double dt, double h)
-{
-    if (i == k) return 1.0;
-    if (k == i + 3 && k < dx) return dt;
-    if (k == i + 6 && k < dx) return h;
-    return 0.0;
-}
-
 // numpy pairwise_sum_DOUBLE over elem(r), r in [0, n): the summation order of the
-// 1-D np.mean in ClusterTrack._get_D (Tracking.py:286).  `stk` is a per-thread LDS
-// stack (stride = blockDim) for the recursive halves (only used when n > 128).
+// 1-D np.mean in ClusterTrack._get_D (Tracking.py:286).
 template <typename F>
-__device__ inline double np_pairwise_leaf(F elem, int off, int n)
+__device__ __forceinline__ double np_pairwise_leaf(F elem, int off, int n)
 {
     if (n < 8) {
         double res = 0.0;
@@ -97,21 +104,21 @@ __device__ inline double np_pairwise_leaf(F elem, int off, int n)
     return res;
 }
 
+// `stk` is a per-thread LDS stack (stride = blockDim) for the recursive halves (n > 128 only).
 template <typename F>
-__device__ inline double np_pairwise_sum(F elem, int n, double *stk, int stride)
+__device__ __forceinline__ double np_pairwise_sum(F elem, int n, double *stk, int stride)
 {
     if (n <= 128) return np_pairwise_leaf(elem, 0, n);
-    // Iterative post-order walk of numpy's split tree.  Frame = (off, len) packed in
-    // an int pair kept in two small register arrays addressed through selects.
-    // Depth <= 5 for n <= 4096.
-    int foff[6], flen[6], fstate[6];
+    // Iterative post-order walk of numpy's split tree; frames in small register arrays
+    // addressed through selects (static indices only).
+    int foff[kPwStackDepth + 1], flen[kPwStackDepth + 1], fstate[kPwStackDepth + 1];
     int d = 0;
     foff[0] = 0; flen[0] = n; fstate[0] = 0;
     double ret = 0.0;
     while (d >= 0) {
         int off = 0, len = 0, stt = 0;
 #pragma unroll
-        for (int q = 0; q < 6; q++)
+        for (int q = 0; q <= kPwStackDepth; q++)
             if (q == d) { off = foff[q]; len = flen[q]; stt = fstate[q]; }
         if (len <= 128) {
             ret = np_pairwise_leaf(elem, off, len);
@@ -122,7 +129,7 @@ __device__ inline double np_pairwise_sum(F elem, int n, double *stk, int stride)
         n2 -= n2 % 8;
         if (stt == 0) {  // descend left
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
+            for (int q = 0; q <= kPwStackDepth; q++) {
                 if (q == d) fstate[q] = 1;
                 if (q == d + 1) { foff[q] = off; flen[q] = n2; fstate[q] = 0; }
             }
@@ -130,7 +137,7 @@ __device__ inline double np_pairwise_sum(F elem, int n, double *stk, int stride)
         } else if (stt == 1) {  // left done: stash, descend right
             stk[d * stride] = ret;
 #pragma unroll
-            for (int q = 0; q < 6; q++) {
+            for (int q = 0; q <= kPwStackDepth; q++) {
                 if (q == d) fstate[q] = 2;
                 if (q == d + 1) { foff[q] = off + n2; flen[q] = len - n2; fstate[q] = 0; }
             }
@@ -143,7 +150,7 @@ __device__ inline double np_pairwise_sum(F elem, int n, double *stk, int stride)
     return ret;
 }
 
-__global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+__global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out, int parity)
 {
@@ -168,107 +175,119 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
     int32_t *order = st.order + (size_t)s * cfg.t_cap;
     TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
     int T = hdr->n_tracks;
+    const int Tin = T;
     int err = 0;
-    if (tid == 0) L.misc[2] = T;
+#ifdef MMW_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    double *gate = L.work;
+    double *W = L.work + kGateChunk * kGateStride + wave * kWaveScratch;
+    double *Pw = W, *Aw = W + 81, *Kw = W + 162, *C1w = W + 216, *SIw = W + 270, *Rcw = W + 306, *xw = W + 342, *yw = W + 351;
 
     // ---- stage points: coalesced read of the row-major block, SoA in LDS ----
-    for (int e = tid; e < n * 8; e += kThreads) {
-        double v = pts[e];
-        int col = e & 7;
-        if (col < 6) L.p6[col * NP + (e >> 3)] = v;
+    // (16-byte lanes; eight loads in flight per thread before the first LDS store)
+    {
+        const double2 *src2 = reinterpret_cast<const double2 *>(pts);
+        const int n2 = n * 4;  // double2 elements
+        for (int e0 = 0; e0 < n2; e0 += 8 * kThreads) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * kThreads + tid;
+                v[u] = e < n2 ? src2[e] : double2{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * kThreads + tid;
+                const int col = (e & 3) * 2, row = e >> 2;
+                if (e < n2 && col < 6) { L.p6[col * NP + row] = v[u].x; L.p6[(col + 1) * NP + row] = v[u].y; }
+            }
+        }
     }
     for (int j = tid; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
     __syncthreads();
+    STAMP(0);  // stage points
 
-    // ---- _predict_all (Tracking.py:591-596; filterpy predict) ----
-    {
-        double *W = L.wsc + wave * 288;  // P[81] | A[81] | F[81] | x[9]
-        double *Pw = W, *Aw = W + 81, *Fw = W + 162, *xw = W + 243;
-        const int rounds = (T + kWaves - 1) / kWaves;
-        for (int r = 0; r < rounds; r++) {
-            const int j = r * kWaves + wave;
-            const bool act = j < T;
-            TrackRec *rec = act ? trk + L.slot[j] : nullptr;
-            double dtm = 0, h = 0;
-            if (act) {
-                dtm = rec->lifetime + dt;
-                h = 0.5 * (dtm * dtm);
-                for (int e = lane; e < 81; e += 64) {
-                    int i = e / 9, k = e % 9;
-                    Pw[e] = rec->P[e];
-                    Fw[e] = (i < dx && k < dx) ? Fval(i, k, dx, dtm, h) : 0.0;
-                }
-                if (lane < 9) xw[lane] = rec->x[lane];
-            }
-            __syncthreads();
-            if (act) {
-                for (int e = lane; e < 81; e += 64) {
-                    int i = e / 9, c = e % 9;
-                    if (i < dx && c < dx) {
-                        double a = Fw[i * 9] * Pw[c];
-                        for (int k = 1; k < dx; k++) a += Fw[i * 9 + k] * Pw[k * 9 + c];
-                        Aw[e] = a;
-                    }
-                }
-                if (lane < dx) {
-                    double a = Fw[lane * 9] * xw[0];
-                    for (int k = 1; k < dx; k++) a += Fw[lane * 9 + k] * xw[k];
-                    rec->x[lane] = a;
-                }
-            }
-            __syncthreads();
-            if (act) {
-                const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
-                for (int e = lane; e < 81; e += 64) {
-                    int i = e / 9, c = e % 9;
-                    if (i < dx && c < dx) {
-                        double b = Aw[i * 9] * Fw[c * 9];
-                        for (int k = 1; k < dx; k++) b += Aw[i * 9 + k] * Fw[c * 9 + k];
-                        double q = 0.0;
-                        if (i / 3 == c / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
-                            int qi = i % 3, qc = c % 3, sdeg = qi + qc;
-                            double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
-                                        : sdeg == 3 ? dtm : 1.0;
-                            q = base * cfg.kf_q_std;
-                        }
-                        rec->P[e] = b + q;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- _calc_dist_fun (Tracking.py:530-574) ----
     double bestd[4];
     int bestj[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) { bestd[q] = 0.0; bestj[q] = -1; }
+
     for (int c0 = 0; c0 < T; c0 += kGateChunk) {
         const int tc = min(kGateChunk, T - c0);
-        // C_g = P[:6,:6] + diag((spread/2)^2) + group_disp_est   (Tracking.py:551)
-        for (int e = tid; e < tc * 36; e += kThreads) {
-            int jl = e / 36, a = (e % 36) / 6, b = e % 6;
-            const TrackRec *rec = trk + L.slot[c0 + jl];
-            double rm = 0.0;
-            if (a == b) { double hh = rec->spread[a] / 2; rm = hh * hh; }
-            L.gate[jl * 72 + a * 6 + b] = (rec->P[a * 9 + b] + rm) + rec->gd[a * 6 + b];
+        // ---- one wave per track: _predict_all (Tracking.py:591-596; filterpy predict; motion model
+        //      constants.py:195-215) fused with the gate matrix of _calc_dist_fun (Tracking.py:549-551) ----
+        for (int jl = wave; jl < tc; jl += kWaves) {
+            TrackRec *rec = trk + L.slot[c0 + jl];
+            const double dtm = rec->lifetime + dt;
+            const double h = 0.5 * (dtm * dtm);
+            for (int e = lane; e < 81; e += 64) Pw[e] = rec->P[e];
+            if (lane < 9) xw[lane] = rec->x[lane];
+            wave_sync();
+            // A = F P.  F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense
+            // dot product reduces to these terms (the others are exact zeros).
+            for (int e = lane; e < 81; e += 64) {
+                const int i = e / 9, c = e % 9;
+                if (i < dx && c < dx) {
+                    double a = Pw[e];
+                    if (i + 3 < dx) a += dtm * Pw[(i + 3) * 9 + c];
+                    if (i + 6 < dx) a += h * Pw[(i + 6) * 9 + c];
+                    Aw[e] = a;
+                }
+            }
+            double xn = 0.0;
+            if (lane < dx) {
+                xn = xw[lane];
+                if (lane + 3 < dx) xn += dtm * xw[lane + 3];
+                if (lane + 6 < dx) xn += h * xw[lane + 6];
+            }
+            wave_sync();
+            {
+                const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
+                for (int e = lane; e < 81; e += 64) {
+                    const int i = e / 9, c = e % 9;
+                    if (i < dx && c < dx) {
+                        double b = Aw[e];  // B = A F^T
+                        if (c + 3 < dx) b += Aw[i * 9 + c + 3] * dtm;
+                        if (c + 6 < dx) b += Aw[i * 9 + c + 6] * h;
+                        double q = 0.0;
+                        if (i / 3 == c / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
+                            const int qi = i % 3, qc = c % 3, sdeg = qi + qc;
+                            const double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
+                                              : sdeg == 3 ? dtm : 1.0;
+                            q = base * cfg.kf_q_std;
+                        }
+                        const double pn = b + q;
+                        rec->P[e] = pn;
+                        Pw[e] = pn;
+                    }
+                }
+                if (lane < dx) { rec->x[lane] = xn; xw[lane] = xn; }
+            }
+            wave_sync();
+            // C_g = P[:6,:6] + diag((spread/2)^2) + group_disp_est ; inverse and log|det| (Tracking.py:551-560)
+            {
+                double a = 1.0;
+                if (lane < 36) {
+                    const int r = lane / 6, c = lane % 6;
+                    double rm = 0.0;
+                    if (r == c) { const double hh = rec->spread[r] / 2; rm = hh * hh; }
+                    a = (Pw[r * 9 + c] + rm) + rec->gd[lane];
+                }
+                double inv, det;
+                if (!lu6_inverse_wave(a, lane, inv, det)) err |= ERR_SINGULAR;
+                double *G = gate + jl * kGateStride;
+                if (lane < 36) G[lane] = inv;
+                if (lane == 0) G[36] = dlog(fabs(det));
+                if (lane < 6) G[37 + lane] = xw[lane];
+            }
+            wave_sync();
         }
         __syncthreads();
-        if (tid < tc) {
-            const TrackRec *rec = trk + L.slot[c0 + tid];
-            double inv[36], det;
-            bool ok = lu6_inverse(L.gate + tid * 72, 6, inv, det);
-            if (!ok) err |= ERR_SINGULAR;
-#pragma unroll
-            for (int e = 0; e < 36; e++) L.gate[tid * 72 + e] = inv[e];
-            L.gate[tid * 72 + 36] = dlog(fabs(det));
-#pragma unroll
-            for (int a = 0; a < 6; a++) L.gate[tid * 72 + 37 + a] = rec->x[a];
-        }
-        __syncthreads();
+        STAMP(1);  // predict + gate matrices
+        // ---- gate every point against the chunk's tracks (Tracking.py:553-572) ----
         for (int jl = 0; jl < tc; jl++) {
-            const double *G = L.gate + jl * 72;
+            const double *G = gate + jl * kGateStride;
             double Ci[36];
 #pragma unroll
             for (int e = 0; e < 36; e++) Ci[e] = G[e];
@@ -299,6 +318,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
             }
         }
         __syncthreads();
+        STAMP(2);  // gating
     }
 
     // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
@@ -312,10 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
             mybal[q] = 0;
             if (blk < NB) {  // wave-uniform
                 const int cls = (i < n) ? bestj[q] + 1 : -1;
-                if (i < n) {
-                    L.assoc[i] = bestj[q];
-                    if (assoc_out) assoc_out[(size_t)s * NP + i] = bestj[q];
-                }
+                if (i < n && assoc_out) assoc_out[(size_t)s * NP + i] = bestj[q];
                 for (int c = 0; c <= T; c++) {
                     unsigned long long b = __ballot(cls == c);
                     if (cls == c) mybal[q] = b;
@@ -346,6 +363,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         }
         __syncthreads();
     }
+    STAMP(3);  // class split
 
     // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, ring bookkeeping,
     //      N_est, spread_est; one lane per (track, dimension) ----
@@ -358,9 +376,18 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
             continue;
         }
         const double *col = L.p6 + m * NP;
-        double sum = 0.0, mn = col[L.perm[off]], mx = mn;
-        for (int r = 0; r < nj; r++) {  // np.mean(axis=0): sequential in row order
-            double v = col[L.perm[off + r]];
+        const int *pm = L.perm + off;
+        double sum = 0.0, mn = col[pm[0]], mx = mn;
+        int r = 0;
+        for (; r + 4 <= nj; r += 4) {  // np.mean(axis=0): sequential in row order; loads batched
+            const int i0 = pm[r], i1 = pm[r + 1], i2 = pm[r + 2], i3 = pm[r + 3];
+            const double v0 = col[i0], v1 = col[i1], v2 = col[i2], v3 = col[i3];
+            sum += v0; sum += v1; sum += v2; sum += v3;
+            mn = v0 < mn ? v0 : mn; mn = v1 < mn ? v1 : mn; mn = v2 < mn ? v2 : mn; mn = v3 < mn ? v3 : mn;
+            mx = v0 > mx ? v0 : mx; mx = v1 > mx ? v1 : mx; mx = v2 > mx ? v2 : mx; mx = v3 > mx ? v3 : mx;
+        }
+        for (; r < nj; r++) {
+            const double v = col[pm[r]];
             sum += v;
             mn = v < mn ? v : mn;
             mx = v > mx ? v : mx;
@@ -399,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         }
     }
     __syncthreads();
+    STAMP(4);  // centroid/min/max/spread
     // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
     for (int j = tid; j < T; j += kThreads) {
         if (L.cls_n[j + 1] > 0) {
@@ -408,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
     }
     // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track
     {
-        double *stk = L.gate + tid;  // gate|wsc are idle here: 6 x 256 doubles of pairwise stack
+        double *stk = L.work + tid;  // gate / wave scratch are idle here
         for (int task = tid; task < T * 21; task += kThreads) {
             const int j = task / 21;
             int e = task % 21, a = 0;
@@ -429,6 +457,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
             if (a != b) rec->gd[b * 6 + a] = (1 - al) * rec->gd[b * 6 + a] + al * D;
         }
     }
+    STAMP(5);  // dispersion matrices (wave 0's share)
     // track ring rows: first min(n_j, ring_rows) rows of the cloud, all 8 columns, from the input block
     for (int j = 0; j < T; j++) {
         const int nj = L.cls_n[j + 1];
@@ -440,6 +469,7 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         for (int e = tid; e < keep * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[off + (e >> 3)] * 8 + (e & 7)];
     }
     __syncthreads();
+    STAMP(6);  // track ring rows + barrier (includes waiting for the other waves' dispersion work)
 
     // ---- _maintain_tracks (Tracking.py:513-528) ----
     if (wave == 0) {
@@ -467,110 +497,95 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         for (int j = tid; j < Told; j += kThreads) { L.slot[j] = L.slot2[j]; order[j] = L.slot2[j]; }
     }
     __syncthreads();
+    STAMP(7);  // maintenance
 
-    // ---- _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy update ----
-    for (int c0 = 0; c0 < T; c0 += kGateChunk) {
-        const int tc = min(kGateChunk, T - c0);
-        if (tid < tc) {
-            const TrackRec *rec = trk + L.slot[c0 + tid];
-            double *G = L.gate + tid * 72;  // SI[36] | Rc[36]
+    // ---- _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy update;
+    //      one wave per track, wave-local ordering only ----
+    for (int j = wave; j < T; j += kWaves) {
+        TrackRec *rec = trk + L.slot[j];
+        for (int e = lane; e < 81; e += 64) Pw[e] = rec->P[e];
+        if (lane < 9) xw[lane] = rec->x[lane];
+        if (lane < 6) yw[lane] = rec->centroid[lane] - rec->x[lane];
+        {
             const double N = (double)rec->point_num;
             const double den = (rec->n_est - 1) * N;
             if (den == 0.0) err |= ERR_DIVZERO;
             const double coef = (rec->n_est - N) / den;
-            double SI[36], det;
-            for (int a = 0; a < 6; a++)
-                for (int b = 0; b < 6; b++) {
-                    double rm = 0.0;
-                    if (a == b) { double hh = rec->spread[a] / 2; rm = hh * hh; }
-                    const double rc = rm / N + coef * rec->gd[a * 6 + b];
-                    G[36 + a * 6 + b] = rc;
-                    G[a * 6 + b] = rec->P[a * 9 + b] + rc;  // S = H P H^T + R
-                }
-            if (!lu6_inverse(G, 6, SI, det)) err |= ERR_SINGULAR;
-#pragma unroll
-            for (int e = 0; e < 36; e++) G[e] = SI[e];
+            double a = 1.0;
+            if (lane < 36) {
+                const int r = lane / 6, c = lane % 6;
+                double rm = 0.0;
+                if (r == c) { const double hh = rec->spread[r] / 2; rm = hh * hh; }
+                const double rc = rm / N + coef * rec->gd[lane];
+                Rcw[lane] = rc;
+                a = rec->P[r * 9 + c] + rc;  // S = H P H^T + R
+            }
+            double inv, det;
+            if (!lu6_inverse_wave(a, lane, inv, det)) err |= ERR_SINGULAR;
+            if (lane < 36) SIw[lane] = inv;
         }
-        __syncthreads();
-        const int rounds = (tc + kWaves - 1) / kWaves;
-        for (int r = 0; r < rounds; r++) {
-            const int jl = r * kWaves + wave;
-            const bool act = jl < tc;
-            double *W = L.wsc + wave * 288;  // P[81] | A[81] | K[54] | C1[54] | x[9] | y[6]
-            double *Pw = W, *Aw = W + 81, *Kw = W + 162, *C1 = W + 216, *xw = W + 270, *yw = W + 279;
-            TrackRec *rec = act ? trk + L.slot[c0 + jl] : nullptr;
-            const double *SI = L.gate + jl * 72, *Rc = SI + 36;
-            if (act) {
-                for (int e = lane; e < 81; e += 64) Pw[e] = rec->P[e];
-                if (lane < 9) xw[lane] = rec->x[lane];
-                if (lane < 6) yw[lane] = rec->centroid[lane] - rec->x[lane];
+        wave_sync();
+        if (lane < 54) {  // K = P H^T S^-1
+            const int i = lane / 6, c = lane % 6;
+            if (i < dx) {
+                double a = Pw[i * 9] * SIw[c];
+                for (int k = 1; k < 6; k++) a += Pw[i * 9 + k] * SIw[k * 6 + c];
+                Kw[lane] = a;
             }
-            __syncthreads();
-            if (act && lane < 54) {  // K = P H^T S^-1
-                const int i = lane / 6, c = lane % 6;
-                if (i < dx) {
-                    double a = Pw[i * 9] * SI[c];
-                    for (int k = 1; k < 6; k++) a += Pw[i * 9 + k] * SI[k * 6 + c];
-                    Kw[lane] = a;
-                }
-            }
-            __syncthreads();
-            double xnew = 0.0;
-            if (act) {
-                if (lane < dx) {  // x = x + K y
-                    double a = Kw[lane * 6] * yw[0];
-                    for (int k = 1; k < 6; k++) a += Kw[lane * 6 + k] * yw[k];
-                    xnew = xw[lane] + a;
-                }
-                for (int e = lane; e < 81; e += 64) {  // A = (I - K H) P
-                    const int i = e / 9, c = e % 9;
-                    if (i < dx && c < dx) {
-                        double a = 0.0;
-                        for (int k = 0; k < dx; k++) {
-                            const double d = (i == k) ? 1.0 : 0.0;
-                            const double ikh = k < 6 ? d - Kw[i * 6 + k] : d;
-                            a = (k == 0) ? ikh * Pw[c] : a + ikh * Pw[k * 9 + c];
-                        }
-                        Aw[e] = a;
-                    }
-                }
-                if (lane < 54) {  // C1 = K R
-                    const int i = lane / 6, c = lane % 6;
-                    if (i < dx) {
-                        double a = Kw[i * 6] * Rc[c];
-                        for (int k = 1; k < 6; k++) a += Kw[i * 6 + k] * Rc[k * 6 + c];
-                        C1[lane] = a;
-                    }
-                }
-            }
-            __syncthreads();
-            if (act) {
-                for (int e = lane; e < 81; e += 64) {  // P = A (I-KH)^T + C1 K^T
-                    const int i = e / 9, c = e % 9;
-                    if (i < dx && c < dx) {
-                        double b = 0.0;
-                        for (int k = 0; k < dx; k++) {
-                            const double d = (c == k) ? 1.0 : 0.0;
-                            const double ikh = k < 6 ? d - Kw[c * 6 + k] : d;
-                            b = (k == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + k] * ikh;
-                        }
-                        double c2 = C1[i * 6] * Kw[c * 6];
-                        for (int k = 1; k < 6; k++) c2 += C1[i * 6 + k] * Kw[c * 6 + k];
-                        rec->P[e] = b + c2;
-                    }
-                }
-                if (lane < dx) {
-                    if (lane == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
-                        const double var = rec->centroid[0] - xnew;
-                        if (!(var == 0.0) && rec->lifetime == 0.0) xnew += var * 0.4;
-                    }
-                    rec->x[lane] = xnew;
-                }
-            }
-            __syncthreads();
         }
+        wave_sync();
+        double xnew = 0.0;
+        if (lane < dx) {  // x = x + K y
+            double a = Kw[lane * 6] * yw[0];
+            for (int k = 1; k < 6; k++) a += Kw[lane * 6 + k] * yw[k];
+            xnew = xw[lane] + a;
+        }
+        for (int e = lane; e < 81; e += 64) {  // A = (I - K H) P
+            const int i = e / 9, c = e % 9;
+            if (i < dx && c < dx) {
+                double a = 0.0;
+                for (int k = 0; k < dx; k++) {
+                    const double d = (i == k) ? 1.0 : 0.0;
+                    const double ikh = k < 6 ? d - Kw[i * 6 + k] : d;
+                    a = (k == 0) ? ikh * Pw[c] : a + ikh * Pw[k * 9 + c];
+                }
+                Aw[e] = a;
+            }
+        }
+        if (lane < 54) {  // C1 = K R
+            const int i = lane / 6, c = lane % 6;
+            if (i < dx) {
+                double a = Kw[i * 6] * Rcw[c];
+                for (int k = 1; k < 6; k++) a += Kw[i * 6 + k] * Rcw[k * 6 + c];
+                C1w[lane] = a;
+            }
+        }
+        wave_sync();
+        for (int e = lane; e < 81; e += 64) {  // P = A (I-KH)^T + C1 K^T
+            const int i = e / 9, c = e % 9;
+            if (i < dx && c < dx) {
+                double b = 0.0;
+                for (int k = 0; k < dx; k++) {
+                    const double d = (c == k) ? 1.0 : 0.0;
+                    const double ikh = k < 6 ? d - Kw[c * 6 + k] : d;
+                    b = (k == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + k] * ikh;
+                }
+                double c2 = C1w[i * 6] * Kw[c * 6];
+                for (int k = 1; k < 6; k++) c2 += C1w[i * 6 + k] * Kw[c * 6 + k];
+                rec->P[e] = b + c2;
+            }
+        }
+        if (lane < dx) {
+            if (lane == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
+                const double var = rec->centroid[0] - xnew;
+                if (!(var == 0.0) && rec->lifetime == 0.0) xnew += var * 0.4;
+            }
+            rec->x[lane] = xnew;
+        }
+        wave_sync();
     }
 
+    STAMP(8);  // update (wave 0's tracks)
     // ---- batch.add_frame(unassigned) on the global ring + DBSCAN trigger (Tracking.py:689-697) ----
     const int nun = L.cls_n[0];
     if (tid == 0) {
@@ -606,11 +621,11 @@ __global__ __launch_bounds__(kThreads) void k_track(DevCfg cfg, DevState st, con
         for (int e = tid; e < nun * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[e >> 3] * 8 + (e & 7)];
     }
     if (err) atomicOr(&hdr->err, err);
+    STAMP(9);  // global ring append
     if (tid == 0 && st.stats) {
-        // algorithmic bytes of this scene-frame: points in, assoc out,
-        // track records read+written, unassigned rows appended to the ring
-        const int Tin = L.misc[2];
-        int ring_rows = 0;  // rows appended to per-track rings (kept for the feature map)
+        // algorithmic bytes of this scene-frame: points in, assoc out, track records
+        // read+written, unassigned rows appended to the global ring, rows appended to track rings
+        int ring_rows = 0;
         for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
         atomicAdd(&st.stats[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun + 64 * ring_rows));
         atomicAdd(&st.stats[2], 1ULL);

@@ -200,7 +200,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.g_ring, S * (size_t)ring * max_pts * 8 * sizeof(double));
     ALLOC(c->d_posture, MMW_NKP * sizeof(float));
     ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
-    ALLOC(c->d_stats, 8 * sizeof(unsigned long long));
+    ALLOC(c->d_stats, 32 * sizeof(unsigned long long));
     ALLOC(c->d_db_list, 3 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
 #undef ALLOC
@@ -209,7 +209,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     c->st.db_list = c->d_db_list;
     c->st.db_count = c->d_db_count;
     if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
@@ -319,6 +319,7 @@ int mmw_normalize(mmw_ctx *c, const double *raw, const int32_t *n_raw, double *p
 int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
 {
     if (!c || !pts || !n_pts || !dt) return fail(c, MMW_E_ARG, "mmw_step: null input pointer");
+    if (((uintptr_t)pts & 15) != 0) return fail(c, MMW_E_ARG, "mmw_step: pts must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
     prof_begin(c, MMW_K_TRACK, ep);
@@ -531,10 +532,17 @@ int mmw_stats_get(mmw_ctx *c, uint64_t *out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
 }
+int mmw_stats_get_ext(mmw_ctx *c, uint64_t *out)
+{
+    if (!c || !out) return MMW_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
 int mmw_stats_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
-    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 32 * sizeof(uint64_t), c->stream));
     return MMW_OK;
 }
 

@@ -129,4 +129,78 @@ __device__ inline unsigned long long lanemask_lt()
     return lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
 }
 
+// Ordering point between phases that exchange data through LDS inside ONE wave: DS operations
+// of a wave execute in issue order, so only the compiler has to be kept from moving accesses.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The same 6x6 LU / determinant / inverse as lu6_inverse(), one matrix per wave: lane r*6+c
+// (< 36) owns element [r][c]; rows/columns travel by cross-lane reads.  Every element sees
+// exactly the operations of the serial version in the same order, so results are bit-equal;
+// the wave needs ~10 VGPRs instead of two 36-element register arrays.  All 64 lanes must call.
+__device__ __forceinline__ bool lu6_inverse_wave(double a, int lane, double &inv_elem, double &det)
+{
+    const int r = lane < 36 ? lane / 6 : 0, c = lane < 36 ? lane % 6 : 0;
+    int prow = r;  // original index of the row now at position r
+    bool neg = false, ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        double best = fabs(__shfl(a, k * 6 + k));
+#pragma unroll
+        for (int r2 = k + 1; r2 < 6; r2++) {
+            const double v = fabs(__shfl(a, r2 * 6 + k));
+            if (v > best) { best = v; p = r2; }
+        }
+        if (!(best > 0.0)) ok = false;
+        {   // swap rows k and p (no-op when p == k); p is wave-uniform
+            const int srow = (r == k) ? p : ((r == p) ? k : r);
+            a = __shfl(a, srow * 6 + c);
+            prow = __shfl(prow, srow * 6 + c);
+            if (p != k) neg = !neg;
+        }
+        const double akk = __shfl(a, k * 6 + k), ark = __shfl(a, r * 6 + k), akc = __shfl(a, k * 6 + c);
+        if (r > k) {
+            const double l = ark / akk;
+            if (c == k) a = l;
+            else if (c > k) a = a - l * akc;
+        }
+    }
+    double d = __shfl(a, 0);
+#pragma unroll
+    for (int k = 1; k < 6; k++) d = d * __shfl(a, k * 7);
+    det = neg ? -d : d;
+    // forward substitution, column c of the identity (permuted): y_r = b_r - sum_{k<r} L[r][k] y_k
+    double y = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++) {
+        double s = (prow == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < rr; k++) {
+            const double lrk = __shfl(a, r * 6 + k), yk = __shfl(y, k * 6 + c);
+            s = s - lrk * yk;
+        }
+        if (r == rr) y = s;
+    }
+    // back substitution: x_r = (y_r - sum_{k>r} U[r][k] x_k) / U[r][r]
+    double x = 0.0;
+#pragma unroll
+    for (int rr = 5; rr >= 0; rr--) {
+        double s = y;
+#pragma unroll
+        for (int k = rr + 1; k < 6; k++) {
+            const double urk = __shfl(a, r * 6 + k), xk = __shfl(x, k * 6 + c);
+            s = s - urk * xk;
+        }
+        const double urr = __shfl(a, r * 7);
+        if (r == rr) x = s / urr;
+    }
+    inv_elem = x;
+    return ok;
+}
+
 }  // namespace mmw
