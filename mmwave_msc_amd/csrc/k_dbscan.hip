@@ -19,7 +19,7 @@
 // Size classes: the cloud is the concatenation of <= ring frames of UNASSIGNED points, so
 // its size U varies from a few dozen (steady state: clutter only) to ring*max_pts.  LDS is
 // carved per class so that small clouds do not pay for the largest one:
-//   class 0: U <= 256   one wave64 per scene, all 8 columns staged in LDS (no re-reads)
+//   class 0: U <= 256   256 threads, thread i owns point i with all 8 columns in registers
 //   class 1: U <= 768   256 threads
 //   class 2: U <= 1920  256 threads
 // k_track appends every scene that must cluster to the work list of its class.
@@ -45,8 +45,7 @@ namespace mmw {
 #endif
 
 struct DbLds {
-    double *X, *Y, *Z;             // [UM] by point index
-    double *F8;                    // [5][UM] columns 3..7 by point index (class 0 only)
+    double *X, *Y, *Z;             // [UM] by point index during the build, by tree position afterwards
     double *key;                   // [UM] split value by position (build) ...
     unsigned long long *mask;      // ... aliased: per-position leaf-state mask (query/label)
     int *idx;                      // [UM] position -> point index
@@ -93,7 +92,6 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(X, double, UM)
     CARVE(Y, double, UM)
     CARVE(Z, double, UM)
-    CARVE(F8, double, all8 ? 5 * UM : 0)
     if constexpr (WRITE) L->mask = (unsigned long long *)(base + off);
     CARVE(key, double, UM)
     CARVE(idx, int, UM)
@@ -111,7 +109,7 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(mm, unsigned long long, half * 16)
     CARVE(sdim, int, half)
     CARVE(lbase, int, half)
-    CARVE(blk, int, NB + 1)
+    CARVE(blk, int, (NB + 1) > 64 ? (NB + 1) : 64)
     CARVE(misc, int, 16)
     CARVE(cnt, int, NB *(CL + 1))
     CARVE(cl_n, int, CL + 2)
@@ -186,17 +184,20 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     const int tid = threadIdx.x, lane = tid & 63;
     const double rw = cfg.db_range_weight, zw = cfg.db_z_weight;
 
-    // ---- stage x,y,z (and the other five columns for small clouds); identity order ----
+    // ---- stage x,y,z in LDS (by point index); identity order.  ALL8 (U <= NT): thread i owns
+    //      point i and keeps all 8 of its columns in registers for the whole tree build ----
+    (void)UMc;
+    double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0;
+    int mypos = tid;  // ALL8: tree position of point `tid`
     if (ALL8) {
-        for (int e = tid; e < U * 8; e += NT) {
-            const int i = e >> 3, f = e & 7;
-            const double v = src.row(i)[f];
-            if (f == 0) L.X[i] = v;
-            else if (f == 1) L.Y[i] = v;
-            else if (f == 2) L.Z[i] = v;
-            else L.F8[(f - 3) * UMc + i] = v;
+        if (tid < U) {
+            const double2 *r2 = reinterpret_cast<const double2 *>(src.row(tid));
+            const double2 a = r2[0], b = r2[1], c = r2[2], d = r2[3];
+            f0 = a.x; f1 = a.y; f2 = b.x; f3 = b.y; f4 = c.x; f5 = c.y; f6 = d.x; f7 = d.y;
+            L.X[tid] = f0; L.Y[tid] = f1; L.Z[tid] = f2;
+            L.idx[tid] = tid;
+            L.lab[tid] = -1;
         }
-        for (int i = tid; i < U; i += NT) { L.idx[i] = i; L.lab[i] = -1; }
     } else {
         for (int i = tid; i < U; i += NT) {
             const double *r = src.row(i);
@@ -214,13 +215,96 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         if (f == 0) return L.X[i];
         if (f == 1) return L.Y[i];
         if (f == 2) return L.Z[i];
-        if (ALL8) return L.F8[(f - 3) * UMc + i];
         return src.row(i)[f];
     };
 
     DSTAMP(0);
     // ---- _recursive_build, level by level (_binary_tree.pxi.tp:1040-1084) ----
     int *idx = L.idx, *idx2 = L.idx2;
+    if (ALL8) {
+        // Thread-per-point build: min/max by fire-and-forget LDS atomics, rank by a scan of the
+        // node's keys, stable partition by ballots in lane (= point index) order.
+        const int wave = tid >> 6;
+        for (int level = 0; level + 1 < n_levels; level++) {
+            const int first = (1 << level) - 1, nn = 1 << level;
+            for (int e = tid; e < nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;
+            __syncthreads();
+            const bool act = tid < U;
+            const int node = act ? node_of(L, mypos, level) : -1;
+            if (act) {  // find_node_split_dim over all 8 features (_binary_tree.pxi.tp:598-645)
+                unsigned long long *m = &L.mm[(node - first) * 16];
+                atomicMin(&m[0], sortable(f0)); atomicMax(&m[1], sortable(f0));
+                atomicMin(&m[2], sortable(f1)); atomicMax(&m[3], sortable(f1));
+                atomicMin(&m[4], sortable(f2)); atomicMax(&m[5], sortable(f2));
+                atomicMin(&m[6], sortable(f3)); atomicMax(&m[7], sortable(f3));
+                atomicMin(&m[8], sortable(f4)); atomicMax(&m[9], sortable(f4));
+                atomicMin(&m[10], sortable(f5)); atomicMax(&m[11], sortable(f5));
+                atomicMin(&m[12], sortable(f6)); atomicMax(&m[13], sortable(f6));
+                atomicMin(&m[14], sortable(f7)); atomicMax(&m[15], sortable(f7));
+            }
+            __syncthreads();
+            DSTAMP(6);  // (diagnostic) min/max
+            if (tid < nn) {
+                int jmax = 0;
+                double best = 0;
+                for (int f = 0; f < 8; f++) {
+                    const double spread = unsortable(L.mm[(tid * 8 + f) * 2 + 1]) - unsortable(L.mm[(tid * 8 + f) * 2]);
+                    if (spread > best) { best = spread; jmax = f; }
+                }
+                L.sdim[tid] = jmax;
+            }
+            __syncthreads();
+            double kp = 0.0;
+            int s = 0, e = 0;
+            if (act) {
+                const int sd = L.sdim[node - first];
+                kp = sd == 0 ? f0 : sd == 1 ? f1 : sd == 2 ? f2 : sd == 3 ? f3 : sd == 4 ? f4 : sd == 5 ? f5 : sd == 6 ? f6 : f7;
+                L.key[mypos] = kp;
+                s = L.nstart[node];
+                e = L.nend[node];
+            }
+            __syncthreads();
+            DSTAMP(7);  // (diagnostic) split dim + keys
+            // partition_node_indices: the n_mid smallest under (value, index) go left
+            // (_partition_nodes.pyx:35-39); both halves keep ascending point-index order.
+            bool left = false;
+            if (act) {
+                int c = 0;
+#pragma unroll 4
+                for (int q = s; q < e; q++) {
+                    const double kq = L.key[q];
+                    const int iq = idx[q];
+                    c += (kq < kp || (kq == kp && iq < tid)) ? 1 : 0;
+                }
+                left = c < (e - s) / 2;
+            }
+            DSTAMP(8);  // (diagnostic) rank scan
+            unsigned long long mine = 0;
+            for (int nd = 0; nd < nn; nd++) {
+                const unsigned long long b = __ballot(act && left && node == first + nd);
+                if (node == first + nd) mine = b;
+                if (lane == 0) L.blk[wave * nn + nd] = __popcll(b);
+            }
+            __syncthreads();
+            int np = mypos;
+            if (act) {
+                int lc = __popcll(mine & lanemask_lt());  // lefts of my node with a smaller point index
+                for (int w = 0; w < wave; w++) lc += L.blk[w * nn + (node - first)];
+                const int nmid = (e - s) / 2;
+                np = left ? s + lc : s + nmid + ((mypos - s) - lc);
+                idx2[np] = tid;
+            }
+            if (tid < nn) {
+                const int nd = first + tid, ss = L.nstart[nd], ee = L.nend[nd], nmid = (ee - ss) / 2;
+                L.nstart[2 * nd + 1] = ss; L.nend[2 * nd + 1] = ss + nmid;
+                L.nstart[2 * nd + 2] = ss + nmid; L.nend[2 * nd + 2] = ee;
+            }
+            DSTAMP(9);  // (diagnostic) partition
+            mypos = np;
+            { int *t = idx; idx = idx2; idx2 = t; }
+            __syncthreads();
+        }
+    } else
     for (int level = 0; level + 1 < n_levels; level++) {
         const int first = (1 << level) - 1, nn = 1 << level;
         for (int e = tid; e < nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;  // [node][f][0]=min key, [1]=max key
@@ -347,11 +431,25 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         const int node = t / 3;
         L.ncen[t] = L.nsum[t] / (double)(L.nend[node] - L.nstart[node]);
     }
+    // From here on x,y,z are addressed by TREE POSITION (leaf ranges become contiguous reads):
+    // permute the three columns in place (every by-index read above is complete: barrier in the loop).
+    if (ALL8) {
+        __syncthreads();
+        if (tid < U) { L.X[mypos] = f0; L.Y[mypos] = f1; L.Z[mypos] = f2; }
+    } else {
+        for (int c = 0; c < 3; c++) {
+            double *col = c == 0 ? L.X : (c == 1 ? L.Y : L.Z);
+            __syncthreads();
+            for (int p = tid; p < U; p += NT) L.key[p] = col[idx[p]];
+            __syncthreads();
+            for (int p = tid; p < U; p += NT) col[p] = L.key[p];
+        }
+    }
     __syncthreads();
     for (int p0 = 0; p0 < U; p0 += NT) {
         const int p = p0 + tid;
         const bool act = p < U;
-        const int i = act ? idx[p] : 0;
+        const int i = act ? p : 0;
         const double px = L.X[i], py = L.Y[i], pz = L.Z[i];
         int node = 0;
         for (int level = 0; level < n_levels; level++) {
@@ -377,8 +475,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     // ---- BallTree.query_radius(X, eps) for every point (_binary_tree.pxi.tp:1903-1980) ----
     const int lbits = n_levels - 1;
     for (int p = tid; p < U; p += NT) {
-        const int i = idx[p];
-        const double px = L.X[i], py = L.Y[i], pz = L.Z[i];
+        const double px = L.X[p], py = L.Y[p], pz = L.Z[p];
         unsigned long long m = 0;
         int count = 0, node = 0, level = 0;
         for (;;) {
@@ -401,10 +498,11 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 const int s = L.nstart[node], e = L.nend[node];
                 if (state == 1) count += e - s;
                 else
-                    for (int q = s; q < e; q++) {
-                        const int iq = idx[q];
-                        count += alt_dist(px, py, pz, L.X[iq], L.Y[iq], L.Z[iq], rw, zw) <= eps ? 1 : 0;
-                    }
+                {
+#pragma unroll 4
+                    for (int q = s; q < e; q++)
+                        count += alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1 : 0;
+                }
             }
             while (node != 0 && (node & 1) == 0) { node = (node - 1) >> 1; level--; }  // climb while right child
             if (node == 0) break;
@@ -441,17 +539,14 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         while (fcount > 0) {
             for (int q = tid; q < U; q += NT) {
                 if (L.lab[q] >= 0) continue;
-                const int iq = idx[q], lq = L.leafpos[q];
-                const double qx = L.X[iq], qy = L.Y[iq], qz = L.Z[iq];
+                const int lq = L.leafpos[q];
+                const double qx = L.X[q], qy = L.Y[q], qz = L.Z[q];
                 bool hit = false;
                 for (int f = 0; f < fcount && !hit; f++) {
                     const int pp = front[f];
                     const int stt = (int)((L.mask[pp] >> (2 * lq)) & 3ULL);
                     if (stt == 1) hit = true;
-                    else if (stt == 2) {
-                        const int ip = idx[pp];
-                        hit = alt_dist(L.X[ip], L.Y[ip], L.Z[ip], qx, qy, qz, rw, zw) <= eps;
-                    }
+                    else if (stt == 2) hit = alt_dist(L.X[pp], L.Y[pp], L.Z[pp], qx, qy, qz, rw, zw) <= eps;
                 }
                 if (hit) {
                     L.lab[q] = n_clusters;
@@ -582,11 +677,7 @@ __global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, in
         double sum = 0.0, mn = 0.0, mx = 0.0;
         for (int r = 0; r < n; r++) {
             const int i = memb[off + r];
-            double v;
-            if (m == 0) v = L.X[i];
-            else if (m == 1) v = L.Y[i];
-            else if (m == 2) v = L.Z[i];
-            else v = ALL8 ? L.F8[(m - 3) * UMc + i] : src.row(i)[m];
+            const double v = src.row(i)[m];  // (LDS x,y,z are in tree-position order by now)
             sum += v;
             mn = (r == 0 || v < mn) ? v : mn;
             mx = (r == 0 || v > mx) ? v : mx;

@@ -31,9 +31,9 @@ tot = float(out[8:18].sum())
 print(f"k_track: {frames:.0f} scene-frames, mean cycles/WG {tot / frames:.0f}")
 for i, nme in enumerate(names_t):
     print(f"  {nme:28s} {float(out[8 + i]) / frames:9.0f} cyc  {100 * float(out[8 + i]) / tot:5.1f} %")
-names_d = ["stage", "tree build", "centroids+radii", "queries", "labelling", "output+spawn"]
+names_d = ["stage", "tree build (rest)", "centroids+radii", "queries", "labelling", "-", "  build: min/max", "  build: split dim+keys", "  build: rank scan", "  build: partition"]
 calls = float(out[3])
-totd = float(out[20:26].sum())
+totd = float(out[20:30].sum())
 if calls and totd:
     print(f"k_dbscan: {calls:.0f} calls, mean U {float(out[4]) / calls:.0f}, mean cycles/WG {totd / calls:.0f}")
     for i, nme in enumerate(names_d):
