@@ -48,6 +48,8 @@ struct TrackLds {
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+// levels of numpy's pairwise split above the 128-element leaves, i.e. LDS stack entries per thread
+__host__ __device__ inline int pw_depth(int n) { int d = 0; while (n > 128) { n = n - ((n / 2) - (n / 2) % 8); d++; } return d < kPwStackDepth ? d : kPwStackDepth; }
 
 // WRITE=false only sizes the layout.  (No `if (L)` null test: in the private address space a
 // null check on an alloca cannot be folded and would pin the struct in scratch memory.)
@@ -55,12 +57,15 @@ template <bool WRITE>
 __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
 {
     const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
-    const int work_a = kGateChunk * kGateStride + kWaves * kWaveScratch, work_b = kPwStackDepth * kThreads;
+    // One region, three lives: (1) gate matrices + per-wave scratch while tracks are predicted and
+    // points gated (points sit in registers then); (2) the SoA point tile + the pairwise-sum stack
+    // while cluster statistics are formed; (3) per-wave scratch again for the Kalman update.
+    const int work_a = kGateChunk * kGateStride + kWaves * kWaveScratch, work_b = 6 * NP + pw_depth(NP) * kThreads;
     size_t off = 0;
 #define CARVE(field, type, count)                            \
     if constexpr (WRITE) L->field = (type *)(base + off);    \
     off = align16(off + sizeof(type) * (size_t)(count));
-    CARVE(p6, double, 6 * NP)
+    if constexpr (WRITE) L->p6 = (double *)(base + off);
     CARVE(work, double, work_a > work_b ? work_a : work_b)
     CARVE(cen, double, c.t_cap * 6)
     CARVE(perm, int, NP)
@@ -150,7 +155,10 @@ __device__ __forceinline__ double np_pairwise_sum(F elem, int n, double *stk, in
     return ret;
 }
 
-__global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+// PPT = points per thread = ceil(max_pts / 256): a template so that per-point registers are not
+// reserved for points a configuration can never have.
+template <int PPT>
+__global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out, int parity)
 {
@@ -184,34 +192,27 @@ __global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, 
     double *W = L.work + kGateChunk * kGateStride + wave * kWaveScratch;
     double *Pw = W, *Aw = W + 81, *Kw = W + 162, *C1w = W + 216, *SIw = W + 270, *Rcw = W + 306, *xw = W + 342, *yw = W + 351;
 
-    // ---- stage points: coalesced read of the row-major block, SoA in LDS ----
-    // (16-byte lanes; eight loads in flight per thread before the first LDS store)
+    // ---- this thread's points (rows tid, tid+256, ...): columns 0..5 straight into registers with
+    //      16-byte loads; issued first so HBM latency hides under the track prediction below.
+    //      They are gated from registers and only then parked in the LDS tile for the statistics ----
+    double2 pr[PPT][3];
     {
         const double2 *src2 = reinterpret_cast<const double2 *>(pts);
-        const int n2 = n * 4;  // double2 elements
-        for (int e0 = 0; e0 < n2; e0 += 8 * kThreads) {
-            double2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + u * kThreads + tid;
-                v[u] = e < n2 ? src2[e] : double2{0.0, 0.0};
-            }
+        for (int q = 0; q < PPT; q++) {
+            const int i = q * kThreads + tid;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + u * kThreads + tid;
-                const int col = (e & 3) * 2, row = e >> 2;
-                if (e < n2 && col < 6) { L.p6[col * NP + row] = v[u].x; L.p6[(col + 1) * NP + row] = v[u].y; }
-            }
+            for (int u = 0; u < 3; u++) pr[q][u] = (i < n) ? src2[i * 4 + u] : double2{0.0, 0.0};
         }
     }
     for (int j = tid; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
     __syncthreads();
-    STAMP(0);  // stage points
+    STAMP(0);  // issue point loads
 
-    double bestd[4];
-    int bestj[4];
+    double bestd[PPT];
+    int bestj[PPT];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { bestd[q] = 0.0; bestj[q] = -1; }
+    for (int q = 0; q < PPT; q++) { bestd[q] = 0.0; bestj[q] = -1; }
 
     for (int c0 = 0; c0 < T; c0 += kGateChunk) {
         const int tc = min(kGateChunk, T - c0);
@@ -286,32 +287,30 @@ __global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, 
         __syncthreads();
         STAMP(1);  // predict + gate matrices
         // ---- gate every point against the chunk's tracks (Tracking.py:553-572) ----
-        for (int jl = 0; jl < tc; jl++) {
-            const double *G = gate + jl * kGateStride;
-            double Ci[36];
+        // (points in registers, the 6x6 inverse read from LDS as wave-uniform broadcasts: keeping it
+        //  in registers as well costs 72 VGPRs and a workgroup per CU)
 #pragma unroll
-            for (int e = 0; e < 36; e++) Ci[e] = G[e];
-            const double ld = G[36];
-            double hx[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) hx[a] = G[37 + a];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = q * kThreads + tid;
-                if (i < n) {
-                    double y[6];
-#pragma unroll
-                    for (int a = 0; a < 6; a++) y[a] = L.p6[a * NP + i] - hx[a];
+        for (int q = 0; q < PPT; q++) {
+            const int i = q * kThreads + tid;
+            if (q * kThreads < n) {  // wave-uniform
+                const double p0 = pr[q][0].x, p1 = pr[q][0].y, p2 = pr[q][1].x, p3 = pr[q][1].y, p4 = pr[q][2].x, p5 = pr[q][2].y;
+                for (int jl = 0; jl < tc; jl++) {
+                    const double *G = gate + jl * kGateStride;
+                    const double y0 = p0 - G[37], y1 = p1 - G[38], y2 = p2 - G[39], y3 = p3 - G[40], y4 = p4 - G[41], y5 = p5 - G[42];
                     double quad = 0.0;
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        double v = y[0] * Ci[k];
-#pragma unroll
-                        for (int a = 1; a < 6; a++) v += y[a] * Ci[a * 6 + k];
-                        if (k == 0) quad = v * y[0]; else quad += v * y[k];
+                        double v = y0 * G[k];
+                        v += y1 * G[6 + k];
+                        v += y2 * G[12 + k];
+                        v += y3 * G[18 + k];
+                        v += y4 * G[24 + k];
+                        v += y5 * G[30 + k];
+                        const double yk = k == 0 ? y0 : k == 1 ? y1 : k == 2 ? y2 : k == 3 ? y3 : k == 4 ? y4 : y5;
+                        if (k == 0) quad = v * yk; else quad += v * yk;
                     }
-                    const double d = ld + quad;
-                    if (d < cfg.tr_gate) {
+                    const double d = G[36] + quad;
+                    if (i < n && d < cfg.tr_gate) {
                         if (bestj[q] < 0 || d < bestd[q]) { bestj[q] = c0 + jl; bestd[q] = d; }
                     }
                 }
@@ -320,13 +319,24 @@ __global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, 
         __syncthreads();
         STAMP(2);  // gating
     }
+    // ---- park the points in the LDS tile (SoA, 6 columns) for the cluster statistics; the gate /
+    //      scratch area it overlays is dead until the update phase ----
+#pragma unroll
+    for (int q = 0; q < PPT; q++) {
+        const int i = q * kThreads + tid;
+        if (i < n) {
+            L.p6[0 * NP + i] = pr[q][0].x; L.p6[1 * NP + i] = pr[q][0].y;
+            L.p6[2 * NP + i] = pr[q][1].x; L.p6[3 * NP + i] = pr[q][1].y;
+            L.p6[4 * NP + i] = pr[q][2].x; L.p6[5 * NP + i] = pr[q][2].y;
+        }
+    }
 
     // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
     {
         const int NB = (n + 63) / 64;
-        unsigned long long mybal[4];
+        unsigned long long mybal[PPT];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
             const int blk = q * kWaves + wave;
             mybal[q] = 0;
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, 
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
             if (i < n) {
                 const int cls = bestj[q] + 1, blk = q * kWaves + wave;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, 
     }
     // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track
     {
-        double *stk = L.work + tid;  // gate / wave scratch are idle here
+        double *stk = L.work + 6 * NP + tid;  // behind the point tile
         for (int task = tid; task < T * 21; task += kThreads) {
             const int j = task / 21;
             int e = task % 21, a = 0;
@@ -634,16 +644,30 @@ __global__ __launch_bounds__(kThreads, 3) void k_track(DevCfg cfg, DevState st, 
     }
 }
 
+template <int PPT>
+static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+                           int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_track<PPT>), dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, parity);
+}
+
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream)
 {
-    const size_t lds = track_lds_bytes(cfg);
-    hipLaunchKernelGGL(k_track, dim3(cfg.n_scenes), dim3(kThreads), lds, stream, cfg, st, pts, n_pts, dt, assoc, db_n, parity);
+    const int ppt = (cfg.max_pts + kThreads - 1) / kThreads;
+    if (ppt <= 1) launch_track_t<1>(cfg, st, pts, n_pts, dt, assoc, db_n, parity, stream);
+    else if (ppt == 2) launch_track_t<2>(cfg, st, pts, n_pts, dt, assoc, db_n, parity, stream);
+    else launch_track_t<4>(cfg, st, pts, n_pts, dt, assoc, db_n, parity, stream);
 }
 
 hipError_t prepare_track(const DevCfg &cfg)
 {
-    return hipFuncSetAttribute((const void *)k_track, hipFuncAttributeMaxDynamicSharedMemorySize, (int)track_lds_bytes(cfg));
+    const int lds = (int)track_lds_bytes(cfg);
+    hipError_t e = hipFuncSetAttribute((const void *)k_track<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_track<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *)k_track<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 }  // namespace mmw
