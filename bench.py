@@ -215,7 +215,10 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 key = f"{S}x{N}x{args.tracks}"
-                traffic = tj.get(key, {}).get(_lib.load().mmw_kernel_name(dom).decode())
+                ent = tj.get(key, {}).get(_lib.load().mmw_kernel_name(dom).decode())
+                # FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, bytes per launch, from a
+                # separate rocprofv3 --pmc run of this workload (profiles/README.md)
+                traffic = ent.get("hbm_bytes_per_launch_fetch_x2") if isinstance(ent, dict) else ent
             except Exception:
                 traffic = None
         line = {

@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     const int nun = L.cls_n[0];
     if (tid == 0) {
         int len = hdr->g_len;
-        int gs[MMW_RING_MAX], gn[MMW_RING_MAX];
+        int *gs = L.misc + 4, *gn = L.misc + 8;  // small indexed arrays live in LDS, not in scratch
         for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
         while (len >= cfg.ring) {
             const int first = gs[0];

@@ -147,7 +147,7 @@ __device__ __forceinline__ bool lu6_inverse_wave(double a, int lane, double &inv
     const int r = lane < 36 ? lane / 6 : 0, c = lane < 36 ? lane % 6 : 0;
     int prow = r;  // original index of the row now at position r
     bool neg = false, ok = true;
-#pragma unroll
+#pragma unroll 1  // rolled on purpose: unrolled, the 6 steps keep ~60 extra VGPRs live
     for (int k = 0; k < 6; k++) {
         int p = k;
         double best = fabs(__shfl(a, k * 6 + k));
@@ -176,7 +176,7 @@ __device__ __forceinline__ bool lu6_inverse_wave(double a, int lane, double &inv
     det = neg ? -d : d;
     // forward substitution, column c of the identity (permuted): y_r = b_r - sum_{k<r} L[r][k] y_k
     double y = 0.0;
-#pragma unroll
+#pragma unroll 1
     for (int rr = 0; rr < 6; rr++) {
         double s = (prow == c) ? 1.0 : 0.0;
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ __forceinline__ bool lu6_inverse_wave(double a, int lane, double &inv
     }
     // back substitution: x_r = (y_r - sum_{k>r} U[r][k] x_k) / U[r][r]
     double x = 0.0;
-#pragma unroll
+#pragma unroll 1
     for (int rr = 5; rr >= 0; rr--) {
         double s = y;
 #pragma unroll
