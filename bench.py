@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--py-scenes", type=int, default=64)
     ap.add_argument("--py-frames", type=int, default=20)
     ap.add_argument("--c-scenes", type=int, default=1024)
+    ap.add_argument("--no-posture", action="store_true", help="skip the (untimed-for-value) feature-map + CNN leg")
     ap.add_argument("--gen-workers", type=int, default=-1,
                     help="processes for scene generation (-1 = auto; use 1 under rocprofv3: its preloaded tool initialises "
                          "the GPU before main(), and forking after that hangs)")
@@ -186,6 +187,41 @@ def main():
     stats = sb.stats()
     prof = {k: sb.profile_get(k) for k in (_lib.K_TRACK, _lib.K_DBSCAN, _lib.K_TABLE)}
 
+    # ---- secondary: the posture leg on the final state (features kernel -> MARS CNN -> keypoints).
+    #      Not part of `value`; reported so configs[3]/[4] (end-to-end) have a measured number. ----
+    posture = None
+    if not args.no_posture:
+        try:
+            from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+            cap = S * min(sb.track_cap, 2 * args.tracks)
+            d_feat = torch.empty((cap, sb.ring, 8, 8, 5), dtype=torch.float32, device=dev)
+            d_owner = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            model = MarsCNN.from_keras_weights(random_keras_weights(0, sb.ring)).to(dev)
+
+            def posture_iter():
+                nrow = sb.features_dev(d_feat.data_ptr(), d_owner.data_ptr(), cap)
+                with torch.no_grad():
+                    kp = model(d_feat[:nrow])
+                sb.set_keypoints_dev(kp.data_ptr(), d_owner.data_ptr(), nrow)
+                return nrow
+
+            for _ in range(2):
+                nrow = posture_iter()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                nrow = posture_iter()
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp) / reps
+            flop = 25187328.0 if sb.ring == 3 else 2837504.0
+            posture = {"tracks": int(nrow), "ms_per_iter": round(tp * 1e3, 3), "samples_per_s": round(nrow / tp, 1),
+                       "cnn_tflops_fp32": round(nrow * flop / tp / 1e12, 2), "mfma_fp32_peak_tflops": 157.3,
+                       "note": "features kernel + torch-ROCm CNN (fp32, random Keras-layout weights) + keypoint scatter on the final state; "
+                               "with this leg every frame the step would take ms_per_step + ms_per_iter"}
+        except Exception as exc:  # never lose the headline line over the secondary leg
+            posture = {"error": repr(exc)[:200]}
+
     parity = None
     if finals is not None:
         ntr = sb.num_tracks()
@@ -249,6 +285,8 @@ def main():
         line.update(cpu)
         if parity is not None:
             line["parity"] = parity
+        if posture is not None:
+            line["posture_leg"] = posture
         if "cpu_baseline" in cpu:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["cpu_baseline"]["value"], 1)
             line["speedup_vs_cpu_native"] = round(line["value"] / cpu["cpu_baseline_native"]["value"], 1)

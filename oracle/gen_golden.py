@@ -51,6 +51,8 @@ SCENARIOS = {
     "clutter_only": dict(seed=111, N=400, K=0, F=5, over={}),
     "fb0": dict(seed=112, N=128, K=2, F=16, over={"FB_FRAMES_BATCH": 0}),
     "empty_frames": dict(seed=113, N=96, K=1, F=16, over={}, zero_frames=(3, 9)),
+    "kf_est": dict(seed=114, N=128, K=2, F=20, over={"KF_ENABLE_EST": True}, presence="flicker"),
+    "max_size": dict(seed=115, N=640, K=0, F=4, over={}),
 }
 
 

@@ -64,6 +64,8 @@ def overrides_to_cfg_kwargs(over):
             kw["dim_x"] = 6 if v == "CONST_VEL_MODEL" else 9
         elif k == "FB_FRAMES_BATCH":
             kw["fb_frames_batch"] = int(v)
+        elif k == "KF_ENABLE_EST":
+            kw["kf_enable_est"] = int(bool(v))
         else:
             raise KeyError(k)
     return kw

@@ -148,3 +148,57 @@ def test_dbscan_golden():
             assert np.array_equal(labels[i, :sz], want), f"n={sz} min_samples={ms}"
             assert ncl[i] == want.max() + 1
     sb.close()
+
+
+def test_full_size_config_against_oracle():
+    """BASELINE.json configs[2] shape (512 pts, TR_MAX_TRACKS 8, mixed target counts) on 384 scenes:
+    final track state after 10 frames bit-equal to the oracle for EVERY scene, plus the
+    size-independent invariants (labels in range, association indices valid, ring lengths)."""
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    import bench
+    S, N, T, F = 384, 512, 8, 10
+    pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=1)
+    sb = _mk(S, N, tr_max_tracks=T)
+    ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
+    co.batch_run_f32(ob, pts, cnt, dts, 0)
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        ntr_before = sb.num_tracks()
+        for s in range(0, S, 37):
+            a = assoc[s, : cnt[f, s]]
+            assert a.min() >= -1
+            if dbn[s] >= 0:
+                lab = labels[s, : dbn[s]]
+                assert lab.min() >= -1 and (lab.max() < 0 or set(range(lab.max() + 1)) <= set(lab.tolist()))
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=int(ntr.max()))
+    ln, rn = sb.batch_ring()
+    for s in range(S):
+        want = ob.scenes[s].tracks()
+        assert ntr[s] == len(want), s
+        assert_tracks_match(trk[s, : ntr[s]], want, ctx=f"scene {s}", exact=True)
+        assert np.array_equal(rn[s, : ln[s]], ob.scenes[s].batch_ring())
+    sb.close()
+
+
+def test_error_paths_are_loud():
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.synth import make_batch
+    # capacity: a track list that cannot hold the clusters of frame 0
+    sb = SceneBatch(_lib.default_config(track_cap=1), 1, 256)
+    p, c, d = make_batch([3], 1, 256, 3)
+    with pytest.raises(_lib.MmwError) as ei:
+        sb.step_host(p[0].astype(np.float64), c[0], d[0])
+    assert ei.value.code == _lib.E_CAPACITY
+    sb.close()
+    # misaligned device pointer
+    sb = SceneBatch(_lib.default_config(), 1, 64)
+    buf = sb.alloc(64 * 64 + 64)
+    nb = sb.alloc(4).upload(np.array([8], np.int32))
+    db = sb.alloc(8).upload(np.array([0.1]))
+    with pytest.raises(_lib.MmwError) as ei:
+        sb.step_dev(buf.ptr + 8, nb.ptr, db.ptr)
+    assert ei.value.code == _lib.E_ARG
+    sb.close()
