@@ -30,8 +30,8 @@ namespace mmw {
 #define STAMP(k)
 #endif
 
-constexpr int kGateStride = 44;   // per track: Ci[36] | logdet | hx[6] | pad
-constexpr int kWaveScratch = 360; // per wave: P[81] A[81] K[54] C1[54] SI[36] Rc[36] x[9] y[6] (+pad)
+constexpr int kGateStride = 72;   // per track: gating Ci[36] | logdet | hx[6]; update SI[36] | Rc[36]
+constexpr int kWaveScratch = 288; // per wave: P[81] A[81] K[54] C1[54] x[9] y[6] (+pad)
 constexpr int kPwStackDepth = 4;  // numpy pairwise-sum recursion depth for n <= 2048
 
 struct TrackLds {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
 #endif
     double *gate = L.work;
     double *W = L.work + kGateChunk * kGateStride + wave * kWaveScratch;
-    double *Pw = W, *Aw = W + 81, *Kw = W + 162, *C1w = W + 216, *SIw = W + 270, *Rcw = W + 306, *xw = W + 342, *yw = W + 351;
+    double *Pw = W, *Aw = W + 81, *Kw = W + 162, *C1w = W + 216, *xw = W + 270, *yw = W + 279;
 
     // ---- this thread's points (rows tid, tid+256, ...): columns 0..5 straight into registers with
     //      16-byte loads; issued first so HBM latency hides under the track prediction below.
@@ -266,23 +266,32 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                 if (lane < dx) { rec->x[lane] = xn; xw[lane] = xn; }
             }
             wave_sync();
-            // C_g = P[:6,:6] + diag((spread/2)^2) + group_disp_est ; inverse and log|det| (Tracking.py:551-560)
-            {
-                double a = 1.0;
-                if (lane < 36) {
-                    const int r = lane / 6, c = lane % 6;
-                    double rm = 0.0;
-                    if (r == c) { const double hh = rec->spread[r] / 2; rm = hh * hh; }
-                    a = (Pw[r * 9 + c] + rm) + rec->gd[lane];
-                }
-                double inv, det;
-                if (!lu6_inverse_wave(a, lane, inv, det)) err |= ERR_SINGULAR;
-                double *G = gate + jl * kGateStride;
-                if (lane < 36) G[lane] = inv;
-                if (lane == 0) G[36] = dlog(fabs(det));
-                if (lane < 6) G[37 + lane] = xw[lane];
+        }
+        __syncthreads();
+        // ---- gate matrices of the whole chunk in ONE pass: eight 6x6 systems per wave (lane group g,
+        //      lane-in-group r = row r of track 8*wave+g).  C_g = P[:6,:6] + diag((spread/2)^2) +
+        //      group_disp_est; inverse and log|det| (Tracking.py:551-560) ----
+        if (wave * 8 < tc) {
+            const int g = lane >> 3, r = lane & 7, jl = wave * 8 + g;
+            const bool valid = jl < tc && r < 6;
+            double a[6], inv[6], det;
+#pragma unroll
+            for (int c = 0; c < 6; c++) a[c] = (r == c) ? 1.0 : 0.0;  // idle lanes/groups: identity
+            const TrackRec *rec = trk + L.slot[c0 + (jl < tc ? jl : 0)];
+            if (valid) {
+                const double hh = rec->spread[r] / 2;
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[c] = (rec->P[r * 9 + c] + ((r == c) ? hh * hh : 0.0)) + rec->gd[r * 6 + c];
             }
-            wave_sync();
+            const bool ok = lu6_inverse_rows(a, lane, inv, det);
+            if (valid) {
+                if (!ok) err |= ERR_SINGULAR;
+                double *G = gate + jl * kGateStride;
+#pragma unroll
+                for (int c = 0; c < 6; c++) G[r * 6 + c] = inv[c];
+                if (r == 0) G[36] = dlog(fabs(det));
+                G[37 + r] = rec->x[r];
+            }
         }
         __syncthreads();
         STAMP(1);  // predict + gate matrices
@@ -511,29 +520,45 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
 
     // ---- _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy update;
     //      one wave per track, wave-local ordering only ----
-    for (int j = wave; j < T; j += kWaves) {
-        TrackRec *rec = trk + L.slot[j];
+    for (int c0 = 0; c0 < T; c0 += kGateChunk) {
+      const int tc = min(kGateChunk, T - c0);
+      // innovation covariances of the whole chunk in one pass (eight 6x6 systems per wave):
+      // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
+      if (wave * 8 < tc) {
+          const int g = lane >> 3, r = lane & 7, jl = wave * 8 + g;
+          const bool valid = jl < tc && r < 6;
+          double a[6], inv[6], det;
+#pragma unroll
+          for (int c = 0; c < 6; c++) a[c] = (r == c) ? 1.0 : 0.0;
+          const TrackRec *rec = trk + L.slot[c0 + (jl < tc ? jl : 0)];
+          double *G = gate + (jl < tc ? jl : 0) * kGateStride;
+          if (valid) {
+              const double N = (double)rec->point_num;
+              const double den = (rec->n_est - 1) * N;
+              if (den == 0.0) err |= ERR_DIVZERO;
+              const double coef = (rec->n_est - N) / den;
+              const double hh = rec->spread[r] / 2;
+#pragma unroll
+              for (int c = 0; c < 6; c++) {
+                  const double rc = ((r == c) ? hh * hh : 0.0) / N + coef * rec->gd[r * 6 + c];
+                  G[36 + r * 6 + c] = rc;
+                  a[c] = rec->P[r * 9 + c] + rc;  // S = H P H^T + R
+              }
+          }
+          const bool ok = lu6_inverse_rows(a, lane, inv, det);
+          if (valid) {
+              if (!ok) err |= ERR_SINGULAR;
+#pragma unroll
+              for (int c = 0; c < 6; c++) G[r * 6 + c] = inv[c];
+          }
+      }
+      __syncthreads();
+      for (int jl = wave; jl < tc; jl += kWaves) {
+        TrackRec *rec = trk + L.slot[c0 + jl];
+        const double *SIw = gate + jl * kGateStride, *Rcw = SIw + 36;
         for (int e = lane; e < 81; e += 64) Pw[e] = rec->P[e];
         if (lane < 9) xw[lane] = rec->x[lane];
         if (lane < 6) yw[lane] = rec->centroid[lane] - rec->x[lane];
-        {
-            const double N = (double)rec->point_num;
-            const double den = (rec->n_est - 1) * N;
-            if (den == 0.0) err |= ERR_DIVZERO;
-            const double coef = (rec->n_est - N) / den;
-            double a = 1.0;
-            if (lane < 36) {
-                const int r = lane / 6, c = lane % 6;
-                double rm = 0.0;
-                if (r == c) { const double hh = rec->spread[r] / 2; rm = hh * hh; }
-                const double rc = rm / N + coef * rec->gd[lane];
-                Rcw[lane] = rc;
-                a = rec->P[r * 9 + c] + rc;  // S = H P H^T + R
-            }
-            double inv, det;
-            if (!lu6_inverse_wave(a, lane, inv, det)) err |= ERR_SINGULAR;
-            if (lane < 36) SIw[lane] = inv;
-        }
         wave_sync();
         if (lane < 54) {  // K = P H^T S^-1
             const int i = lane / 6, c = lane % 6;
@@ -593,6 +618,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             rec->x[lane] = xnew;
         }
         wave_sync();
+      }
+      __syncthreads();
     }
 
     STAMP(8);  // update (wave 0's tracks)

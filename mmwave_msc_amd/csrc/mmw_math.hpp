@@ -203,4 +203,80 @@ __device__ __forceinline__ bool lu6_inverse_wave(double a, int lane, double &inv
     return ok;
 }
 
+// Up to EIGHT 6x6 matrices per wave: lanes 8g..8g+5 hold rows 0..5 of matrix g (lanes 8g+6, 8g+7
+// idle).  First-max partial pivoting, L stored in place, det = signed product of pivots; the
+// inverse is solved for all six right-hand sides at once in axpy form: forward substitution
+// subtracts L[r][k]*Y[k] for k ascending, back substitution subtracts U[r][k]*X[k] for k
+// DESCENDING and divides by U[r][r] last (the order the CPU oracle restates).  One call costs
+// about what the one-matrix-per-wave version costs, so a scene's tracks share it.
+// All 64 lanes must call; `ok` is per group.
+__device__ __forceinline__ bool lu6_inverse_rows(double (&a)[6], int lane, double (&inv)[6], double &det)
+{
+    const int r = lane & 7, gb = lane & ~7;
+    int prow = r;
+    bool neg = false, ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        double best = fabs(__shfl(a[k], gb + k));
+#pragma unroll
+        for (int r2 = k + 1; r2 < 6; r2++) {
+            const double v = fabs(__shfl(a[k], gb + r2));
+            if (v > best) { best = v; p = r2; }
+        }
+        if (!(best > 0.0)) ok = false;
+        const int src = gb + ((r == k) ? p : ((r == p) ? k : r));
+#pragma unroll
+        for (int c = 0; c < 6; c++) a[c] = __shfl(a[c], src);
+        prow = __shfl(prow, src);
+        if (p != k) neg = !neg;
+        double piv[6];
+#pragma unroll
+        for (int c = k; c < 6; c++) piv[c] = __shfl(a[c], gb + k);
+        if (r > k && r < 6) {
+            const double l = a[k] / piv[k];
+            a[k] = l;
+#pragma unroll
+            for (int c = k + 1; c < 6; c++) a[c] = a[c] - l * piv[c];
+        }
+    }
+    double d = __shfl(a[0], gb);
+#pragma unroll
+    for (int k = 1; k < 6; k++) d = d * __shfl(a[k], gb + k);
+    det = neg ? -d : d;
+    double y[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) y[c] = (prow == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        double yk[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) yk[c] = __shfl(y[c], gb + k);
+        if (r > k && r < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) y[c] = y[c] - a[k] * yk[c];
+        }
+    }
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+        const double ukk = __shfl(a[k], gb + k);
+        if (r == k) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) y[c] = y[c] / ukk;
+        }
+        if (k > 0) {
+            double xk[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) xk[c] = __shfl(y[c], gb + k);
+            if (r < k) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) y[c] = y[c] - a[k] * xk[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) inv[c] = y[c];
+    return ok;
+}
+
 }  // namespace mmw

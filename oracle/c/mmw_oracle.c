@@ -310,9 +310,11 @@ static int lu6(const double *M, double *inv, double *det)
             for (int k = 0; k < r; k++) s = s - A[r * 6 + k] * y[k];
             y[r] = s;
         }
+        /* back substitution in axpy (column-sweep) order: x_r subtracts U[r][k]*x_k for k = 5 down
+         * to r+1, then divides -- the order a lane-parallel solver produces naturally */
         for (int r = 5; r >= 0; r--) {
             double s = y[r];
-            for (int k = r + 1; k < 6; k++) s = s - A[r * 6 + k] * inv[k * 6 + col];
+            for (int k = 5; k > r; k--) s = s - A[r * 6 + k] * inv[k * 6 + col];
             inv[r * 6 + col] = s / A[r * 6 + r];
         }
     }
