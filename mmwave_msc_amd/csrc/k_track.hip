@@ -42,6 +42,8 @@ struct TrackLds {
     int *cnt;        // [NB][CLS]
     int *cls_n;      // [CLS]
     int *cls_off;    // [CLS+1]
+    int *seg_off;    // [CLS+1] row-copy segments (16-byte units)
+    long long *seg_dst; // [CLS] destination offsets (doubles) of the segments
     int *slot;       // [t_cap]
     int *slot2;      // [t_cap]
     int *misc;       // [16]
@@ -72,6 +74,8 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     CARVE(cnt, int, NB *CLS)
     CARVE(cls_n, int, CLS)
     CARVE(cls_off, int, CLS + 1)
+    CARVE(seg_off, int, CLS + 2)
+    CARVE(seg_dst, long long, CLS + 1)
     CARVE(slot, int, c.t_cap)
     CARVE(slot2, int, c.t_cap)
     CARVE(misc, int, 16)
@@ -370,6 +374,26 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             int run = 0;
             for (int c = 0; c <= T; c++) { L.cls_off[c] = run; run += L.cls_n[c]; }
             L.cls_off[T + 1] = run;
+            // row-copy segments in 16-byte units: segment j < T = rows kept in track j's ring,
+            // segment T = unassigned rows appended to the global ring
+            int r2 = 0;
+            for (int j = 0; j < T; j++) { L.seg_off[j] = r2; r2 += min(L.cls_n[j + 1], cfg.ring_rows) * 4; }
+            L.seg_off[T] = r2;
+            L.seg_off[T + 1] = r2 + L.cls_n[0] * 4;
+        }
+        // where each segment goes, from the ring state BEFORE this frame's push (the bookkeeping itself
+        // happens after the copies): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
+        for (int j = tid; j <= T; j += kThreads) {
+            if (j < T) {
+                const TrackRec *rec = trk + L.slot[j];
+                const int len = rec->ring_len;
+                const int phys = len >= cfg.ring ? rec->ring_slot[0] : rec->ring_slot[len];
+                L.seg_dst[j] = (((long long)s * cfg.t_cap + L.slot[j]) * cfg.ring + phys) * (long long)cfg.ring_rows * 8;
+            } else {
+                const int len = hdr->g_len;
+                const int phys = len >= cfg.ring ? hdr->g_slot[0] : hdr->g_slot[len];
+                L.seg_dst[j] = ((long long)s * cfg.ring + phys) * (long long)NP * 8;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -386,7 +410,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
 
     // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, ring bookkeeping,
     //      N_est, spread_est; one lane per (track, dimension) ----
-    for (int task = tid; task < T * 6; task += kThreads) {
+    // When the statistics fit one wave (T <= 10) wave 0 walks the per-(track,column) chains while
+    // waves 1-3 move this frame's rows into the rings: two latency-bound jobs side by side.
+    const bool overlap = T * 6 <= 64;
+    for (int task = tid; task < T * 6 && (!overlap || wave == 0); task += kThreads) {
         const int j = task / 6, m = task % 6;
         TrackRec *rec = trk + L.slot[j];
         const int nj = L.cls_n[j + 1], off = L.cls_off[j + 1];
@@ -432,7 +459,48 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
             else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
             rec->n_est = ne;
-            // BatchedData.add_frame on the track ring (Tracking.py:43-51)
+        }
+    }
+    // row copies (all 8 columns, 16-byte pieces): eight loads in flight per thread, then eight stores
+    if (!overlap || wave > 0) {
+        const int ct = overlap ? tid - 64 : tid, nthr = overlap ? kThreads - 64 : kThreads;
+        const int total2 = L.seg_off[T + 1];
+        const double2 *src2 = reinterpret_cast<const double2 *>(pts);
+        for (int base = 0; base < total2; base += nthr * 8) {
+            double2 v[8];
+            long long dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int item = base + u * nthr + ct;
+                dst[u] = -1;
+                v[u] = double2{0.0, 0.0};
+                if (item < total2) {
+                    int seg = 0;
+                    while (item >= L.seg_off[seg + 1]) seg++;
+                    const int local = item - L.seg_off[seg];
+                    const int row = L.perm[(seg < T ? L.cls_off[seg + 1] : 0) + (local >> 2)];
+                    v[u] = src2[row * 4 + (local & 3)];
+                    dst[u] = L.seg_dst[seg] + (long long)local * 2;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (dst[u] >= 0) {
+                    double *base_ptr = (base + u * nthr + ct) >= L.seg_off[T] ? st.g_ring : st.trk_ring;
+                    *reinterpret_cast<double2 *>(base_ptr + dst[u]) = v[u];
+                }
+        }
+    }
+    __syncthreads();
+    STAMP(4);  // centroid/min/max/spread
+    // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
+    for (int j = tid; j < T; j += kThreads) {
+        const int nj = L.cls_n[j + 1];
+        if (nj > 0) {
+            TrackRec *rec = trk + L.slot[j];
+            const double v3 = L.cen[j * 6 + 3], v4 = L.cen[j * 6 + 4], v5 = L.cen[j * 6 + 5];
+            rec->is_static = sqrt((v3 * v3 + v4 * v4) + v5 * v5) < cfg.tr_vel_thres ? 1 : 0;
+            // BatchedData.add_frame on the track ring (Tracking.py:43-51); the rows were written above
             int len = rec->ring_len;
             while (len >= cfg.ring) {  // pop_frame: the freed physical slot becomes the first free entry
                 const int first = rec->ring_slot[0];
@@ -442,15 +510,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             }
             rec->ring_n[len] = nj;
             rec->ring_len = len + 1;
-        }
-    }
-    __syncthreads();
-    STAMP(4);  // centroid/min/max/spread
-    // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
-    for (int j = tid; j < T; j += kThreads) {
-        if (L.cls_n[j + 1] > 0) {
-            const double v3 = L.cen[j * 6 + 3], v4 = L.cen[j * 6 + 4], v5 = L.cen[j * 6 + 5];
-            trk[L.slot[j]].is_static = sqrt((v3 * v3 + v4 * v4) + v5 * v5) < cfg.tr_vel_thres ? 1 : 0;
         }
     }
     // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track
@@ -477,16 +536,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         }
     }
     STAMP(5);  // dispersion matrices (wave 0's share)
-    // track ring rows: first min(n_j, ring_rows) rows of the cloud, all 8 columns, from the input block
-    for (int j = 0; j < T; j++) {
-        const int nj = L.cls_n[j + 1];
-        if (nj == 0) continue;
-        const TrackRec *rec = trk + L.slot[j];
-        const int keep = min(nj, cfg.ring_rows), off = L.cls_off[j + 1];
-        const int phys = rec->ring_slot[rec->ring_len - 1];
-        double *dst = st.trk_ring + (((size_t)s * cfg.t_cap + L.slot[j]) * cfg.ring + phys) * (size_t)cfg.ring_rows * 8;
-        for (int e = tid; e < keep * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[off + (e >> 3)] * 8 + (e & 7)];
-    }
     __syncthreads();
     STAMP(6);  // track ring rows + barrier (includes waiting for the other waves' dispersion work)
 
@@ -651,11 +700,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
             st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
         }
-    }
-    __syncthreads();
-    {
-        double *dst = st.g_ring + ((size_t)s * cfg.ring + L.misc[1]) * (size_t)NP * 8;
-        for (int e = tid; e < nun * 8; e += kThreads) dst[e] = pts[(size_t)L.perm[e >> 3] * 8 + (e & 7)];
     }
     if (err) atomicOr(&hdr->err, err);
     STAMP(9);  // global ring append

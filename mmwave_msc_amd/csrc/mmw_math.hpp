@@ -46,74 +46,6 @@ __device__ inline double dlog(double x)
     return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
 }
 
-// 6x6 LU with partial pivoting (first max), determinant and inverse, entirely in
-// registers (all indices static after unrolling).  M is read with stride `ld`.
-// Returns false when a pivot is exactly zero (numpy: LinAlgError).
-__device__ inline bool lu6_inverse(const double *M, int ld, double *inv /*[36]*/, double &det)
-{
-    double A[36];
-    int perm[6];
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-        perm[r] = r;
-#pragma unroll
-        for (int c = 0; c < 6; c++) A[r * 6 + c] = M[r * ld + c];
-    }
-    bool neg = false, ok = true;
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        int p = k;
-        double best = fabs(A[k * 6 + k]);
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            double v = fabs(A[r * 6 + k]);
-            if (v > best) { best = v; p = r; }
-        }
-        if (!(best > 0.0)) ok = false;
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            if (p == r) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) { double t = A[k * 6 + c]; A[k * 6 + c] = A[r * 6 + c]; A[r * 6 + c] = t; }
-                int tp = perm[k]; perm[k] = perm[r]; perm[r] = tp;
-                neg = !neg;
-            }
-        }
-#pragma unroll
-        for (int r = k + 1; r < 6; r++) {
-            double l = A[r * 6 + k] / A[k * 6 + k];
-            A[r * 6 + k] = l;
-#pragma unroll
-            for (int c = k + 1; c < 6; c++) A[r * 6 + c] = A[r * 6 + c] - l * A[k * 6 + c];
-        }
-    }
-    double d = A[0];
-#pragma unroll
-    for (int k = 1; k < 6; k++) d = d * A[k * 6 + k];
-    det = neg ? -d : d;
-#pragma unroll
-    for (int col = 0; col < 6; col++) {
-        double y[6], xs[6];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            double s = (perm[r] == col) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < r; k++) s = s - A[r * 6 + k] * y[k];
-            y[r] = s;
-        }
-#pragma unroll
-        for (int r = 5; r >= 0; r--) {
-            double s = y[r];
-#pragma unroll
-            for (int k = r + 1; k < 6; k++) s = s - A[r * 6 + k] * xs[k];
-            xs[r] = s / A[r * 6 + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; r++) inv[r * 6 + col] = xs[r];
-    }
-    return ok;
-}
-
 // altered_EuclideanDist (Utils.py:242-247), operation order kept.
 __device__ inline double alt_dist(double ax, double ay, double az, double bx, double by, double bz,
                                   double range_w, double z_w)
@@ -138,73 +70,9 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The same 6x6 LU / determinant / inverse as lu6_inverse(), one matrix per wave: lane r*6+c
-// (< 36) owns element [r][c]; rows/columns travel by cross-lane reads.  Every element sees
-// exactly the operations of the serial version in the same order, so results are bit-equal;
-// the wave needs ~10 VGPRs instead of two 36-element register arrays.  All 64 lanes must call.
-__device__ __forceinline__ bool lu6_inverse_wave(double a, int lane, double &inv_elem, double &det)
-{
-    const int r = lane < 36 ? lane / 6 : 0, c = lane < 36 ? lane % 6 : 0;
-    int prow = r;  // original index of the row now at position r
-    bool neg = false, ok = true;
-#pragma unroll 1  // rolled on purpose: unrolled, the 6 steps keep ~60 extra VGPRs live
-    for (int k = 0; k < 6; k++) {
-        int p = k;
-        double best = fabs(__shfl(a, k * 6 + k));
-#pragma unroll
-        for (int r2 = k + 1; r2 < 6; r2++) {
-            const double v = fabs(__shfl(a, r2 * 6 + k));
-            if (v > best) { best = v; p = r2; }
-        }
-        if (!(best > 0.0)) ok = false;
-        {   // swap rows k and p (no-op when p == k); p is wave-uniform
-            const int srow = (r == k) ? p : ((r == p) ? k : r);
-            a = __shfl(a, srow * 6 + c);
-            prow = __shfl(prow, srow * 6 + c);
-            if (p != k) neg = !neg;
-        }
-        const double akk = __shfl(a, k * 6 + k), ark = __shfl(a, r * 6 + k), akc = __shfl(a, k * 6 + c);
-        if (r > k) {
-            const double l = ark / akk;
-            if (c == k) a = l;
-            else if (c > k) a = a - l * akc;
-        }
-    }
-    double d = __shfl(a, 0);
-#pragma unroll
-    for (int k = 1; k < 6; k++) d = d * __shfl(a, k * 7);
-    det = neg ? -d : d;
-    // forward substitution, column c of the identity (permuted): y_r = b_r - sum_{k<r} L[r][k] y_k
-    double y = 0.0;
-#pragma unroll 1
-    for (int rr = 0; rr < 6; rr++) {
-        double s = (prow == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < rr; k++) {
-            const double lrk = __shfl(a, r * 6 + k), yk = __shfl(y, k * 6 + c);
-            s = s - lrk * yk;
-        }
-        if (r == rr) y = s;
-    }
-    // back substitution: x_r = (y_r - sum_{k>r} U[r][k] x_k) / U[r][r]
-    double x = 0.0;
-#pragma unroll 1
-    for (int rr = 5; rr >= 0; rr--) {
-        double s = y;
-#pragma unroll
-        for (int k = rr + 1; k < 6; k++) {
-            const double urk = __shfl(a, r * 6 + k), xk = __shfl(x, k * 6 + c);
-            s = s - urk * xk;
-        }
-        const double urr = __shfl(a, r * 7);
-        if (r == rr) x = s / urr;
-    }
-    inv_elem = x;
-    return ok;
-}
-
-// Up to EIGHT 6x6 matrices per wave: lanes 8g..8g+5 hold rows 0..5 of matrix g (lanes 8g+6, 8g+7
-// idle).  First-max partial pivoting, L stored in place, det = signed product of pivots; the
+// 6x6 partial-pivot LU, determinant and inverse (stands for np.linalg.det / np.linalg.inv at
+// Tracking.py:558-560 and filterpy's inv(S)), up to EIGHT matrices per wave: lanes 8g..8g+5 hold
+// rows 0..5 of matrix g (lanes 8g+6, 8g+7 idle).  First-max partial pivoting, L stored in place, det = signed product of pivots; the
 // inverse is solved for all six right-hand sides at once in axpy form: forward substitution
 // subtracts L[r][k]*Y[k] for k ascending, back substitution subtracts U[r][k]*X[k] for k
 // DESCENDING and divides by U[r][r] last (the order the CPU oracle restates).  One call costs
