@@ -225,6 +225,13 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         // Thread-per-point build: min/max by fire-and-forget LDS atomics, rank by a scan of the
         // node's keys, stable partition by ballots in lane (= point index) order.
         const int wave = tid >> 6;
+        // spare threads help: thread t works for point (t mod U) on slice (t / U) of `parts` slices
+        const int parts = NT / U > 0 ? NT / U : 1;
+        const int hpart = tid / U, hi = tid - hpart * U;
+        const bool helper = hpart < parts;
+        int *rankc = L.front;   // per-position rank counters (free until labelling)
+        int *posarr = L.next;   // point index -> tree position
+        if (tid < U) posarr[tid] = tid;
         for (int level = 0; level + 1 < n_levels; level++) {
             const int first = (1 << level) - 1, nn = 1 << level;
             for (int e = tid; e < nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;
@@ -260,6 +267,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 const int sd = L.sdim[node - first];
                 kp = sd == 0 ? f0 : sd == 1 ? f1 : sd == 2 ? f2 : sd == 3 ? f3 : sd == 4 ? f4 : sd == 5 ? f5 : sd == 6 ? f6 : f7;
                 L.key[mypos] = kp;
+                rankc[mypos] = 0;
                 s = L.nstart[node];
                 e = L.nend[node];
             }
@@ -268,16 +276,23 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             // partition_node_indices: the n_mid smallest under (value, index) go left
             // (_partition_nodes.pyx:35-39); both halves keep ascending point-index order.
             bool left = false;
-            if (act) {
+            if (helper) {  // slice `hpart` of the node of point `hi`
+                const int hp = posarr[hi];
+                const int hnode = node_of(L, hp, level);
+                const int hs = L.nstart[hnode], he = L.nend[hnode], len = he - hs;
+                const int q0 = hs + (int)(((long long)len * hpart) / parts), q1 = hs + (int)(((long long)len * (hpart + 1)) / parts);
+                const double hk = L.key[hp];
                 int c = 0;
 #pragma unroll 4
-                for (int q = s; q < e; q++) {
+                for (int q = q0; q < q1; q++) {
                     const double kq = L.key[q];
                     const int iq = idx[q];
-                    c += (kq < kp || (kq == kp && iq < tid)) ? 1 : 0;
+                    c += (kq < hk || (kq == hk && iq < hi)) ? 1 : 0;
                 }
-                left = c < (e - s) / 2;
+                if (parts == 1) rankc[hp] = c; else atomicAdd(&rankc[hp], c);
             }
+            __syncthreads();
+            if (act) left = rankc[mypos] < (e - s) / 2;
             DSTAMP(8);  // (diagnostic) rank scan
             unsigned long long mine = 0;
             for (int nd = 0; nd < nn; nd++) {
@@ -293,6 +308,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 const int nmid = (e - s) / 2;
                 np = left ? s + lc : s + nmid + ((mypos - s) - lc);
                 idx2[np] = tid;
+                posarr[tid] = np;
             }
             if (tid < nn) {
                 const int nd = first + tid, ss = L.nstart[nd], ee = L.nend[nd], nmid = (ee - ss) / 2;
@@ -474,7 +490,17 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     DSTAMP(2);
     // ---- BallTree.query_radius(X, eps) for every point (_binary_tree.pxi.tp:1903-1980) ----
     const int lbits = n_levels - 1;
-    for (int p = tid; p < U; p += NT) {
+    // ALL8: spare threads share a query -- slice `qpart` of `qparts` takes every qparts-th candidate of a
+    // TEST leaf; counts meet in an LDS counter.  Otherwise one thread per query.
+    const int qparts = ALL8 ? (NT / U > 0 ? NT / U : 1) : 1;
+    int *qcount = L.front;
+    if (ALL8 && qparts > 1) {
+        for (int p = tid; p < U; p += NT) qcount[p] = 0;
+        __syncthreads();
+    }
+    for (int t = tid; t < (ALL8 ? U * qparts : U); t += NT) {
+        const int qpart = ALL8 ? t / U : 0;
+        const int p = ALL8 ? t - qpart * U : t;
         const double px = L.X[p], py = L.Y[p], pz = L.Z[p];
         unsigned long long m = 0;
         int count = 0, node = 0, level = 0;
@@ -496,11 +522,11 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 const unsigned long long sel = span == 32 ? ~0ULL : ((1ULL << (2 * span)) - 1ULL);
                 m |= (pat & sel) << (2 * fl);
                 const int s = L.nstart[node], e = L.nend[node];
-                if (state == 1) count += e - s;
+                if (state == 1) count += (qpart == 0) ? e - s : 0;
                 else
                 {
 #pragma unroll 4
-                    for (int q = s; q < e; q++)
+                    for (int q = s + qpart; q < e; q += qparts)
                         count += alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1 : 0;
                 }
             }
@@ -509,10 +535,15 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             node++;  // left child -> its sibling
         }
         // the key[] buffer is dead after the build: it now holds the masks
-        L.mask[p] = m;
-        L.core[p] = count >= min_samples ? 1 : 0;
+        if (qpart == 0) L.mask[p] = m;
+        if (qparts > 1) atomicAdd(&qcount[p], count);
+        else L.core[p] = count >= min_samples ? 1 : 0;
     }
     __syncthreads();
+    if (qparts > 1) {
+        for (int p = tid; p < U; p += NT) L.core[p] = qcount[p] >= min_samples ? 1 : 0;
+        __syncthreads();
+    }
 
     DSTAMP(3);
     // ---- dbscan_inner (sklearn/cluster/_dbscan_inner.pyx): clusters seeded in ascending
@@ -743,7 +774,7 @@ __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const d
 
 // ---- host side ---------------------------------------------------------------------------
 static const int kClassUM[3] = {256, 768, 1920};
-constexpr int kClass0Threads = 256;
+constexpr int kClass0Threads = 512;
 
 int dbscan_class_um(int cls, int UM) { return kClassUM[cls] < UM ? kClassUM[cls] : UM; }
 int dbscan_class_cl(int cls, int UM, int t_cap, int min_samples)
