@@ -28,6 +28,14 @@ for st in $STAGES; do
       (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --steps 10 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log 2>&1)
       python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write | tee gpurun_out/pmc_summary.json
       find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete ;;
+    posture)
+      rm -rf gpurun_out/prof_posture gpurun_out/pmc_posture
+      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_posture -- python3 $GRAFT_REPO_ROOT/scripts/bench_posture.py > $GRAFT_REPO_ROOT/gpurun_out/prof_posture.log 2>&1)
+      tail -1 gpurun_out/prof_posture.log
+      for f in $(find gpurun_out/prof_posture -name "*kernel_stats.csv"); do head -9 $f | cut -c1-180; done
+      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_posture -- python3 $GRAFT_REPO_ROOT/scripts/bench_posture.py > $GRAFT_REPO_ROOT/gpurun_out/pmc_posture.log 2>&1)
+      python scripts/mfma_summary.py gpurun_out/pmc_posture | tee gpurun_out/mfma_summary.json
+      find gpurun_out/prof_posture gpurun_out/pmc_posture -name "*.csv" -size +20M -delete ;;
     *) echo "unknown stage $st" ;;
   esac
 done
