@@ -198,6 +198,14 @@ int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32
 #define MMW_K_NORMALIZE 3
 #define MMW_K_TABLE 4
 #define MMW_K_COUNT 5
+/* The two Conv3D(3x3x3, same, relu) layers of define_CNN_3D (train.py:73-82) fused on the fp32 matrix
+ * cores, on the current device and the given hipStream_t (NULL = default stream).  All dev pointers:
+ *   feat[n][3][8][8][5]   channels-last input (what mmw_features writes)
+ *   w1[3][3][3][5][16], b1[16], w2[3][3][3][16][32], b2[32]   Keras kernel layout (kd,kh,kw,in,out)
+ *   out[n][3][8][8][32]   = Keras Flatten order (d,h,w,c): feed Dense-1 with Keras' weight rows. */
+int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2,
+                    float *out, int32_t n);
+
 /* Work counters accumulated by the kernels since the last reset (sync):
  * [0] k_track algorithmic bytes  [1] k_dbscan algorithmic bytes  [2] scene-frames stepped
  * [3] apply_DBscan calls  [4] sum of U over those calls  [5] sum of tracks entering track()

@@ -28,7 +28,7 @@ EXPORTS = [
     "mmw_normalize", "mmw_step", "mmw_step_host", "mmw_dbscan", "mmw_features", "mmw_set_keypoints", "mmw_check",
     "mmw_get_num_tracks", "mmw_get_tracks", "mmw_get_batch_ring", "mmw_get_track_ring_frame",
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
-    "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext",
+    "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
 ]
 
 
@@ -153,6 +153,7 @@ def load():
         "mmw_stats_get": (C.c_int, [vp, vp]),
         "mmw_stats_reset": (C.c_int, [vp]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
+        "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),
         "mmw_format_frames": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)

@@ -30,6 +30,8 @@ void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const 
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
 void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st);
+void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
+                      hipStream_t stream);
 }  // namespace mmw
 
 using namespace mmw;
@@ -522,6 +524,16 @@ int mmw_track_table(mmw_ctx *c, mmw_track_summary *table, int32_t slots, int32_t
     launch_table(c->dc, c->st, table, slots, scene_base, c->stream);
     prof_end(c, ep);
     HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2,
+                    float *out, int32_t n)
+{
+    if (n < 0 || (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out))) return fail(nullptr, MMW_E_ARG, "mmw_mars_conv3d: bad argument");
+    launch_mars_conv(feat, w1, b1, w2, b2, out, n, (hipStream_t)hip_stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv3d launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 

@@ -64,8 +64,17 @@ class MarsCNN(nn.Module):
         self.conv2 = conv(16, 32, 3, padding=1)
         flat = (self.frames if self.three_d else 1) * 64 * 32
         hidden = 512 * (3 if self.three_d else 1)
-        self.dense1 = nn.Linear(flat, hidden)   # BN1 folded in
+        self.dense1 = nn.Linear(flat, hidden)   # BN1 folded in, rows in channels-first flatten order
         self.dense2 = nn.Linear(hidden, N_KEYPOINTS)  # BN2 folded in
+        # hand-written fused Conv3D x2 on the fp32 matrix cores (csrc/k_mars.hip): Keras-layout kernels
+        # and a Dense-1 whose rows follow Keras' own (d,h,w,c) flatten order
+        self.use_hip_conv = self.three_d and self.frames == 3
+        if self.use_hip_conv:
+            self.register_buffer("k_w1", torch.zeros(27 * 5 * 16))
+            self.register_buffer("k_b1", torch.zeros(16))
+            self.register_buffer("k_w2", torch.zeros(27 * 16 * 32))
+            self.register_buffer("k_b2", torch.zeros(32))
+            self.dense1_dhwc = nn.Linear(flat, hidden)
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -88,6 +97,14 @@ class MarsCNN(nn.Module):
         w1 = f64["dense1_w"].reshape(spatial, 32, -1)            # [s, c, out]
         b1 = f64["dense1_b"] + np.einsum("c,sco->o", c1, w1)
         w1 = (w1 * a1[None, :, None]).transpose(1, 0, 2).reshape(flat, -1)  # [(c,s), out]
+        if m.use_hip_conv:
+            m.k_w1.copy_(torch.from_numpy(f64["conv1_w"].reshape(-1)).float())
+            m.k_b1.copy_(torch.from_numpy(f64["conv1_b"]).float())
+            m.k_w2.copy_(torch.from_numpy(f64["conv2_w"].reshape(-1)).float())
+            m.k_b2.copy_(torch.from_numpy(f64["conv2_b"]).float())
+            wk = (f64["dense1_w"].reshape(spatial, 32, -1) * a1[None, :, None]).reshape(flat, -1)  # Keras row order kept
+            m.dense1_dhwc.weight.copy_(torch.from_numpy(wk.T.copy()).float())
+            m.dense1_dhwc.bias.copy_(torch.from_numpy(b1).float())
         m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
         m.dense1.bias.copy_(torch.from_numpy(b1).float())
         a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
@@ -102,8 +119,24 @@ class MarsCNN(nn.Module):
         z = np.load(path)
         return cls.from_keras_weights({k: z[k] for k in z.files})
 
+    def _hip_convs(self, x: torch.Tensor) -> torch.Tensor:
+        """Conv3D+ReLU twice in one HIP kernel (mmw_mars_conv3d) -> (B, 6144) in (d,h,w,c) order."""
+        from . import _lib
+        L = _lib.load()
+        x = x.contiguous()
+        out = torch.empty((x.shape[0], 6144), dtype=torch.float32, device=x.device)
+        rc = L.mmw_mars_conv3d(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), self.k_w1.data_ptr(),
+                               self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), x.shape[0])
+        if rc != 0:
+            raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""
+        if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32:
+            with torch.cuda.device(x.device):
+                h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
+            return self.dense2(h)
         if self.three_d:
             h = x.permute(0, 4, 1, 2, 3)
         else:

@@ -1,0 +1,30 @@
+"""The hand-written fused Conv3D x2 (csrc/k_mars.hip, fp32 MFMA) against torch's convolutions and the
+fp64 numpy oracle: activations within 1e-4, keypoints within the 1e-4 m tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("batch", [1, 7, 600])
+def test_hip_convs_match_torch_and_oracle(batch):
+    import torch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from oracle.mars_np import _conv_same, mars_forward_np
+    w = random_keras_weights(seed=11, frames=3)
+    model = MarsCNN.from_keras_weights(w).to("cuda:0")
+    assert model.use_hip_conv
+    rng = np.random.default_rng(batch)
+    x = rng.normal(0, 0.5, size=(batch, 3, 8, 8, 5)).astype(np.float32)
+    x[:, :, 6:, :, :] = 0.0  # zero-padded rows as real feature maps have
+    xt = torch.from_numpy(x).to("cuda:0")
+    with torch.no_grad():
+        got = model._hip_convs(xt).float().cpu().numpy().reshape(batch, 3, 8, 8, 32)
+        ref_t = torch.relu(model.conv2(torch.relu(model.conv1(xt.permute(0, 4, 1, 2, 3))))).permute(0, 2, 3, 4, 1).cpu().numpy()
+        kp = model(xt).float().cpu().numpy()
+    f64 = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
+    h = np.maximum(_conv_same(x.astype(np.float64), f64["conv1_w"], f64["conv1_b"]), 0)
+    ref = np.maximum(_conv_same(h, f64["conv2_w"], f64["conv2_b"]), 0)
+    assert np.abs(got - ref).max() <= 1e-4, np.abs(got - ref).max()
+    assert np.abs(got - ref_t).max() <= 1e-4
+    assert np.abs(kp - mars_forward_np(w, x)).max() <= 1e-4
