@@ -179,7 +179,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (n <= 0 || n > NP) {  // offline_main.py:56: empty frames never reach track()
-        if (tid == 0) hdr->need_db = 0;
+        if (tid == 0) {
+            hdr->need_db = 0;
+            if (n < 0 || n > NP) atomicOr(&hdr->err, ERR_BADCOUNT);  // a count the context was not sized for
+        }
         return;
     }
     const double dt = dt_all[s];

@@ -17,7 +17,7 @@ constexpr int kMaxLeaves = 32;      // n <= 1920 -> <= 63 nodes -> <= 32 leaves
 constexpr int kMaxNodes = 63;
 
 // per-scene error bits (sticky until mmw_reset)
-enum : int { ERR_SINGULAR = 1, ERR_DIVZERO = 2, ERR_CAPACITY = 4 };
+enum : int { ERR_SINGULAR = 1, ERR_DIVZERO = 2, ERR_CAPACITY = 4, ERR_BADCOUNT = 8 };
 
 struct DevCfg {
     int32_t ring;            // FB_FRAMES_BATCH + 1

@@ -193,6 +193,13 @@ def test_error_paths_are_loud():
         sb.step_host(p[0].astype(np.float64), c[0], d[0])
     assert ei.value.code == _lib.E_CAPACITY
     sb.close()
+    # a point count the context was not sized for is an error, not a silently skipped frame
+    sb = SceneBatch(_lib.default_config(), 2, 64)
+    pts = np.zeros((2, 64, 8)); pts[..., 1] = 1.0; pts[..., 2] = 1.0
+    with pytest.raises(_lib.MmwError) as ei:
+        sb.step_host(pts, np.array([10, 65], np.int32), np.array([0.1, 0.1]))
+    assert ei.value.code == _lib.E_ARG
+    sb.close()
     # misaligned device pointer
     sb = SceneBatch(_lib.default_config(), 1, 64)
     buf = sb.alloc(64 * 64 + 64)
