@@ -208,8 +208,58 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     }
     const int n_levels = db_levels(U);
     const int n_nodes = (1 << n_levels) - 1;
-    if (tid == 0) { L.nstart[0] = 0; L.nend[0] = U; }
+    if (tid == 0) { L.nstart[0] = 0; L.nend[0] = U; L.mm[0] = ~0ULL; L.mm[1] = 0ULL; L.misc[3] = 0; }
     __syncthreads();
+
+    // ---- exact early exit: can ANY point reach min_samples tree-neighbours? ----
+    // metric(a,b) = w_ab * E(a,b)^2 with E the weighted Euclidean norm sqrt(dx^2+dy^2+z_w*dz^2) (a true
+    // norm for z_w >= 0) and w_ab = 1 - range_w*(ay+by)/2 >= wmin > 0 over the data's y range (node
+    // centroids are means, so their y lies in that range too).  A BallTree neighbour q of p is either
+    // leaf-tested, metric(p,q) <= eps => E(p,q)^2 <= eps/wmin, or taken with a whole node of centroid
+    // c: metric(p,c) + radius <= eps with radius >= metric(c,q), so by the triangle inequality of E
+    // E(p,q)^2 <= (sqrt(m(p,c)/wmin) + sqrt(m(c,q)/wmin))^2 <= 2*(m(p,c)+radius)/wmin <= 2*eps/wmin.
+    // If no point has min_samples points (itself included) within E^2 <= 2*eps/wmin there is no core
+    // point and every label is -1 -- exactly what sklearn returns -- and the tree is never built.
+    // Steady-state rings of clutter end here.
+    if (min_samples > 1 && zw >= 0.0 && eps >= 0.0) {
+        double ylo = 1.7976931348623157e308, yhi = -1.7976931348623157e308;
+        for (int i = tid; i < U; i += NT) {
+            const double y = L.Y[i];
+            ylo = y < ylo ? y : ylo;
+            yhi = y > yhi ? y : yhi;
+        }
+        ylo = wave_min_d(ylo);
+        yhi = wave_max_d(yhi);
+        if (lane == 0 && ylo <= yhi) { atomicMin(&L.mm[0], sortable(ylo)); atomicMax(&L.mm[1], sortable(yhi)); }
+        __syncthreads();
+        const double ymin = unsortable(L.mm[0]), ymax = unsortable(L.mm[1]);
+        const double wa = 1 - ymax * rw, wb = 1 - ymin * rw;
+        const double wmin = wa < wb ? wa : wb;
+        if (wmin > 0.0) {  // wave-uniform (same LDS values for every thread)
+            const double R2 = 2.0 * (eps / wmin) * (1.0 + 1e-9);
+            const int bparts = ALL8 ? (NT / U > 0 ? NT / U : 1) : 1;
+            bool dense = false;
+            for (int t = tid; t < (ALL8 ? U * bparts : U); t += NT) {
+                const int part = ALL8 ? t / U : 0, p = ALL8 ? t - part * U : t;
+                const double px = L.X[p], py = L.Y[p], pz = L.Z[p];
+                int c = 0;
+#pragma unroll 4
+                for (int q = part; q < U; q += bparts) {
+                    const double dx = px - L.X[q], dy = py - L.Y[q], dz = pz - L.Z[q];
+                    c += ((dx * dx + dy * dy) + zw * (dz * dz) <= R2) ? 1 : 0;
+                }
+                // a slice that alone reaches min_samples/bparts (rounded up) may add up to a core point
+                if (c * bparts >= min_samples) dense = true;
+            }
+            if (dense) L.misc[3] = 1;
+            __syncthreads();
+            if (L.misc[3] == 0) {
+                for (int i = tid; i < U; i += NT) L.idx2[i] = -1;
+                __syncthreads();
+                return 0;
+            }
+        }
+    }
 
     auto feature = [&](int i, int f) -> double {
         if (f == 0) return L.X[i];
