@@ -177,7 +177,7 @@ __device__ __forceinline__ int node_of(const DbLds &L, int p, int level)
 // point i (-1 noise) and the number of clusters is returned (uniform).
 template <int NT, bool ALL8>
 __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc src, int U, int UMc, double eps, int min_samples,
-                                           unsigned long long *dbg)
+                                           unsigned long long *dbg, bool screened = false)
 {
     DSTAMP_INIT
     (void)dbg;
@@ -197,6 +197,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             L.X[tid] = f0; L.Y[tid] = f1; L.Z[tid] = f2;
             L.idx[tid] = tid;
             L.lab[tid] = -1;
+            L.front[tid] = 0;
         }
     } else {
         for (int i = tid; i < U; i += NT) {
@@ -221,7 +222,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     // If no point has min_samples points (itself included) within E^2 <= 2*eps/wmin there is no core
     // point and every label is -1 -- exactly what sklearn returns -- and the tree is never built.
     // Steady-state rings of clutter end here.
-    if (min_samples > 1 && zw >= 0.0 && eps >= 0.0) {
+    if (!screened && min_samples > 1 && zw >= 0.0 && eps >= 0.0) {
         double ylo = 1.7976931348623157e308, yhi = -1.7976931348623157e308;
         for (int i = tid; i < U; i += NT) {
             const double y = L.Y[i];
@@ -248,11 +249,18 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                     const double dx = px - L.X[q], dy = py - L.Y[q], dz = pz - L.Z[q];
                     c += ((dx * dx + dy * dy) + zw * (dz * dz) <= R2) ? 1 : 0;
                 }
-                // a slice that alone reaches min_samples/bparts (rounded up) may add up to a core point
-                if (c * bparts >= min_samples) dense = true;
+                if (ALL8 && bparts > 1) atomicAdd(&L.front[p], c);  // slices of one point add up in LDS
+                else if (c >= min_samples) dense = true;
+            }
+            if (ALL8 && bparts > 1) {
+                __syncthreads();
+                if (tid < U && L.front[tid] >= min_samples) dense = true;
             }
             if (dense) L.misc[3] = 1;
             __syncthreads();
+#ifdef MMW_STAMPS
+            if (tid == 0 && dbg && L.misc[3] == 0) atomicAdd(&dbg[31], 1ULL);
+#endif
             if (L.misc[3] == 0) {
                 for (int i = tid; i < U; i += NT) L.idx2[i] = -1;
                 __syncthreads();
@@ -658,44 +666,143 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
 
 // Tracking.py:697-703 for the scenes of one size class: apply_DBscan on the global ring,
 // batch.clear(), _add_tracks.
-template <int NT, bool ALL8>
-__global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int cls,
-                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+__device__ __forceinline__ RowSrc ring_rows_of(const DevCfg &cfg, const DevState &st, const SceneHdr *hdr, int s)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    DbLds L;
-    db_lds_layout<true>(UMc, CL, ALL8, lds_raw, &L);
-    const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.x >= st.db_count[parity * 4 + cls]) return;
-    const int s = st.db_list[(size_t)cls * cfg.n_scenes + blockIdx.x];
-    SceneHdr *hdr = st.hdr + s;
-    const int U = hdr->db_u, NP = cfg.max_pts;
     RowSrc src;
-    {
-        const int nfr = hdr->g_len;
-        const int big = 0x7fffffff;
-        src.gb = st.g_ring + (size_t)s * cfg.ring * (size_t)NP * 8;
-        src.stride = (size_t)NP * 8;
-        src.slots = (unsigned)hdr->g_slot[0] | ((unsigned)hdr->g_slot[1] << 8) | ((unsigned)hdr->g_slot[2] << 16) | ((unsigned)hdr->g_slot[3] << 24);
-        const int n0 = hdr->g_n[0], n1 = hdr->g_n[1], n2 = hdr->g_n[2];
-        src.c1 = nfr > 1 ? n0 : big;
-        src.c2 = nfr > 2 ? n0 + n1 : big;
-        src.c3 = nfr > 3 ? n0 + n1 + n2 : big;
+    const int nfr = hdr->g_len, NP = cfg.max_pts;
+    const int big = 0x7fffffff;
+    src.gb = st.g_ring + (size_t)s * cfg.ring * (size_t)NP * 8;
+    src.stride = (size_t)NP * 8;
+    src.slots = (unsigned)hdr->g_slot[0] | ((unsigned)hdr->g_slot[1] << 8) | ((unsigned)hdr->g_slot[2] << 16) | ((unsigned)hdr->g_slot[3] << 24);
+    const int n0 = hdr->g_n[0], n1 = hdr->g_n[1], n2 = hdr->g_n[2];
+    src.c1 = nfr > 1 ? n0 : big;
+    src.c2 = nfr > 2 ? n0 + n1 : big;
+    src.c3 = nfr > 3 ? n0 + n1 + n2 : big;
+    return src;
+}
+
+// apply_DBscan found (or can find) nothing: labels -1, bookkeeping as after a full run with 0 clusters
+__device__ __forceinline__ void finish_scene_stats(const DevState &st, int s, int U, int ncl)
+{
+    if (st.stats) {  // algorithmic bytes: ring rows in, labels out, new track records + ring rows out
+        unsigned long long *sl = stats_slot(st, s);
+        atomicAdd(&sl[1], (unsigned long long)(64 * U + 4 * U) + (unsigned long long)ncl * (sizeof(TrackRec) + 64ULL * 64ULL));
+        atomicAdd(&sl[3], 1ULL);
+        atomicAdd(&sl[4], (unsigned long long)U);
+        atomicAdd(&sl[7], (unsigned long long)ncl);
     }
+}
+
+// First stage of apply_DBscan for every scene k_track flagged (hdr->need_db), one small workgroup per
+// scene.  Clouds of U <= 256 points (the steady state: a ring of clutter) get the exact "no point can be
+// a core point" test of dbscan_core on its own, in a small-footprint kernel (6 KiB LDS, 8 workgroups
+// per CU), so that the BallTree kernel with its 512 threads and large LDS carve-up only starts for
+// scenes that may really hold a cluster.  Scenes that pass are finished here (labels -1, need_db
+// cleared); the others go to work list 3, larger clouds to the work list of their size class.
+__global__ __launch_bounds__(256) void k_dbscan_screen(DevCfg cfg, DevState st, int UM_out, int parity,
+                                                      int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    __shared__ double X[256], Y[256], Z[256];
+    __shared__ int cnt[256];
+    __shared__ unsigned long long mm[2];
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
+    const int min_samples = cfg.db_min_samples;
+    {
+        const int s = blockIdx.x;
+        SceneHdr *hdr = st.hdr + s;
+        if (!hdr->need_db) return;
+        const int U = hdr->db_u;
+        if (U > 256) {
+            if (tid == 0) {
+                const int cls = U <= 768 ? 1 : 2;
+                const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
+                st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
+            }
+            return;
+        }
+        const RowSrc src = ring_rows_of(cfg, st, hdr, s);
+        double y = 0.0;
+        if (tid < U) {
+            const double *r = src.row(tid);
+            const double2 a = *reinterpret_cast<const double2 *>(r);
+            X[tid] = a.x; Y[tid] = y = a.y; Z[tid] = r[2];
+            cnt[tid] = 0;
+        }
+        if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; flag = 0; }
+        __syncthreads();
+        bool dense = !(min_samples > 1 && zw >= 0.0 && eps >= 0.0);
+        if (!dense) {  // uniform
+            double ylo = tid < U ? y : 1.7976931348623157e308, yhi = tid < U ? y : -1.7976931348623157e308;
+            ylo = wave_min_d(ylo);
+            yhi = wave_max_d(yhi);
+            if (lane == 0 && ylo <= yhi) { atomicMin(&mm[0], sortable(ylo)); atomicMax(&mm[1], sortable(yhi)); }
+            __syncthreads();
+            const double ymin = unsortable(mm[0]), ymax = unsortable(mm[1]);
+            const double wa = 1 - ymax * rw, wb = 1 - ymin * rw;
+            const double wmin = wa < wb ? wa : wb;
+            if (wmin > 0.0) {
+                const double R2 = 2.0 * (eps / wmin) * (1.0 + 1e-9);  // see dbscan_core
+                const int parts = 256 / U > 0 ? 256 / U : 1;
+                const int part = tid / U, p = tid - part * U;
+                if (part < parts) {
+                    const double px = X[p], py = Y[p], pz = Z[p];
+                    int c = 0;
+#pragma unroll 4
+                    for (int q = part; q < U; q += parts) {
+                        const double dx = px - X[q], dy = py - Y[q], dz = pz - Z[q];
+                        c += ((dx * dx + dy * dy) + zw * (dz * dz) <= R2) ? 1 : 0;
+                    }
+                    if (parts > 1) atomicAdd(&cnt[p], c);
+                    else if (c >= min_samples) dense = true;
+                }
+                if (parts > 1) {
+                    __syncthreads();
+                    if (tid < U && cnt[tid] >= min_samples) dense = true;
+                }
+            } else {
+                dense = true;
+            }
+        }
+        if (dense) flag = 1;
+        __syncthreads();
+        if (flag) {
+            if (tid == 0) {
+                const int pos = atomicAdd(&st.db_count[parity * 4 + 3], 1);
+                st.db_list[(size_t)3 * cfg.n_scenes + pos] = s;
+            }
+        } else {
+            if (labels_out && tid < U) labels_out[(size_t)s * UM_out + tid] = -1;
+            if (tid == 0) {
+                if (db_n_out) db_n_out[s] = U;
+                hdr->need_db = 0;
+                finish_scene_stats(st, s, U, 0);
+#ifdef MMW_STAMPS
+                if (st.stats) atomicAdd(&stats_slot(st, s)[31], 1ULL);
+#endif
+            }
+        }
+    }
+}
+
+template <int NT, bool ALL8>
+__device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &st, const DbLds &L, int s, int UMc, int CL, int UM_out,
+                                            bool screened, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    SceneHdr *hdr = st.hdr + s;
+    const int U = hdr->db_u;
+    const RowSrc src = ring_rows_of(cfg, st, hdr, s);
     __syncthreads();  // every thread has read the header before anyone rewrites it below
-    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, st.stats);
+    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, stats_slot(st, s), screened);
     const int *labi = L.idx2;
     if (labels_out)
         for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM_out + i] = labi[i];
     if (tid == 0) {
         if (db_n_out) db_n_out[s] = U;
         hdr->need_db = 0;
-        if (st.stats) {  // algorithmic bytes: ring rows in, labels out, new track records + ring rows out
-            atomicAdd(&st.stats[1], (unsigned long long)(64 * U + 4 * U) + (unsigned long long)ncl * (sizeof(TrackRec) + 64ULL * 64ULL));
-            atomicAdd(&st.stats[3], 1ULL);
-            atomicAdd(&st.stats[4], (unsigned long long)U);
-            atomicAdd(&st.stats[7], (unsigned long long)ncl);
-        }
+        finish_scene_stats(st, s, U, ncl);
     }
     if (ncl == 0) return;
 
@@ -800,6 +907,24 @@ __global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, in
     }
 }
 
+// Persistent over work list `cls` (0..2 = size classes filled by k_track, 3 = class-0 scenes that the
+// screen could not rule out): workgroups that find nothing to do leave at once, so an empty or short
+// list costs one small wave of workgroups instead of n_scenes large-LDS ones.
+template <int NT, bool ALL8>
+__global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int cls,
+                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    DbLds L;
+    db_lds_layout<true>(UMc, CL, ALL8, lds_raw, &L);
+    const int count = st.db_count[parity * 4 + cls];
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
+        spawn_scene<NT, ALL8>(cfg, st, L, s, UMc, CL, UM_out, cls == 3, labels_out, db_n_out);
+        __syncthreads();  // LDS is reused by the next scene
+    }
+}
+
 // Utils.apply_DBscan on caller-provided clouds: pts[S][max_n][8]
 __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const double *__restrict__ pts,
                                                     const int32_t *__restrict__ n_all, int max_n, double eps,
@@ -854,14 +979,23 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
 // One launch per size class that can occur (class c exists when its lower bound < UM).
 void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
+    const int S = cfg.n_scenes;
+    hipLaunchKernelGGL(k_dbscan_screen, dim3(S), dim3(256), 0, stream, cfg, st, UM, parity, labels, db_n);
     for (int cls = 0; cls < 3; cls++) {
         if (cls > 0 && kClassUM[cls - 1] >= UM) break;
         const int umc = dbscan_class_um(cls, UM), cl = dbscan_class_cl(cls, UM, cfg.t_cap, cfg.db_min_samples);
         const size_t lds = dbscan_lds_bytes(cls, UM, cfg.t_cap, cfg.db_min_samples);
+        // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
+        int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));
+        const int nt = cls == 0 ? kClass0Threads : 256;
+        if (per_cu > 2048 / nt) per_cu = 2048 / nt;
+        if (per_cu < 1) per_cu = 1;
+        int grid = 256 * per_cu;
+        if (grid > S) grid = S;
         if (cls == 0)
-            hipLaunchKernelGGL((k_dbscan_spawn<kClass0Threads, true>), dim3(cfg.n_scenes), dim3(kClass0Threads), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
+            hipLaunchKernelGGL((k_dbscan_spawn<kClass0Threads, true>), dim3(grid), dim3(kClass0Threads), lds, stream, cfg, st, umc, cl, UM, parity, 3, labels, db_n);
         else
-            hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(cfg.n_scenes), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
+            hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(grid), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
     }
 }
 

@@ -22,7 +22,7 @@ namespace mmw {
     do {                                                                                      \
         if (tid == 0) {                                                                       \
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();                   \
-            atomicAdd(&st.stats[8 + (k)], t_now - t_prev);                                    \
+            atomicAdd(&stats_slot(st, blockIdx.x)[8 + (k)], t_now - t_prev);                                    \
             t_prev = t_now;                                                                   \
         }                                                                                     \
     } while (0)
@@ -697,12 +697,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         hdr->n_tracks = T;
         hdr->db_u = U;
         const bool need = U > 0 && T < cfg.tr_max_tracks;
-        hdr->need_db = need ? 1 : 0;
-        if (need) {  // work list of the cloud's size class (k_dbscan.hip)
-            const int cls = U <= 256 ? 0 : (U <= 768 ? 1 : 2);
-            const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
-            st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
-        }
+        hdr->need_db = need ? 1 : 0;  // picked up by k_dbscan_screen (k_dbscan.hip)
     }
     if (err) atomicOr(&hdr->err, err);
     STAMP(9);  // global ring append
@@ -711,10 +706,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         // read+written, unassigned rows appended to the global ring, rows appended to track rings
         int ring_rows = 0;
         for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
-        atomicAdd(&st.stats[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun + 64 * ring_rows));
-        atomicAdd(&st.stats[2], 1ULL);
-        atomicAdd(&st.stats[5], (unsigned long long)Tin);
-        atomicAdd(&st.stats[6], (unsigned long long)n * (unsigned long long)Tin);
+        unsigned long long *sl = stats_slot(st, s);
+        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun + 64 * ring_rows));
+        atomicAdd(&sl[2], 1ULL);
+        atomicAdd(&sl[5], (unsigned long long)Tin);
+        atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);
     }
 }
 

@@ -202,8 +202,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.g_ring, S * (size_t)ring * max_pts * 8 * sizeof(double));
     ALLOC(c->d_posture, MMW_NKP * sizeof(float));
     ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
-    ALLOC(c->d_stats, 32 * sizeof(unsigned long long));
-    ALLOC(c->d_db_list, 3 * S * sizeof(int32_t));
+    ALLOC(c->d_stats, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long));
+    ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
@@ -211,7 +211,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     c->st.db_list = c->d_db_list;
     c->st.db_count = c->d_db_count;
     if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(c->d_stats, 0, 32 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
@@ -538,24 +538,34 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
     return MMW_OK;
 }
 
+// the device keeps kStatSlots partial copies of the counters (mmw_device.hpp); the totals are formed here
+static int read_stats(mmw_ctx *c, uint64_t *out, int words)
+{
+    std::vector<uint64_t> h((size_t)kStatSlots * kStatWords);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_stats, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int w = 0; w < words; w++) {
+        uint64_t sum = 0;
+        for (int k = 0; k < kStatSlots; k++) sum += h[(size_t)k * kStatWords + w];
+        out[w] = sum;
+    }
+    return MMW_OK;
+}
+
 int mmw_stats_get(mmw_ctx *c, uint64_t *out)
 {
     if (!c || !out) return MMW_E_ARG;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MMW_OK;
+    return read_stats(c, out, 8);
 }
 int mmw_stats_get_ext(mmw_ctx *c, uint64_t *out)
 {
     if (!c || !out) return MMW_E_ARG;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MMW_OK;
+    return read_stats(c, out, kStatWords);
 }
 int mmw_stats_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
-    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 32 * sizeof(uint64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(uint64_t), c->stream));
     return MMW_OK;
 }
 

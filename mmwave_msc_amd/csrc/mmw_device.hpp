@@ -82,10 +82,20 @@ struct DevState {
     double *trk_ring;     // [S][t_cap][ring][ring_rows][8]
     double *g_ring;       // [S][ring][max_pts][8]
     const float *default_posture;  // [57]
-    unsigned long long *stats;     // [8] algorithmic-byte / work counters (see mmw_stats_get)
-    int32_t *db_list;              // [3][S] scenes that must run apply_DBscan this step, per size class
+    unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
+    int32_t *db_list;              // [4][S] scenes whose apply_DBscan needs the BallTree this step: size classes 0..2 (list 3 = class 0), built by k_dbscan_screen
     int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
 };
+
+// Counters are spread over kStatSlots copies (one 256-byte line each, picked by scene index): thousands of
+// workgroups adding to ONE address serialise in the memory-side atomic unit and that tail was longer than
+// the kernels themselves.
+constexpr int kStatSlots = 256;
+constexpr int kStatWords = 32;
+__device__ inline unsigned long long *stats_slot(const DevState &st, int scene)
+{
+    return st.stats ? st.stats + (size_t)(scene & (kStatSlots - 1)) * kStatWords : nullptr;
+}
 
 __host__ __device__ inline size_t trk_ring_stride_track(const DevCfg &c) { return (size_t)c.ring * c.ring_rows * 8; }
 

@@ -35,6 +35,7 @@ names_d = ["stage", "tree build (rest)", "centroids+radii", "queries", "labellin
 calls = float(out[3])
 totd = float(out[20:30].sum())
 if calls and totd:
+    print(f"k_dbscan early exits: {float(out[31]):.0f} of {calls:.0f} calls")
     print(f"k_dbscan: {calls:.0f} calls, mean U {float(out[4]) / calls:.0f}, mean cycles/WG {totd / calls:.0f}")
     for i, nme in enumerate(names_d):
         print(f"  {nme:28s} {float(out[20 + i]) / calls:9.0f} cyc  {100 * float(out[20 + i]) / totd:5.1f} %")
