@@ -25,6 +25,7 @@
 // k_track appends every scene that must cluster to the work list of its class.
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
+#include "mmw_cloud.hpp"
 
 namespace mmw {
 
@@ -118,49 +119,6 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
 #undef CARVE
     return off;
 }
-
-__device__ inline unsigned long long sortable(double v)
-{
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
-}
-__device__ inline double unsortable(unsigned long long k)
-{
-    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
-    return __longlong_as_double((long long)u);
-}
-
-__device__ inline double wave_min_d(double v)
-{
-    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
-}
-__device__ inline double wave_max_d(double v)
-{
-    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
-}
-
-// Row source: the candidate cloud is either the concatenation (oldest first) of the
-// scene's global ring frames (Tracking.py:51) or a caller-provided [n][8] block.
-// Pure arithmetic on scalars, passed by value: a struct of four base pointers picked by
-// comparisons gets turned into an indexed load from a private (scratch) copy by the compiler.
-struct RowSrc {
-    const double *gb;     // base of the scene's ring storage (or of the caller's block)
-    size_t stride;        // doubles per physical frame slot
-    unsigned slots;       // physical slot of frame k in byte k
-    int c1, c2, c3;       // first point index of frames 1..3 (INT_MAX when absent)
-    __device__ __forceinline__ const double *row(int i) const
-    {
-        const int k = (i >= c1 ? 1 : 0) + (i >= c2 ? 1 : 0) + (i >= c3 ? 1 : 0);
-        int c = 0;
-        c = i >= c1 ? c1 : c;
-        c = i >= c2 ? c2 : c;
-        c = i >= c3 ? c3 : c;
-        const unsigned slot = (slots >> (8 * k)) & 255u;
-        return gb + (size_t)slot * stride + (size_t)(i - c) * 8;
-    }
-};
 
 __device__ __forceinline__ int node_of(const DbLds &L, int p, int level)
 {
@@ -666,22 +624,6 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
 
 // Tracking.py:697-703 for the scenes of one size class: apply_DBscan on the global ring,
 // batch.clear(), _add_tracks.
-__device__ __forceinline__ RowSrc ring_rows_of(const DevCfg &cfg, const DevState &st, const SceneHdr *hdr, int s)
-{
-    RowSrc src;
-    const int nfr = hdr->g_len, NP = cfg.max_pts;
-    const int big = 0x7fffffff;
-    src.gb = st.g_ring + (size_t)s * cfg.ring * (size_t)NP * 8;
-    src.stride = (size_t)NP * 8;
-    src.slots = (unsigned)hdr->g_slot[0] | ((unsigned)hdr->g_slot[1] << 8) | ((unsigned)hdr->g_slot[2] << 16) | ((unsigned)hdr->g_slot[3] << 24);
-    const int n0 = hdr->g_n[0], n1 = hdr->g_n[1], n2 = hdr->g_n[2];
-    src.c1 = nfr > 1 ? n0 : big;
-    src.c2 = nfr > 2 ? n0 + n1 : big;
-    src.c3 = nfr > 3 ? n0 + n1 + n2 : big;
-    return src;
-}
-
-// apply_DBscan found (or can find) nothing: labels -1, bookkeeping as after a full run with 0 clusters
 __device__ __forceinline__ void finish_scene_stats(const DevState &st, int s, int U, int ncl)
 {
     if (st.stats) {  // algorithmic bytes: ring rows in, labels out, new track records + ring rows out
@@ -695,94 +637,40 @@ __device__ __forceinline__ void finish_scene_stats(const DevState &st, int s, in
 
 // First stage of apply_DBscan for every scene k_track flagged (hdr->need_db), one small workgroup per
 // scene.  Clouds of U <= 256 points (the steady state: a ring of clutter) get the exact "no point can be
-// a core point" test of dbscan_core on its own, in a small-footprint kernel (6 KiB LDS, 8 workgroups
-// per CU), so that the BallTree kernel with its 512 threads and large LDS carve-up only starts for
-// scenes that may really hold a cluster.  Scenes that pass are finished here (labels -1, need_db
-// cleared); the others go to work list 3, larger clouds to the work list of their size class.
+// a core point" test (cloud_has_no_core, mmw_cloud.hpp) in a small-footprint kernel (5 KiB LDS, 8
+// workgroups per CU), so that the BallTree kernel with its 512 threads and large LDS carve-up only
+// starts for scenes that may really hold a cluster.  Scenes that pass are finished here (labels -1,
+// need_db cleared); the others go to work list 3, larger clouds to the work list of their size class.
 __global__ __launch_bounds__(256) void k_dbscan_screen(DevCfg cfg, DevState st, int UM_out, int parity,
                                                       int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
-    __shared__ double X[256], Y[256], Z[256];
+    __shared__ float4 P4[256];
     __shared__ int cnt[256];
-    __shared__ unsigned long long mm[2];
+    __shared__ unsigned long long mm[3];
     __shared__ int flag;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
-    const int min_samples = cfg.db_min_samples;
-    {
-        const int s = blockIdx.x;
-        SceneHdr *hdr = st.hdr + s;
-        if (!hdr->need_db) return;
-        const int U = hdr->db_u;
-        if (U > 256) {
-            if (tid == 0) {
-                const int cls = U <= 768 ? 1 : 2;
-                const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
-                st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
-            }
-            return;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x;
+    SceneHdr *hdr = st.hdr + s;
+    if (!hdr->need_db) return;
+    const int U = hdr->db_u;
+    bool tree = true;
+    if (U <= 256) tree = !cloud_has_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, &flag);
+    if (tree) {
+        if (tid == 0) {
+            const int cls = U <= 256 ? 3 : (U <= 768 ? 1 : 2);
+            const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
+            st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
         }
-        const RowSrc src = ring_rows_of(cfg, st, hdr, s);
-        double y = 0.0;
-        if (tid < U) {
-            const double *r = src.row(tid);
-            const double2 a = *reinterpret_cast<const double2 *>(r);
-            X[tid] = a.x; Y[tid] = y = a.y; Z[tid] = r[2];
-            cnt[tid] = 0;
-        }
-        if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; flag = 0; }
-        __syncthreads();
-        bool dense = !(min_samples > 1 && zw >= 0.0 && eps >= 0.0);
-        if (!dense) {  // uniform
-            double ylo = tid < U ? y : 1.7976931348623157e308, yhi = tid < U ? y : -1.7976931348623157e308;
-            ylo = wave_min_d(ylo);
-            yhi = wave_max_d(yhi);
-            if (lane == 0 && ylo <= yhi) { atomicMin(&mm[0], sortable(ylo)); atomicMax(&mm[1], sortable(yhi)); }
-            __syncthreads();
-            const double ymin = unsortable(mm[0]), ymax = unsortable(mm[1]);
-            const double wa = 1 - ymax * rw, wb = 1 - ymin * rw;
-            const double wmin = wa < wb ? wa : wb;
-            if (wmin > 0.0) {
-                const double R2 = 2.0 * (eps / wmin) * (1.0 + 1e-9);  // see dbscan_core
-                const int parts = 256 / U > 0 ? 256 / U : 1;
-                const int part = tid / U, p = tid - part * U;
-                if (part < parts) {
-                    const double px = X[p], py = Y[p], pz = Z[p];
-                    int c = 0;
-#pragma unroll 4
-                    for (int q = part; q < U; q += parts) {
-                        const double dx = px - X[q], dy = py - Y[q], dz = pz - Z[q];
-                        c += ((dx * dx + dy * dy) + zw * (dz * dz) <= R2) ? 1 : 0;
-                    }
-                    if (parts > 1) atomicAdd(&cnt[p], c);
-                    else if (c >= min_samples) dense = true;
-                }
-                if (parts > 1) {
-                    __syncthreads();
-                    if (tid < U && cnt[tid] >= min_samples) dense = true;
-                }
-            } else {
-                dense = true;
-            }
-        }
-        if (dense) flag = 1;
-        __syncthreads();
-        if (flag) {
-            if (tid == 0) {
-                const int pos = atomicAdd(&st.db_count[parity * 4 + 3], 1);
-                st.db_list[(size_t)3 * cfg.n_scenes + pos] = s;
-            }
-        } else {
-            if (labels_out && tid < U) labels_out[(size_t)s * UM_out + tid] = -1;
-            if (tid == 0) {
-                if (db_n_out) db_n_out[s] = U;
-                hdr->need_db = 0;
-                finish_scene_stats(st, s, U, 0);
+        return;
+    }
+    if (labels_out && tid < U) labels_out[(size_t)s * UM_out + tid] = -1;
+    if (tid == 0) {
+        if (db_n_out) db_n_out[s] = U;
+        hdr->need_db = 0;
+        finish_scene_stats(st, s, U, 0);
 #ifdef MMW_STAMPS
-                if (st.stats) atomicAdd(&stats_slot(st, s)[31], 1ULL);
+        if (st.stats) atomicAdd(&stats_slot(st, s)[31], 1ULL);
 #endif
-            }
-        }
     }
 }
 

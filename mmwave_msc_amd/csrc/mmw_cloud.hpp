@@ -1,0 +1,143 @@
+// mmw_cloud.hpp -- the DBSCAN candidate cloud (the scene's global BatchedData ring, Tracking.py:51,689-697)
+// as seen by k_track and k_dbscan, and the exact "apply_DBscan cannot find a core point" screen.
+#pragma once
+
+#include "mmw_device.hpp"
+
+namespace mmw {
+
+__device__ inline unsigned long long sortable(double v)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+__device__ inline double unsortable(unsigned long long k)
+{
+    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__device__ inline double wave_min_d(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ inline double wave_max_d(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+
+// Row source: the candidate cloud is either the concatenation (oldest first) of the
+// scene's global ring frames (Tracking.py:51) or a caller-provided [n][8] block.
+// Pure arithmetic on scalars, passed by value: a struct of four base pointers picked by
+// comparisons gets turned into an indexed load from a private (scratch) copy by the compiler.
+struct RowSrc {
+    const double *gb;     // base of the scene's ring storage (or of the caller's block)
+    size_t stride;        // doubles per physical frame slot
+    unsigned slots;       // physical slot of frame k in byte k
+    int c1, c2, c3;       // first point index of frames 1..3 (INT_MAX when absent)
+    __device__ __forceinline__ const double *row(int i) const
+    {
+        const int k = (i >= c1 ? 1 : 0) + (i >= c2 ? 1 : 0) + (i >= c3 ? 1 : 0);
+        int c = 0;
+        c = i >= c1 ? c1 : c;
+        c = i >= c2 ? c2 : c;
+        c = i >= c3 ? c3 : c;
+        const unsigned slot = (slots >> (8 * k)) & 255u;
+        return gb + (size_t)slot * stride + (size_t)(i - c) * 8;
+    }
+};
+
+__device__ __forceinline__ RowSrc ring_rows_of(const DevCfg &cfg, const DevState &st, const SceneHdr *hdr, int s)
+{
+    RowSrc src;
+    const int nfr = hdr->g_len, NP = cfg.max_pts;
+    const int big = 0x7fffffff;
+    src.gb = st.g_ring + (size_t)s * cfg.ring * (size_t)NP * 8;
+    src.stride = (size_t)NP * 8;
+    src.slots = (unsigned)hdr->g_slot[0] | ((unsigned)hdr->g_slot[1] << 8) | ((unsigned)hdr->g_slot[2] << 16) | ((unsigned)hdr->g_slot[3] << 24);
+    const int n0 = hdr->g_n[0], n1 = hdr->g_n[1], n2 = hdr->g_n[2];
+    src.c1 = nfr > 1 ? n0 : big;
+    src.c2 = nfr > 2 ? n0 + n1 : big;
+    src.c3 = nfr > 3 ? n0 + n1 + n2 : big;
+    return src;
+}
+
+
+// Exact screen for clouds of U <= 256 points, 256 threads (all of them must call; barriers inside).
+// Returns true (uniformly) when NO point can be a core point of sklearn's BallTree DBSCAN, i.e. every
+// label is -1 (Utils.py:268-275 then returns no clusters).
+//
+// Bound (proof in dbscan_core, k_dbscan.hip): every BallTree neighbour q of p has
+//   E(p,q)^2 = dx^2 + dy^2 + z_w dz^2 <= 2 eps / wmin,   wmin = min over the cloud of 1 - range_w * y.
+// The count of points inside that ellipsoid is a SUPERSET count, so it may be formed in fp32 as long as
+// the radius is widened by everything fp32 can lose: coordinates (z pre-scaled by sqrt(z_w)) are rounded
+// once, |error| <= M 2^-24 per coordinate with M the largest magnitude in the cloud, i.e. at most
+// 2 sqrt(3) M 2^-24 on E (a norm), and the fp32 evaluation of the squared norm is good to a few 2^-24
+// relative.  R below carries 4 M 6e-8 absolute and 1e-5 relative slack, far more than both.
+// P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.
+__device__ __forceinline__ bool cloud_has_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
+                                                  unsigned long long *mm, int *flag)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
+    const int min_samples = cfg.db_min_samples;
+    if (!(min_samples > 1 && zw >= 0.0 && eps >= 0.0)) return false;
+    const double sqzw = sqrt(zw);
+    double y = 0.0, mag = 0.0;
+    if (tid < U) {
+        const double *r = src.row(tid);
+        const double2 a = *reinterpret_cast<const double2 *>(r);
+        const double zs = r[2] * sqzw;
+        y = a.y;
+        P4[tid] = make_float4((float)a.x, (float)a.y, (float)zs, 0.f);
+        mag = fmax(fmax(fabs(a.x), fabs(a.y)), fabs(zs));
+        if (!(mag <= 1e15)) mag = __longlong_as_double(0x7ff0000000000000LL);  // NaN/inf/huge: give up below
+        cnt[tid] = 0;
+    }
+    if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; mm[2] = 0ULL; *flag = 0; }
+    __syncthreads();
+    double ylo = tid < U ? y : 1.7976931348623157e308, yhi = tid < U ? y : -1.7976931348623157e308;
+    ylo = wave_min_d(ylo);
+    yhi = wave_max_d(yhi);
+    mag = wave_max_d(mag);
+    if (lane == 0 && ylo <= yhi) {
+        atomicMin(&mm[0], sortable(ylo));
+        atomicMax(&mm[1], sortable(yhi));
+        atomicMax(&mm[2], (unsigned long long)__double_as_longlong(mag));  // mag >= 0: bit order == value order
+    }
+    __syncthreads();
+    const double ymin = unsortable(mm[0]), ymax = unsortable(mm[1]), M = __longlong_as_double((long long)mm[2]);
+    const double wa = 1 - ymax * rw, wb = 1 - ymin * rw;
+    const double wmin = wa < wb ? wa : wb;
+    if (!(wmin > 0.0) || !(M <= 1e15)) return false;  // uniform: same LDS values for every thread
+    const double R = sqrt(2.0 * (eps / wmin)) * (1.0 + 1e-9) + 4.0 * M * 6e-8;
+    const float R2f = (float)(R * R * (1.0 + 1e-5));
+    // tasks (point p, slice `part` of the partners), about four per thread
+    int parts = 1024 / U;
+    parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+    const int q256 = 256 / U, r256 = 256 - q256 * U, ntask = U * parts;
+    int part = tid / U, p = tid - part * U;
+    for (int t = tid; t < ntask; t += 256) {
+        const float4 a = P4[p];
+        int c = 0;
+#pragma unroll 4
+        for (int q = part; q < U; q += parts) {
+            const float4 b = P4[q];
+            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+            const float e = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            c += (e <= R2f) ? 1 : 0;
+        }
+        atomicAdd(&cnt[p], c);
+        p += r256;
+        part += q256;
+        if (p >= U) { p -= U; part++; }
+    }
+    __syncthreads();
+    if (tid < U && cnt[tid] >= min_samples) *flag = 1;
+    __syncthreads();
+    return *flag == 0;
+}
+
+}  // namespace mmw
