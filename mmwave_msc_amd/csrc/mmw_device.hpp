@@ -11,7 +11,7 @@ namespace mmw {
 
 constexpr int kThreads = 256;       // 4 waves per workgroup, one workgroup per scene
 constexpr int kWaves = kThreads / 64;
-constexpr int kGateChunk = 16;      // tracks whose 6x6 inverses are staged in LDS at once
+constexpr int kGateChunk = 8;       // tracks predicted / gated / updated together (their matrices sit in LDS)
 constexpr int kLeafSize = 30;       // sklearn BallTree default leaf_size (DBSCAN passes it through)
 constexpr int kMaxLeaves = 32;      // n <= 1920 -> <= 63 nodes -> <= 32 leaves
 constexpr int kMaxNodes = 63;

@@ -71,79 +71,83 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // 6x6 partial-pivot LU, determinant and inverse (stands for np.linalg.det / np.linalg.inv at
-// Tracking.py:558-560 and filterpy's inv(S)), up to EIGHT matrices per wave: lanes 8g..8g+5 hold
-// rows 0..5 of matrix g (lanes 8g+6, 8g+7 idle).  First-max partial pivoting, L stored in place, det = signed product of pivots; the
-// inverse is solved for all six right-hand sides at once in axpy form: forward substitution
-// subtracts L[r][k]*Y[k] for k ascending, back substitution subtracts U[r][k]*X[k] for k
-// DESCENDING and divides by U[r][r] last (the order the CPU oracle restates).  One call costs
-// about what the one-matrix-per-wave version costs, so a scene's tracks share it.
-// All 64 lanes must call; `ok` is per group.
-__device__ __forceinline__ bool lu6_inverse_rows(double (&a)[6], int lane, double (&inv)[6], double &det)
+// Tracking.py:558-560 and filterpy's inv(S)), FOUR matrices per wave, column-parallel Gauss-Jordan
+// on the augmented matrix [A | I]: in every 16-lane group lane c < 6 holds column c of A in v[0..5],
+// lanes 6..11 hold the columns of the identity (set here), lanes 12..15 idle.
+//
+// Why columns: the pivot search of step k and the multipliers l_i = A[i][k] / A[k][k] only involve
+// column k, i.e. ONE lane's registers.  Every lane runs the step on its own column; what lane k found
+// (pivot row, 1/pivot, the multipliers) is broadcast in one batch of cross-lane reads, then every lane
+// swaps and eliminates locally: one cross-lane round trip per pivot step, and one more for the whole
+// back substitution -- the wave spends its time on 6x6 arithmetic, not on the LDS crossbar.
+//
+// The arithmetic per element is that of the CPU oracle's lu6(): first-max pivoting; 1/pivot formed
+// once (rp); l = a*rp; a[i][c] -= l_i*a[k][c]; the right-hand sides see the same row operations
+// (forward substitution, k ascending); back substitution subtracts U[r][k]*x[k] for k DESCENDING and
+// scales by rp[r] last; det = signed product of the pivots in order.
+// On return lanes 6..11 hold columns 0..5 of the inverse in v; det is valid in every lane of the group.
+// All 64 lanes must call; the result (false = a zero pivot) is per group.
+__device__ __forceinline__ bool lu6_inverse_cols(double (&v)[6], int lane, double &det)
 {
-    const int r = lane & 7, gb = lane & ~7;
-    int prow = r;
+    const int c = lane & 15, gb = lane & ~15;
+    if (c >= 6) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = (c - 6 == i) ? 1.0 : 0.0;
+    }
     bool neg = false, ok = true;
+    double rp[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
+        // this lane's column as if it were column k: pivot row, 1/pivot, swapped column, multipliers
         int p = k;
-        double best = fabs(__shfl(a[k], gb + k));
+        double best = fabs(v[k]), pv = v[k];
 #pragma unroll
         for (int r2 = k + 1; r2 < 6; r2++) {
-            const double v = fabs(__shfl(a[k], gb + r2));
-            if (v > best) { best = v; p = r2; }
+            const double t = fabs(v[r2]);
+            if (t > best) { best = t; p = r2; pv = v[r2]; }
         }
+        const double rpl = 1.0 / pv;
+        double l[6];
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) l[i] = ((p == i) ? v[k] : v[i]) * rpl;  // row i after the swap k <-> p
+        // what lane k found, for the whole group
+        p = __shfl(p, gb + k);
+        best = __shfl(best, gb + k);
+        rp[k] = __shfl(rpl, gb + k);
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) l[i] = __shfl(l[i], gb + k);
         if (!(best > 0.0)) ok = false;
-        const int src = gb + ((r == k) ? p : ((r == p) ? k : r));
-#pragma unroll
-        for (int c = 0; c < 6; c++) a[c] = __shfl(a[c], src);
-        prow = __shfl(prow, src);
         if (p != k) neg = !neg;
-        double piv[6];
+        {  // rows k <-> p of this lane's column
+            const double tk = v[k];
 #pragma unroll
-        for (int c = k; c < 6; c++) piv[c] = __shfl(a[c], gb + k);
-        if (r > k && r < 6) {
-            const double l = a[k] / piv[k];
-            a[k] = l;
+            for (int r2 = k + 1; r2 < 6; r2++)
+                if (p == r2) { v[k] = v[r2]; v[r2] = tk; }
+        }
 #pragma unroll
-            for (int c = k + 1; c < 6; c++) a[c] = a[c] - l * piv[c];
+        for (int i = k + 1; i < 6; i++) {
+            const double e = v[i] - l[i] * v[k];
+            v[i] = (c == k) ? l[i] : ((c > k) ? e : v[i]);  // column k keeps L, finished columns stay
         }
     }
-    double d = __shfl(a[0], gb);
+    // U above the diagonal and the pivots, all at once
+    double u[6][6], piv[6];
 #pragma unroll
-    for (int k = 1; k < 6; k++) d = d * __shfl(a[k], gb + k);
+    for (int k = 0; k < 6; k++) {
+        piv[k] = __shfl(v[k], gb + k);
+#pragma unroll
+        for (int r = 0; r < k; r++) u[r][k] = __shfl(v[r], gb + k);
+    }
+    double d = piv[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) d = d * piv[k];
     det = neg ? -d : d;
-    double y[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) y[c] = (prow == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        double yk[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) yk[c] = __shfl(y[c], gb + k);
-        if (r > k && r < 6) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) y[c] = y[c] - a[k] * yk[c];
-        }
-    }
 #pragma unroll
     for (int k = 5; k >= 0; k--) {
-        const double ukk = __shfl(a[k], gb + k);
-        if (r == k) {
+        v[k] = v[k] * rp[k];
 #pragma unroll
-            for (int c = 0; c < 6; c++) y[c] = y[c] / ukk;
-        }
-        if (k > 0) {
-            double xk[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) xk[c] = __shfl(y[c], gb + k);
-            if (r < k) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) y[c] = y[c] - a[k] * xk[c];
-            }
-        }
+        for (int r = 0; r < k; r++) v[r] = v[r] - u[r][k] * v[k];
     }
-#pragma unroll
-    for (int c = 0; c < 6; c++) inv[c] = y[c];
     return ok;
 }
 

@@ -274,7 +274,8 @@ static void kf_predict(const orc_config *c, trk_t *t, double dtm)
  * np.linalg.det / np.linalg.inv at Tracking.py:558-560 and filterpy's inv(S)). */
 static int lu6(const double *M, double *inv, double *det)
 {
-    double A[36];
+    double A[36], rp[6];   /* rp[k] = 1 / pivot k: ONE division per pivot, every other "division"
+                            * is a multiplication by it (the GPU kernel does the same, bit for bit) */
     int perm[6];
     int neg = 0;
     memcpy(A, M, sizeof(A));
@@ -292,8 +293,9 @@ static int lu6(const double *M, double *inv, double *det)
             { int tp = perm[k]; perm[k] = perm[p]; perm[p] = tp; }
             neg ^= 1;
         }
+        rp[k] = 1.0 / A[k * 6 + k];
         for (int r = k + 1; r < 6; r++) {
-            double l = A[r * 6 + k] / A[k * 6 + k];
+            double l = A[r * 6 + k] * rp[k];
             A[r * 6 + k] = l;
             for (int cc = k + 1; cc < 6; cc++) A[r * 6 + cc] = A[r * 6 + cc] - l * A[k * 6 + cc];
         }
@@ -311,11 +313,11 @@ static int lu6(const double *M, double *inv, double *det)
             y[r] = s;
         }
         /* back substitution in axpy (column-sweep) order: x_r subtracts U[r][k]*x_k for k = 5 down
-         * to r+1, then divides -- the order a lane-parallel solver produces naturally */
+         * to r+1, then scales by 1/U[r][r] -- the order a lane-parallel solver produces naturally */
         for (int r = 5; r >= 0; r--) {
             double s = y[r];
             for (int k = 5; k > r; k--) s = s - A[r * 6 + k] * inv[k * 6 + col];
-            inv[r * 6 + col] = s / A[r * 6 + r];
+            inv[r * 6 + col] = s * rp[r];
         }
     }
     return 0;
