@@ -30,15 +30,12 @@ namespace mmw {
 #define STAMP(k)
 #endif
 
-constexpr int kGateStride = 72;   // per track: gating Ci[36] | logdet | hx[6]; update SI[36] | Rc[36]
-// per track of a chunk: P[81] A[81] K[54] C1[54] x[9] y[6] scalars[3] centroid[6] (+pad)
-constexpr int kTrkScratch = 296;
-constexpr int oP = 0, oA = 81, oK = 162, oC1 = 216, oX = 270, oY = 279, oS = 285, oCen = 288;
+constexpr int kGateStride = 44;   // per track: Ci[36] | log|det| | hx[6] (k_predict's gate record)
 constexpr int kPwStackDepth = 4;  // numpy pairwise-sum recursion depth for n <= 2048
 
 struct TrackLds {
     double *p6;      // [6][NP] point columns x,y,z,vx,vy,vz
-    double *work;    // union: gate[kGateChunk][72] + per-track scratch [kGateChunk][296] | point tile + pairwise stack
+    double *work;    // union: gate[kGateChunk][kGateStride] | point tile + pairwise stack
     double *cen;     // [t_cap][6] centroid of this frame's cloud per track
     int *perm;       // [NP] point indices grouped by class (0 = unassigned, j+1 = track j), input order kept
     int *cnt;        // [NB][CLS]
@@ -64,7 +61,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     // One region, three lives: (1) gate matrices + per-wave scratch while tracks are predicted and
     // points gated (points sit in registers then); (2) the SoA point tile + the pairwise-sum stack
     // while cluster statistics are formed; (3) per-wave scratch again for the Kalman update.
-    const int work_a = kGateChunk * (kGateStride + kTrkScratch), work_b = 6 * NP + pw_depth(NP) * kThreads;
+    const int work_a = kGateChunk * kGateStride, work_b = 6 * NP + pw_depth(NP) * kThreads;
     size_t off = 0;
 #define CARVE(field, type, count)                            \
     if constexpr (WRITE) L->field = (type *)(base + off);    \
@@ -179,7 +176,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     // Wave w of every resident workgroup tends to sit on SIMD w, so a fixed choice would queue the serial
     // work of all workgroups of a CU on one SIMD while the other three idle; rotating by scene spreads it.
     const int role = (wave + s) & (kWaves - 1), rtid = role * 64 + lane;
-    const int NP = cfg.max_pts, dx = cfg.dx, CLS = cfg.t_cap + 1;
+    const int NP = cfg.max_pts, CLS = cfg.t_cap + 1;
     const int n = n_pts[s];
     SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
@@ -202,7 +199,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
     double *gate = L.work;
-    double *scr = L.work + kGateChunk * kGateStride;  // [kGateChunk][kTrkScratch]
 
     // ---- this thread's points (rows tid, tid+256, ...): columns 0..5 straight into registers with
     //      16-byte loads; issued first so HBM latency hides under the track prediction below.
@@ -228,107 +224,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
 
     for (int c0 = 0; c0 < T; c0 += kGateChunk) {
         const int tc = min(kGateChunk, T - c0);
-        // ---- _predict_all (Tracking.py:591-596; filterpy predict; motion model constants.py:195-215)
-        //      for all tracks of the chunk at once, one matrix ELEMENT per thread and a barrier per
-        //      stage: one global round trip and three short stages instead of a wave walking through
-        //      its tracks one after the other ----
-        for (int e = tid; e < tc * 136; e += kThreads) {  // stage P, x, group dispersion, spread, lifetime
-            const int jl = e / 136, k = e - jl * 136;
-            const TrackRec *rec = trk + L.slot[c0 + jl];
-            double *Wj = scr + jl * kTrkScratch;
-            if (k < 81) Wj[oP + k] = rec->P[k];
-            else if (k < 90) Wj[oX + k - 81] = rec->x[k - 81];
-            else if (k < 126) Wj[oK + k - 90] = rec->gd[k - 90];        // K / C1 are dead until the update
-            else if (k < 132) Wj[oK + 36 + k - 126] = rec->spread[k - 126];
-            else if (k == 132) Wj[oS] = rec->lifetime + dt;
-        }
-        __syncthreads();
-        for (int e = tid; e < tc * 90; e += kThreads) {
-            const int jl = e / 90, k = e - jl * 90;
-            double *Wj = scr + jl * kTrkScratch;
-            const double *Pw = Wj + oP, *xw = Wj + oX;
-            const double dtm = Wj[oS];
-            const double h = 0.5 * (dtm * dtm);
-            if (k < 81) {
-                // A = F P.  F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense
-                // dot product reduces to these terms (the others are exact zeros).
-                const int i = k / 9, c = k - i * 9;
-                if (i < dx && c < dx) {
-                    double a = Pw[k];
-                    if (i + 3 < dx) a += dtm * Pw[(i + 3) * 9 + c];
-                    if (i + 6 < dx) a += h * Pw[(i + 6) * 9 + c];
-                    Wj[oA + k] = a;
-                }
-            } else {
-                const int i = k - 81;
-                if (i < dx) {
-                    double xn = xw[i];
-                    if (i + 3 < dx) xn += dtm * xw[i + 3];
-                    if (i + 6 < dx) xn += h * xw[i + 6];
-                    Wj[oC1 + i] = xn;
-                }
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < tc * 90; e += kThreads) {
-            const int jl = e / 90, k = e - jl * 90;
-            TrackRec *rec = trk + L.slot[c0 + jl];
-            double *Wj = scr + jl * kTrkScratch;
-            const double *Aw = Wj + oA;
-            const double dtm = Wj[oS];
-            const double h = 0.5 * (dtm * dtm);
-            if (k < 81) {
-                const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
-                const int i = k / 9, c = k - i * 9;
-                if (i < dx && c < dx) {
-                    double b = Aw[k];  // B = A F^T
-                    if (c + 3 < dx) b += Aw[i * 9 + c + 3] * dtm;
-                    if (c + 6 < dx) b += Aw[i * 9 + c + 6] * h;
-                    double q = 0.0;
-                    if (i / 3 == c / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
-                        const int qi = i % 3, qc = c % 3, sdeg = qi + qc;
-                        const double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
-                                          : sdeg == 3 ? dtm : 1.0;
-                        q = base * cfg.kf_q_std;
-                    }
-                    const double pn = b + q;
-                    rec->P[k] = pn;
-                    Wj[oP + k] = pn;
-                }
-            } else {
-                const int i = k - 81;
-                if (i < dx) { const double xn = Wj[oC1 + i]; rec->x[i] = xn; Wj[oX + i] = xn; }
-            }
-        }
-        __syncthreads();
-        STAMP(10);  // (diagnostic) predict stages before the gate LU
-        // ---- gate matrices of the whole chunk in ONE pass: four 6x6 systems per wave (16-lane group g,
-        //      lane c of the group = column c of track 4*wave+g).  C_g = P[:6,:6] + diag((spread/2)^2) +
-        //      group_disp_est; inverse and log|det| (Tracking.py:551-560) ----
-        if (role * 4 < tc) {
-            const int g = lane >> 4, c = lane & 15, jl = role * 4 + g;
-            const bool live = jl < tc, valid = live && c < 6;
-            double v[6], det;
-#pragma unroll
-            for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;  // idle groups: identity
-            const double *Wj = scr + (live ? jl : 0) * kTrkScratch;
-            if (valid) {
-                const double hh = Wj[oK + 36 + c] / 2;
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[i] = (Wj[oP + i * 9 + c] + ((i == c) ? hh * hh : 0.0)) + Wj[oK + i * 6 + c];
-            }
-            const bool ok = lu6_inverse_cols(v, lane, det);
-            STAMP(11);
-            if (live) {
-                if (!ok) err |= ERR_SINGULAR;
-                double *G = gate + jl * kGateStride;
-                if (c >= 6 && c < 12) {
-#pragma unroll
-                    for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
-                }
-                if (c == 0) G[36] = dlog(fabs(det));
-                if (c < 6) G[37 + c] = Wj[oX + c];
-            }
+        // ---- the chunk's gate matrices (inverse, log|det|, predicted position) as k_predict left them ----
+        for (int e = tid; e < tc * kGateRec; e += kThreads) {
+            const int jl = e / kGateRec, k = e - jl * kGateRec;
+            gate[jl * kGateStride + k] = st.gate_buf[((size_t)s * cfg.t_cap + c0 + jl) * kGateRec + k];
         }
         __syncthreads();
         STAMP(1);  // predict + gate matrices
@@ -600,128 +499,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     __syncthreads();
     STAMP(7);  // maintenance
 
-    // ---- _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy update;
-    //      like the prediction: all tracks of a chunk together, one matrix element per thread ----
-    for (int c0 = 0; c0 < T; c0 += kGateChunk) {
-      const int tc = min(kGateChunk, T - c0);
-      // stage everything the update reads: one global round trip for the whole chunk
-      for (int e = tid; e < tc * 144; e += kThreads) {
-          const int jl = e / 144, k = e - jl * 144;
-          const TrackRec *rec = trk + L.slot[c0 + jl];
-          double *Wj = scr + jl * kTrkScratch;
-          if (k < 81) Wj[oP + k] = rec->P[k];
-          else if (k < 90) Wj[oX + k - 81] = rec->x[k - 81];
-          else if (k < 126) Wj[oC1 + k - 90] = rec->gd[k - 90];          // C1 is formed after Rc has consumed these
-          else if (k < 132) Wj[oC1 + 36 + k - 126] = rec->spread[k - 126];
-          else if (k < 138) Wj[oCen + k - 132] = rec->centroid[k - 132];
-          else if (k == 138) Wj[oS] = (double)rec->point_num;
-          else if (k == 139) Wj[oS + 1] = rec->n_est;
-          else if (k == 140) Wj[oS + 2] = rec->lifetime;
-      }
-      __syncthreads();
-      // innovation covariances of the whole chunk in one pass (four 6x6 systems per wave):
-      // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
-      if (role * 4 < tc) {
-          const int g = lane >> 4, c = lane & 15, jl = role * 4 + g;
-          const bool live = jl < tc, valid = live && c < 6;
-          double v[6], det;
-#pragma unroll
-          for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;
-          double *Wj = scr + (live ? jl : 0) * kTrkScratch;
-          double *G = gate + (live ? jl : 0) * kGateStride;
-          if (valid) {
-              const double N = Wj[oS], nest = Wj[oS + 1];
-              const double den = (nest - 1) * N;
-              if (den == 0.0) err |= ERR_DIVZERO;
-              const double coef = (nest - N) / den;
-              const double hh = Wj[oC1 + 36 + c] / 2;
-#pragma unroll
-              for (int i = 0; i < 6; i++) {
-                  const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * Wj[oC1 + i * 6 + c];
-                  G[36 + i * 6 + c] = rc;
-                  v[i] = Wj[oP + i * 9 + c] + rc;  // S = H P H^T + R
-              }
-              Wj[oY + c] = Wj[oCen + c] - Wj[oX + c];  // y = z - H x
-          }
-          const bool ok = lu6_inverse_cols(v, lane, det);
-          if (live) {
-              if (!ok) err |= ERR_SINGULAR;
-              if (c >= 6 && c < 12) {
-#pragma unroll
-                  for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
-              }
-          }
-      }
-      __syncthreads();
-      for (int e = tid; e < tc * 54; e += kThreads) {  // K = P H^T S^-1
-          const int jl = e / 54, k = e - jl * 54;
-          double *Wj = scr + jl * kTrkScratch;
-          const double *Pw = Wj + oP, *SIw = gate + jl * kGateStride;
-          const int i = k / 6, c = k - i * 6;
-          if (i < dx) {
-              double a = Pw[i * 9] * SIw[c];
-              for (int q = 1; q < 6; q++) a += Pw[i * 9 + q] * SIw[q * 6 + c];
-              Wj[oK + k] = a;
-          }
-      }
-      __syncthreads();
-      for (int e = tid; e < tc * 144; e += kThreads) {
-          const int jl = e / 144, k = e - jl * 144;
-          double *Wj = scr + jl * kTrkScratch;
-          const double *Pw = Wj + oP, *Kw = Wj + oK, *yw = Wj + oY, *Rcw = gate + jl * kGateStride + 36;
-          if (k < 81) {  // A = (I - K H) P
-              const int i = k / 9, c = k - i * 9;
-              if (i < dx && c < dx) {
-                  double a = 0.0;
-                  for (int q = 0; q < dx; q++) {
-                      const double d = (i == q) ? 1.0 : 0.0;
-                      const double ikh = q < 6 ? d - Kw[i * 6 + q] : d;
-                      a = (q == 0) ? ikh * Pw[c] : a + ikh * Pw[q * 9 + c];
-                  }
-                  Wj[oA + k] = a;
-              }
-          } else if (k < 135) {  // C1 = K R
-              const int kk = k - 81, i = kk / 6, c = kk - i * 6;
-              if (i < dx) {
-                  double a = Kw[i * 6] * Rcw[c];
-                  for (int q = 1; q < 6; q++) a += Kw[i * 6 + q] * Rcw[q * 6 + c];
-                  Wj[oC1 + kk] = a;
-              }
-          } else {  // x = x + K y
-              const int i = k - 135;
-              if (i < dx) {
-                  double a = Kw[i * 6] * yw[0];
-                  for (int q = 1; q < 6; q++) a += Kw[i * 6 + q] * yw[q];
-                  double xnew = Wj[oX + i] + a;
-                  if (i == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
-                      const double var = Wj[oCen] - xnew;
-                      if (!(var == 0.0) && Wj[oS + 2] == 0.0) xnew += var * 0.4;
-                  }
-                  trk[L.slot[c0 + jl]].x[i] = xnew;
-              }
-          }
-      }
-      __syncthreads();
-      for (int e = tid; e < tc * 81; e += kThreads) {  // P = A (I-KH)^T + C1 K^T
-          const int jl = e / 81, k = e - jl * 81;
-          const double *Wj = scr + jl * kTrkScratch;
-          const double *Aw = Wj + oA, *Kw = Wj + oK, *C1w = Wj + oC1;
-          const int i = k / 9, c = k - i * 9;
-          if (i < dx && c < dx) {
-              double b = 0.0;
-              for (int q = 0; q < dx; q++) {
-                  const double d = (c == q) ? 1.0 : 0.0;
-                  const double ikh = q < 6 ? d - Kw[c * 6 + q] : d;
-                  b = (q == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + q] * ikh;
-              }
-              double c2 = C1w[i * 6] * Kw[c * 6];
-              for (int q = 1; q < 6; q++) c2 += C1w[i * 6 + q] * Kw[c * 6 + q];
-              trk[L.slot[c0 + jl]].P[k] = b + c2;
-          }
-      }
-      __syncthreads();
-    }
-
+    // (_update_all, Tracking.py:598-603, runs as its own batched kernel right after this one: k_update)
     STAMP(8);  // update
     // ---- batch.add_frame(unassigned) on the global ring + DBSCAN trigger (Tracking.py:689-697) ----
     const int nun = L.cls_n[0];

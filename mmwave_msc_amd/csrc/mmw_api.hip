@@ -14,6 +14,8 @@
 namespace mmw {
 size_t track_lds_bytes(const DevCfg &c);
 hipError_t prepare_track(const DevCfg &cfg);
+void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, hipStream_t stream);
+void launch_update(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, hipStream_t stream);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream);
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
@@ -205,6 +207,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_stats, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long));
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
+    ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
     c->st.stats = c->d_stats;
@@ -235,7 +238,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -325,7 +328,9 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
     prof_begin(c, MMW_K_TRACK, ep);
+    launch_predict(c->dc, c->st, n_pts, dt, c->stream);
     launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, c->step_parity, c->stream);
+    launch_update(c->dc, c->st, n_pts, c->stream);
     prof_end(c, ep);
     prof_begin(c, MMW_K_DBSCAN, ep);
     launch_dbscan_spawn(c->dc, c->st, c->UM, c->step_parity, db_labels, db_n, c->stream);

@@ -11,7 +11,8 @@ namespace mmw {
 
 constexpr int kThreads = 256;       // 4 waves per workgroup, one workgroup per scene
 constexpr int kWaves = kThreads / 64;
-constexpr int kGateChunk = 8;       // tracks predicted / gated / updated together (their matrices sit in LDS)
+constexpr int kGateChunk = 16;      // tracks whose gate matrices sit in LDS at once
+constexpr int kGateRec = 44;        // doubles per gate record: Ci[36] | log|det| | predicted position hx[6] | pad
 constexpr int kLeafSize = 30;       // sklearn BallTree default leaf_size (DBSCAN passes it through)
 constexpr int kMaxLeaves = 32;      // n <= 1920 -> <= 63 nodes -> <= 32 leaves
 constexpr int kMaxNodes = 63;
@@ -85,6 +86,7 @@ struct DevState {
     unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
     int32_t *db_list;              // [4][S] scenes whose apply_DBscan needs the BallTree this step: size classes 0..2 (list 3 = class 0), built by k_dbscan_screen
     int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
+    double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
 };
 
 // Counters are spread over kStatSlots copies (one 256-byte line each, picked by scene index): thousands of
