@@ -31,10 +31,13 @@ namespace mmw {
 #endif
 
 constexpr int kGateStride = 44;   // per track: Ci[36] | log|det| | hx[6] (k_predict's gate record)
+// Columns of the point tile are NP + 2 doubles apart: with a power-of-two stride the same row of all six
+// columns -- what the lanes of one track read together -- would sit in one LDS bank (6-way conflicts).
+constexpr int kTilePad = 2;
 constexpr int kPwStackDepth = 4;  // numpy pairwise-sum recursion depth for n <= 2048
 
 struct TrackLds {
-    double *p6;      // [6][NP] point columns x,y,z,vx,vy,vz
+    double *p6;      // [6][NP + kTilePad] point columns x,y,z,vx,vy,vz, class-sorted (see the split)
     double *work;    // union: gate[kGateChunk][kGateStride] | point tile + pairwise stack
     double *cen;     // [t_cap][6] centroid of this frame's cloud per track
     int *perm;       // [NP] point indices grouped by class (0 = unassigned, j+1 = track j), input order kept
@@ -61,7 +64,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     // One region, three lives: (1) gate matrices + per-wave scratch while tracks are predicted and
     // points gated (points sit in registers then); (2) the SoA point tile + the pairwise-sum stack
     // while cluster statistics are formed; (3) per-wave scratch again for the Kalman update.
-    const int work_a = kGateChunk * kGateStride, work_b = 6 * NP + pw_depth(NP) * kThreads;
+    const int work_a = kGateChunk * kGateStride, work_b = 6 * (NP + kTilePad) + pw_depth(NP) * kThreads;
     size_t off = 0;
 #define CARVE(field, type, count)                            \
     if constexpr (WRITE) L->field = (type *)(base + off);    \
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     // work of all workgroups of a CU on one SIMD while the other three idle; rotating by scene spreads it.
     const int role = (wave + s) & (kWaves - 1), rtid = role * 64 + lane;
     const int NP = cfg.max_pts, CLS = cfg.t_cap + 1;
+    const int NPs = NP + kTilePad;  // column stride of the point tile
     const int n = n_pts[s];
     SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
@@ -264,18 +268,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         __syncthreads();
         STAMP(2);  // gating
     }
-    // ---- park the points in the LDS tile (SoA, 6 columns) for the cluster statistics; the gate /
-    //      scratch area it overlays is dead until the update phase ----
-#pragma unroll
-    for (int q = 0; q < PPT; q++) {
-        const int i = q * kThreads + tid;
-        if (i < n) {
-            L.p6[0 * NP + i] = pr[q][0].x; L.p6[1 * NP + i] = pr[q][0].y;
-            L.p6[2 * NP + i] = pr[q][1].x; L.p6[3 * NP + i] = pr[q][1].y;
-            L.p6[4 * NP + i] = pr[q][2].x; L.p6[5 * NP + i] = pr[q][2].y;
-        }
-    }
-
     // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
     {
         const int NB = (n + 63) / 64;
@@ -332,8 +324,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
             if (i < n) {
+                // park the point in the LDS tile (SoA, 6 columns) at its CLASS-SORTED position: every cloud is
+                // then a contiguous run in input order, and the per-cluster sums below read it with
+                // consecutive addresses instead of chasing perm[].  (The gate area the tile overlays is dead.)
                 const int cls = bestj[q] + 1, blk = q * kWaves + wave;
-                L.perm[L.cls_off[cls] + L.cnt[blk * CLS + cls] + __popcll(mybal[q] & lanemask_lt())] = i;
+                const int pos = L.cls_off[cls] + L.cnt[blk * CLS + cls] + __popcll(mybal[q] & lanemask_lt());
+                L.perm[pos] = i;
+                L.p6[0 * NPs + pos] = pr[q][0].x; L.p6[1 * NPs + pos] = pr[q][0].y;
+                L.p6[2 * NPs + pos] = pr[q][1].x; L.p6[3 * NPs + pos] = pr[q][1].y;
+                L.p6[4 * NPs + pos] = pr[q][2].x; L.p6[5 * NPs + pos] = pr[q][2].y;
             }
         }
         __syncthreads();
@@ -353,19 +352,24 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
             continue;
         }
-        const double *col = L.p6 + m * NP;
-        const int *pm = L.perm + off;
-        double sum = 0.0, mn = col[pm[0]], mx = mn;
+        const double *col = L.p6 + m * NPs + off;
+        const double old = rec->spread[m];                      // issued now, consumed after the chain
+        const double ne_old = (m == 0) ? rec->n_est : 0.0;
+        double sum = 0.0, mn = col[0], mx = mn;
         int r = 0;
-        for (; r + 4 <= nj; r += 4) {  // np.mean(axis=0): sequential in row order; loads batched
-            const int i0 = pm[r], i1 = pm[r + 1], i2 = pm[r + 2], i3 = pm[r + 3];
-            const double v0 = col[i0], v1 = col[i1], v2 = col[i2], v3 = col[i3];
-            sum += v0; sum += v1; sum += v2; sum += v3;
-            mn = v0 < mn ? v0 : mn; mn = v1 < mn ? v1 : mn; mn = v2 < mn ? v2 : mn; mn = v3 < mn ? v3 : mn;
-            mx = v0 > mx ? v0 : mx; mx = v1 > mx ? v1 : mx; mx = v2 > mx ? v2 : mx; mx = v3 > mx ? v3 : mx;
+        for (; r + 8 <= nj; r += 8) {  // np.mean(axis=0): sequential in row order; eight loads in flight
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = col[r + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                sum += v[u];
+                mn = v[u] < mn ? v[u] : mn;
+                mx = v[u] > mx ? v[u] : mx;
+            }
         }
         for (; r < nj; r++) {
-            const double v = col[pm[r]];
+            const double v = col[r];
             sum += v;
             mn = v < mn ? v : mn;
             mx = v > mx ? v : mx;
@@ -381,13 +385,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         if (nj != 1) spread = spread * (double)(nj + 1) / (double)(nj - 1);
         spread = spread < lim2 ? spread : lim2;
         spread = spread > lim ? spread : lim;
-        const double old = rec->spread[m];
         rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
         if (m == 0) {
             rec->lifetime = 0.0;
             rec->point_num = nj;
             // _estimate_point_num Tracking.py:232-244
-            double ne = rec->n_est;
+            double ne = ne_old;
             if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
             else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
             rec->n_est = ne;
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     }
     // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track
     {
-        double *stk = L.work + 6 * NP + tid;  // behind the point tile
+        double *stk = L.work + 6 * NPs + tid;  // behind the point tile
         for (int task = tid; task < T * 21; task += kThreads) {
             const int j = task / 21;
             int e = task % 21, a = 0;
@@ -456,9 +459,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             if (nj == 0) continue;
             TrackRec *rec = trk + L.slot[j];
             const double ca = L.cen[j * 6 + a], cb = L.cen[j * 6 + b];
-            const double *pa = L.p6 + a * NP, *pb = L.p6 + b * NP;
-            const int *pm = L.perm + off;
-            auto elem = [&](int r) { int i = pm[r]; return (pa[i] - ca) * (pb[i] - cb); };
+            const double *pa = L.p6 + a * NPs + off, *pb = L.p6 + b * NPs + off;
+            auto elem = [&](int r) { return (pa[r] - ca) * (pb[r] - cb); };
             const double D = np_pairwise_sum(elem, nj, stk, kThreads) / (double)nj;
             const double ne = rec->n_est;
             if (ne == 0.0) { err |= ERR_DIVZERO; continue; }
