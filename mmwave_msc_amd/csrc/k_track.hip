@@ -40,12 +40,11 @@ struct TrackLds {
     double *p6;      // [6][NP + kTilePad] point columns x,y,z,vx,vy,vz, class-sorted (see the split)
     double *work;    // union: gate[kGateChunk][kGateStride] | point tile + pairwise stack
     double *cen;     // [t_cap][6] centroid of this frame's cloud per track
-    int *perm;       // [NP] point indices grouped by class (0 = unassigned, j+1 = track j), input order kept
     int *cnt;        // [NB][CLS]
     int *cls_n;      // [CLS]
     int *cls_off;    // [CLS+1]
-    int *seg_off;    // [CLS+1] row-copy segments (16-byte units)
-    long long *seg_dst; // [CLS] destination offsets (doubles) of the segments
+    long long *seg_dst; // [CLS] where this frame's rows go: track j's ring slot (j < T), the global ring slot (j == T); in doubles
+    double *wmm;     // [kWaves][24] per-wave min/max hand-over of the cluster statistics
     int *slot;       // [t_cap]
     int *slot2;      // [t_cap]
     int *misc;       // [16]
@@ -72,12 +71,11 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     if constexpr (WRITE) L->p6 = (double *)(base + off);
     CARVE(work, double, work_a > work_b ? work_a : work_b)
     CARVE(cen, double, c.t_cap * 6)
-    CARVE(perm, int, NP)
     CARVE(cnt, int, NB *CLS)
     CARVE(cls_n, int, CLS)
     CARVE(cls_off, int, CLS + 1)
-    CARVE(seg_off, int, CLS + 2)
     CARVE(seg_dst, long long, CLS + 1)
+    CARVE(wmm, double, kWaves * 24)
     CARVE(slot, int, c.t_cap)
     CARVE(slot2, int, c.t_cap)
     CARVE(misc, int, 16)
@@ -175,10 +173,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    // The single-wave jobs below (6x6 systems, per-track chains, track maintenance) go to wave `role == 0`.
-    // Wave w of every resident workgroup tends to sit on SIMD w, so a fixed choice would queue the serial
-    // work of all workgroups of a CU on one SIMD while the other three idle; rotating by scene spreads it.
-    const int role = (wave + s) & (kWaves - 1), rtid = role * 64 + lane;
+    // The single-wave job below (track maintenance) goes to wave `role == 0`, rotated by scene so that the
+    // resident workgroups of a CU do not all queue it on the same SIMD.
+    const int role = (wave + s) & (kWaves - 1);
     const int NP = cfg.max_pts, CLS = cfg.t_cap + 1;
     const int NPs = NP + kTilePad;  // column stride of the point tile
     const int n = n_pts[s];
@@ -207,14 +204,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     // ---- this thread's points (rows tid, tid+256, ...): columns 0..5 straight into registers with
     //      16-byte loads; issued first so HBM latency hides under the track prediction below.
     //      They are gated from registers and only then parked in the LDS tile for the statistics ----
-    double2 pr[PPT][3];
+    double2 pr[PPT][4];
     {
         const double2 *src2 = reinterpret_cast<const double2 *>(pts);
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
 #pragma unroll
-            for (int u = 0; u < 3; u++) pr[q][u] = (i < n) ? src2[i * 4 + u] : double2{0.0, 0.0};
+            for (int u = 0; u < 4; u++) pr[q][u] = (i < n) ? src2[i * 4 + u] : double2{0.0, 0.0};
         }
     }
     for (int j = tid; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
@@ -298,14 +295,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             int run = 0;
             for (int c = 0; c <= T; c++) { L.cls_off[c] = run; run += L.cls_n[c]; }
             L.cls_off[T + 1] = run;
-            // row-copy segments in 16-byte units: segment j < T = rows kept in track j's ring,
-            // segment T = unassigned rows appended to the global ring
-            int r2 = 0;
-            for (int j = 0; j < T; j++) { L.seg_off[j] = r2; r2 += min(L.cls_n[j + 1], cfg.ring_rows) * 4; }
-            L.seg_off[T] = r2;
-            L.seg_off[T + 1] = r2 + L.cls_n[0] * 4;
         }
-        // where each segment goes, from the ring state BEFORE this frame's push (the bookkeeping itself
+        // where this frame's rows go, from the ring state BEFORE this frame's push (the bookkeeping itself
         // happens after the copies): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
         for (int j = tid; j <= T; j += kThreads) {
             if (j < T) {
@@ -328,103 +319,101 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                 // then a contiguous run in input order, and the per-cluster sums below read it with
                 // consecutive addresses instead of chasing perm[].  (The gate area the tile overlays is dead.)
                 const int cls = bestj[q] + 1, blk = q * kWaves + wave;
-                const int pos = L.cls_off[cls] + L.cnt[blk * CLS + cls] + __popcll(mybal[q] & lanemask_lt());
-                L.perm[pos] = i;
+                const int local = L.cnt[blk * CLS + cls] + __popcll(mybal[q] & lanemask_lt());  // rank inside its cloud
+                const int pos = L.cls_off[cls] + local;
                 L.p6[0 * NPs + pos] = pr[q][0].x; L.p6[1 * NPs + pos] = pr[q][0].y;
                 L.p6[2 * NPs + pos] = pr[q][1].x; L.p6[3 * NPs + pos] = pr[q][1].y;
                 L.p6[4 * NPs + pos] = pr[q][2].x; L.p6[5 * NPs + pos] = pr[q][2].y;
+                // ... and its full row (8 columns) goes to the ring it belongs to: track j keeps the first
+                // ring_rows rows of its cloud (Tracking.py:341 via BatchedData), the global ring all unassigned rows
+                if (cls == 0 || local < cfg.ring_rows) {
+                    double *dst = (cls == 0 ? st.g_ring + L.seg_dst[T] : st.trk_ring + L.seg_dst[cls - 1]) + (size_t)local * 8;
+                    double2 *d2 = reinterpret_cast<double2 *>(dst);
+                    d2[0] = pr[q][0]; d2[1] = pr[q][1]; d2[2] = pr[q][2]; d2[3] = pr[q][3];
+                }
             }
         }
         __syncthreads();
     }
     STAMP(3);  // class split
 
-    // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, ring bookkeeping,
-    //      N_est, spread_est; one lane per (track, dimension) ----
-    // When the statistics fit one wave (T <= 10) wave 0 walks the per-(track,column) chains while
-    // waves 1-3 move this frame's rows into the rings: two latency-bound jobs side by side.
-    const bool overlap = T * 6 <= 64;
-    for (int task = rtid; task < T * 6 && (!overlap || role == 0); task += kThreads) {
-        const int j = task / 6, m = task % 6;
-        TrackRec *rec = trk + L.slot[j];
-        const int nj = L.cls_n[j + 1], off = L.cls_off[j + 1];
-        if (nj == 0) {
-            if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
-            continue;
-        }
+    // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, N_est, spread_est.
+    //      The column sums are sequential in row order (np.mean(axis=0)), i.e. serial chains, so the chain
+    //      carries nothing but the add: every wave takes two tracks per round, lanes 0..11 walk the twelve
+    //      (track, column) sums while lanes 16..63 form min/max over four contiguous quarters of each run
+    //      (combined in order with the sequential rule "a later value wins only if strictly smaller/larger",
+    //      which is what a single left-to-right pass yields) ----
+    for (int jb = 0; jb < T; jb += 2 * kWaves) {
+        const bool grpA = lane < 12, grpB = lane >= 16;
+        const int pi = grpA ? lane : (grpB ? (lane - 16) >> 2 : 0), slice = (lane - 16) & 3;
+        const int jj = pi / 6, m = pi - jj * 6, j = jb + wave * 2 + jj;
+        const bool valid = j < T && (grpA || grpB);
+        const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
+        TrackRec *rec = trk + L.slot[valid ? j : 0];
         const double *col = L.p6 + m * NPs + off;
-        const double old = rec->spread[m];                      // issued now, consumed after the chain
-        const double ne_old = (m == 0) ? rec->n_est : 0.0;
-        double sum = 0.0, mn = col[0], mx = mn;
-        int r = 0;
-        for (; r + 8 <= nj; r += 8) {  // np.mean(axis=0): sequential in row order; eight loads in flight
-            double v[8];
+        double old = 0.0, ne_old = 0.0, sum = 0.0;
+        if (grpA && nj > 0) {
+            old = rec->spread[m];  // issued now, consumed after the chain
+            if (m == 0) ne_old = rec->n_est;
+            int r = 0;
+            for (; r + 8 <= nj; r += 8) {  // eight loads in flight, one dependent add each
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = col[r + u];
+                for (int u = 0; u < 8; u++) v[u] = col[r + u];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                sum += v[u];
-                mn = v[u] < mn ? v[u] : mn;
-                mx = v[u] > mx ? v[u] : mx;
+                for (int u = 0; u < 8; u++) sum += v[u];
+            }
+            for (; r < nj; r++) sum += col[r];
+        }
+        double mn = __longlong_as_double(0x7ff0000000000000LL), mx = -mn;  // empty quarter: never wins
+        if (grpB && nj > 0) {
+            const int r0 = (nj * slice) >> 2, r1 = (nj * (slice + 1)) >> 2;
+            if (r0 < r1) { mn = col[r0]; mx = mn; }
+            for (int r = r0 + 1; r < r1; r++) {
+                const double v = col[r];
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
             }
         }
-        for (; r < nj; r++) {
-            const double v = col[r];
-            sum += v;
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
-        }
-        const double cen = sum / (double)nj;
-        L.cen[j * 6 + m] = cen;
-        rec->centroid[m] = cen;
-        rec->minv[m] = mn;
-        rec->maxv[m] = mx;
-        // _estimate_measurement_spread Tracking.py:246-268
-        double spread = mx - mn;
-        const double lim = cfg.kf_spread_lim[m], lim2 = 2 * lim;
-        if (nj != 1) spread = spread * (double)(nj + 1) / (double)(nj - 1);
-        spread = spread < lim2 ? spread : lim2;
-        spread = spread > lim ? spread : lim;
-        rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
-        if (m == 0) {
-            rec->lifetime = 0.0;
-            rec->point_num = nj;
-            // _estimate_point_num Tracking.py:232-244
-            double ne = ne_old;
-            if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
-            else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
-            rec->n_est = ne;
-        }
-    }
-    // row copies (all 8 columns, 16-byte pieces): eight loads in flight per thread, then eight stores
-    if (!overlap || role > 0) {
-        const int ct = overlap ? rtid - 64 : rtid, nthr = overlap ? kThreads - 64 : kThreads;
-        const int total2 = L.seg_off[T + 1];
-        const double2 *src2 = reinterpret_cast<const double2 *>(pts);
-        for (int base = 0; base < total2; base += nthr * 8) {
-            double2 v[8];
-            long long dst[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int item = base + u * nthr + ct;
-                dst[u] = -1;
-                v[u] = double2{0.0, 0.0};
-                if (item < total2) {
-                    int seg = 0;
-                    while (item >= L.seg_off[seg + 1]) seg++;
-                    const int local = item - L.seg_off[seg];
-                    const int row = L.perm[(seg < T ? L.cls_off[seg + 1] : 0) + (local >> 2)];
-                    v[u] = src2[row * 4 + (local & 3)];
-                    dst[u] = L.seg_dst[seg] + (long long)local * 2;
+        for (int d = 1; d <= 2; d <<= 1) {  // quarters (0,1),(2,3) then halves: the partner holds the LATER rows
+            const double tn = __shfl_down(mn, d), tx = __shfl_down(mx, d);
+            mn = tn < mn ? tn : mn;
+            mx = tx > mx ? tx : mx;
+        }
+        double *wmm = L.wmm + wave * 24;
+        if (grpB && slice == 0) { wmm[pi * 2] = mn; wmm[pi * 2 + 1] = mx; }
+        wave_sync();
+        if (grpA && valid) {
+            if (nj == 0) {
+                if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
+            } else {
+                mn = wmm[pi * 2];
+                mx = wmm[pi * 2 + 1];
+                const double cen = sum / (double)nj;
+                L.cen[j * 6 + m] = cen;
+                rec->centroid[m] = cen;
+                rec->minv[m] = mn;
+                rec->maxv[m] = mx;
+                // _estimate_measurement_spread Tracking.py:246-268
+                double spread = mx - mn;
+                const double lim = cfg.kf_spread_lim[m], lim2 = 2 * lim;
+                if (nj != 1) spread = spread * (double)(nj + 1) / (double)(nj - 1);
+                spread = spread < lim2 ? spread : lim2;
+                spread = spread > lim ? spread : lim;
+                rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
+                if (m == 0) {
+                    rec->lifetime = 0.0;
+                    rec->point_num = nj;
+                    // _estimate_point_num Tracking.py:232-244
+                    double ne = ne_old;
+                    if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
+                    else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
+                    rec->n_est = ne;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (dst[u] >= 0) {
-                    double *base_ptr = (base + u * nthr + ct) >= L.seg_off[T] ? st.g_ring : st.trk_ring;
-                    *reinterpret_cast<double2 *>(base_ptr + dst[u]) = v[u];
-                }
         }
+        wave_sync();
     }
     __syncthreads();
     STAMP(4);  // centroid/min/max/spread
