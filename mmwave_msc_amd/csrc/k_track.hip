@@ -10,6 +10,8 @@
 // workgroup work on four tracks independently and meet at workgroup barriers only around the
 // phases that touch all points.  All arithmetic fp64 with a fixed operation order (see
 // mmw_math.hpp) -- the order the parity oracle restates from the reference.
+#include <cstdlib>
+
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 
@@ -26,15 +28,27 @@ namespace mmw {
             t_prev = t_now;                                                                   \
         }                                                                                     \
     } while (0)
+// PROBE(id): raw clock of lane 0 of every wave of ONE workgroup (scene kProbeScene), for timelines
+constexpr int kProbeScene = 1234;
+#define PROBE(id)                                                                             \
+    do {                                                                                      \
+        if (blockIdx.x == kProbeScene && (threadIdx.x & 63) == 0)                             \
+            st.stats[kStatSlots * kStatWords + (threadIdx.x >> 6) * 32 + (id)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define STAMP(k)
+#define PROBE(id)
 #endif
 
 constexpr int kGateStride = 44;   // per track: Ci[36] | log|det| | hx[6] (k_predict's gate record)
 // Columns of the point tile are NP + 2 doubles apart: with a power-of-two stride the same row of all six
 // columns -- what the lanes of one track read together -- would sit in one LDS bank (6-way conflicts).
 constexpr int kTilePad = 2;
-constexpr int kPwStackDepth = 4;  // numpy pairwise-sum recursion depth for n <= 2048
+
+// numpy's pairwise split point and the bound on leaves per frame (see pw_* below): a leaf that comes from a
+// split holds at least 57 rows, so a frame has at most max_pts/57 of them.
+__host__ __device__ inline int pw_split(int n) { const int h = n / 2; return h - h % 8; }
+__host__ __device__ inline int pw_max_leaves(int np) { return np > 128 ? np / 57 + 1 : 0; }
 
 struct TrackLds {
     double *p6;      // [6][NP + kTilePad] point columns x,y,z,vx,vy,vz, class-sorted (see the split)
@@ -45,14 +59,13 @@ struct TrackLds {
     int *cls_off;    // [CLS+1]
     long long *seg_dst; // [CLS] where this frame's rows go: track j's ring slot (j < T), the global ring slot (j == T); in doubles
     double *wmm;     // [kWaves][24] per-wave min/max hand-over of the cluster statistics
+    int *ml;         // multi-leaf clouds (n > 128): [0] leaves, [1] clouds, then per leaf (track, off, len), per cloud (track, first leaf)
     int *slot;       // [t_cap]
     int *slot2;      // [t_cap]
     int *misc;       // [16]
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
-// levels of numpy's pairwise split above the 128-element leaves, i.e. LDS stack entries per thread
-__host__ __device__ inline int pw_depth(int n) { int d = 0; while (n > 128) { n = n - ((n / 2) - (n / 2) % 8); d++; } return d < kPwStackDepth ? d : kPwStackDepth; }
 
 // WRITE=false only sizes the layout.  (No `if (L)` null test: in the private address space a
 // null check on an alloca cannot be folded and would pin the struct in scratch memory.)
@@ -63,7 +76,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     // One region, three lives: (1) gate matrices + per-wave scratch while tracks are predicted and
     // points gated (points sit in registers then); (2) the SoA point tile + the pairwise-sum stack
     // while cluster statistics are formed; (3) per-wave scratch again for the Kalman update.
-    const int work_a = kGateChunk * kGateStride, work_b = 6 * (NP + kTilePad) + pw_depth(NP) * kThreads;
+    const int work_a = kGateChunk * kGateStride, work_b = 6 * (NP + kTilePad) + pw_max_leaves(NP) * 21;
     size_t off = 0;
 #define CARVE(field, type, count)                            \
     if constexpr (WRITE) L->field = (type *)(base + off);    \
@@ -76,6 +89,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     CARVE(cls_off, int, CLS + 1)
     CARVE(seg_dst, long long, CLS + 1)
     CARVE(wmm, double, kWaves * 24)
+    CARVE(ml, int, 2 + 5 * (pw_max_leaves(NP) + 1))
     CARVE(slot, int, c.t_cap)
     CARVE(slot2, int, c.t_cap)
     CARVE(misc, int, 16)
@@ -83,80 +97,77 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     return off;
 }
 
-size_t track_lds_bytes(const DevCfg &c) { return track_lds_layout<false>(c, nullptr, nullptr); }
+size_t track_lds_bytes(const DevCfg &c)
+{
+    size_t b = track_lds_layout<false>(c, nullptr, nullptr);
+#ifdef MMW_STAMPS
+    // diagnostic build only: MMW_DIAG_LDS_EXTRA=<bytes> inflates the allocation to lower the number of
+    // resident workgroups per CU (separates latency from contention in the phase stamps)
+    if (const char *x = getenv("MMW_DIAG_LDS_EXTRA")) b += (size_t)atoi(x);
+#endif
+    return b;
+}
 
-// numpy pairwise_sum_DOUBLE over elem(r), r in [0, n): the summation order of the
-// 1-D np.mean in ClusterTrack._get_D (Tracking.py:286).
-template <typename F>
-__device__ __forceinline__ double np_pairwise_leaf(F elem, int off, int n)
+// numpy pairwise_sum_DOUBLE (the summation order of the 1-D np.mean in ClusterTrack._get_D, Tracking.py:286):
+//   n < 8      : one by one
+//   n <= 128   : eight interleaved accumulators r[k] += x[i+k], ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+//                n%8 leftovers one by one                                   -- a LEAF
+//   otherwise  : n2 = n/2 - (n/2)%8 ;  pairwise(x, n2) + pairwise(x+n2, n-n2)
+// The leaves of one sum are independent, so they are spread over lanes (pw_leaf) and only the few adds of
+// the recursion (pw_combine) stay serial.  D = recursion depth budget: 4 levels cover n <= 2048.
+
+template <int D, typename F>
+__device__ __forceinline__ void pw_for_each_leaf(int off, int n, F f)
+{
+    if constexpr (D == 0) f(off, n);
+    else {
+        if (n <= 128) f(off, n);
+        else { const int n2 = pw_split(n); pw_for_each_leaf<D - 1>(off, n2, f); pw_for_each_leaf<D - 1>(off + n2, n - n2, f); }
+    }
+}
+
+// sums of the leaves, in leaf order, back into the value numpy returns
+template <int D>
+__device__ __forceinline__ double pw_combine(int n, const double *leafsum, int stride, int &idx)
+{
+    if constexpr (D == 0) { const double v = leafsum[idx * stride]; idx++; return v; }
+    else {
+        if (n <= 128) { const double v = leafsum[idx * stride]; idx++; return v; }
+        const int n2 = pw_split(n);
+        const double l = pw_combine<D - 1>(n2, leafsum, stride, idx);
+        const double r = pw_combine<D - 1>(n - n2, leafsum, stride, idx);
+        return l + r;
+    }
+}
+constexpr int kPwDepth = 4;
+
+// one leaf (n <= 128) of sum_r (pa[r]-ca)*(pb[r]-cb)
+__device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, double ca, double cb, int n)
 {
     if (n < 8) {
         double res = 0.0;
-        for (int i = 0; i < n; i++) res += elem(off + i);
+        for (int i = 0; i < n; i++) res += (pa[i] - ca) * (pb[i] - cb);
         return res;
     }
-    double r0 = elem(off), r1 = elem(off + 1), r2 = elem(off + 2), r3 = elem(off + 3);
-    double r4 = elem(off + 4), r5 = elem(off + 5), r6 = elem(off + 6), r7 = elem(off + 7);
-    int i, lim = n - (n % 8);
-    for (i = 8; i < lim; i += 8) {
-        r0 += elem(off + i);
-        r1 += elem(off + i + 1);
-        r2 += elem(off + i + 2);
-        r3 += elem(off + i + 3);
-        r4 += elem(off + i + 4);
-        r5 += elem(off + i + 5);
-        r6 += elem(off + i + 6);
-        r7 += elem(off + i + 7);
+    const int lim = n - (n & 7);
+    double r[8], xa[8], xb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { xa[u] = pa[u]; xb[u] = pb[u]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) r[u] = (xa[u] - ca) * (xb[u] - cb);
+    for (int i = 8; i < lim; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { xa[u] = pa[i + u]; xb[u] = pb[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) r[u] += (xa[u] - ca) * (xb[u] - cb);
     }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += elem(off + i);
+    const int left = n - lim;  // the n%8 leftovers, loaded together, added one by one
+#pragma unroll
+    for (int u = 0; u < 7; u++) { xa[u] = (u < left) ? pa[lim + u] : 0.0; xb[u] = (u < left) ? pb[lim + u] : 0.0; }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int u = 0; u < 7; u++) if (u < left) res += (xa[u] - ca) * (xb[u] - cb);
     return res;
-}
-
-// `stk` is a per-thread LDS stack (stride = blockDim) for the recursive halves (n > 128 only).
-template <typename F>
-__device__ __forceinline__ double np_pairwise_sum(F elem, int n, double *stk, int stride)
-{
-    if (n <= 128) return np_pairwise_leaf(elem, 0, n);
-    // Iterative post-order walk of numpy's split tree; frames in small register arrays
-    // addressed through selects (static indices only).
-    int foff[kPwStackDepth + 1], flen[kPwStackDepth + 1], fstate[kPwStackDepth + 1];
-    int d = 0;
-    foff[0] = 0; flen[0] = n; fstate[0] = 0;
-    double ret = 0.0;
-    while (d >= 0) {
-        int off = 0, len = 0, stt = 0;
-#pragma unroll
-        for (int q = 0; q <= kPwStackDepth; q++)
-            if (q == d) { off = foff[q]; len = flen[q]; stt = fstate[q]; }
-        if (len <= 128) {
-            ret = np_pairwise_leaf(elem, off, len);
-            d--;
-            continue;
-        }
-        int n2 = len / 2;
-        n2 -= n2 % 8;
-        if (stt == 0) {  // descend left
-#pragma unroll
-            for (int q = 0; q <= kPwStackDepth; q++) {
-                if (q == d) fstate[q] = 1;
-                if (q == d + 1) { foff[q] = off; flen[q] = n2; fstate[q] = 0; }
-            }
-            d++;
-        } else if (stt == 1) {  // left done: stash, descend right
-            stk[d * stride] = ret;
-#pragma unroll
-            for (int q = 0; q <= kPwStackDepth; q++) {
-                if (q == d) fstate[q] = 2;
-                if (q == d + 1) { foff[q] = off + n2; flen[q] = len - n2; fstate[q] = 0; }
-            }
-            d++;
-        } else {  // both done
-            ret = stk[d * stride] + ret;
-            d--;
-        }
-    }
-    return ret;
 }
 
 // PPT = points per thread = ceil(max_pts / 256): a template so that per-point registers are not
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         }
     }
     for (int j = tid; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
+    if (tid == 0) { L.ml[0] = 0; L.ml[1] = 0; }
     __syncthreads();
     STAMP(0);  // issue point loads
 
@@ -336,6 +348,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         __syncthreads();
     }
     STAMP(3);  // class split
+    PROBE(3);
 
     // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, N_est, spread_est.
     //      The column sums are sequential in row order (np.mean(axis=0)), i.e. serial chains, so the chain
@@ -352,29 +365,66 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         TrackRec *rec = trk + L.slot[valid ? j : 0];
         const double *col = L.p6 + m * NPs + off;
         double old = 0.0, ne_old = 0.0, sum = 0.0;
+        PROBE(20);
         if (grpA && nj > 0) {
             old = rec->spread[m];  // issued now, consumed after the chain
             if (m == 0) ne_old = rec->n_est;
+            // LDS latency is what this chain waits for, not the adds: sixteen loads in flight, the next
+            // batch requested before the current one is summed
             int r = 0;
-            for (; r + 8 <= nj; r += 8) {  // eight loads in flight, one dependent add each
-                double v[8];
+            double v[16], w[16];
+            if (nj >= 16) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = col[u];
+                for (r = 16; r + 16 <= nj; r += 16) {
+#pragma unroll
+                    for (int u = 0; u < 16; u++) w[u] = col[r + u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) sum += v[u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) v[u] = w[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) sum += v[u];
+            }
+            if (r + 8 <= nj) {
 #pragma unroll
                 for (int u = 0; u < 8; u++) v[u] = col[r + u];
 #pragma unroll
                 for (int u = 0; u < 8; u++) sum += v[u];
+                r += 8;
             }
-            for (; r < nj; r++) sum += col[r];
+            {   // up to seven left
+                const int left = nj - r;
+#pragma unroll
+                for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 7; u++) if (u < left) sum += v[u];
+            }
         }
+        PROBE(21);
         double mn = __longlong_as_double(0x7ff0000000000000LL), mx = -mn;  // empty quarter: never wins
         if (grpB && nj > 0) {
             const int r0 = (nj * slice) >> 2, r1 = (nj * (slice + 1)) >> 2;
             if (r0 < r1) { mn = col[r0]; mx = mn; }
-            for (int r = r0 + 1; r < r1; r++) {
-                const double v = col[r];
-                mn = v < mn ? v : mn;
-                mx = v > mx ? v : mx;
+            int r = r0 + 1;
+            for (; r + 8 <= r1; r += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = col[r + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+            }
+            {
+                const int left = r1 - r;
+                double v[7];
+#pragma unroll
+                for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : mn;  // mn itself never wins a strict compare
+#pragma unroll
+                for (int u = 0; u < 7; u++) if (u < left) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
             }
         }
+        PROBE(22);
 #pragma unroll
         for (int d = 1; d <= 2; d <<= 1) {  // quarters (0,1),(2,3) then halves: the partner holds the LATER rows
             const double tn = __shfl_down(mn, d), tx = __shfl_down(mx, d);
@@ -384,6 +434,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         double *wmm = L.wmm + wave * 24;
         if (grpB && slice == 0) { wmm[pi * 2] = mn; wmm[pi * 2 + 1] = mx; }
         wave_sync();
+        PROBE(23);
         if (grpA && valid) {
             if (nj == 0) {
                 if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
@@ -403,6 +454,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                 spread = spread > lim ? spread : lim;
                 rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
                 if (m == 0) {
+                    if (nj > 128) {  // leaves of this cloud's pairwise sums, for the dispersion phase below
+                        int cnt = 0;
+                        pw_for_each_leaf<kPwDepth>(0, nj, [&](int, int) { cnt++; });
+                        const int first = atomicAdd(&L.ml[0], cnt), c = atomicAdd(&L.ml[1], 1);
+                        int *lf = L.ml + 2 + first * 3, *cl = L.ml + 2 + 3 * pw_max_leaves(NP);
+                        cl[c * 2] = j; cl[c * 2 + 1] = first;
+                        int k = 0;
+                        pw_for_each_leaf<kPwDepth>(0, nj, [&](int o, int len) { lf[k * 3] = j; lf[k * 3 + 1] = o; lf[k * 3 + 2] = len; k++; });
+                    }
                     rec->lifetime = 0.0;
                     rec->point_num = nj;
                     // _estimate_point_num Tracking.py:232-244
@@ -415,8 +475,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         }
         wave_sync();
     }
+    PROBE(24);
     __syncthreads();
     STAMP(4);  // centroid/min/max/spread
+    PROBE(4);
     // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
     for (int j = tid; j < T; j += kThreads) {
         const int nj = L.cls_n[j + 1];
@@ -436,26 +498,51 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             rec->ring_len = len + 1;
         }
     }
-    // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track
+    // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track, each the
+    // 1-D np.mean of n products in numpy's pairwise order (pw_* above).  Work items: (track, entry) for
+    // clouds of one leaf (n <= 128), (leaf, entry) for the leaves of larger clouds, whose sums meet in LDS
+    // and are combined by one lane per (track, entry) after a barrier.
     {
-        double *stk = L.work + 6 * NPs + tid;  // behind the point tile
-        for (int task = tid; task < T * 21; task += kThreads) {
-            const int j = task / 21;
-            int e = task % 21, a = 0;
-            while (e >= 6 - a) { e -= 6 - a; a++; }
-            const int b = a + e;
-            const int nj = L.cls_n[j + 1], off = L.cls_off[j + 1];
-            if (nj == 0) continue;
-            TrackRec *rec = trk + L.slot[j];
-            const double ca = L.cen[j * 6 + a], cb = L.cen[j * 6 + b];
-            const double *pa = L.p6 + a * NPs + off, *pb = L.p6 + b * NPs + off;
-            auto elem = [&](int r) { return (pa[r] - ca) * (pb[r] - cb); };
-            const double D = np_pairwise_sum(elem, nj, stk, kThreads) / (double)nj;
-            const double ne = rec->n_est;
-            if (ne == 0.0) { err |= ERR_DIVZERO; continue; }
+        double *leafsum = L.work + 6 * NPs;  // [leaf][21]
+        const int nleaf = L.ml[0], ncloud = L.ml[1];
+        const int *lf = L.ml + 2, *cl = L.ml + 2 + 3 * pw_max_leaves(NP);
+        auto entry = [](int e, int &a, int &b) { a = 0; while (e >= 6 - a) { e -= 6 - a; a++; } b = a + e; };
+        auto blend = [&](TrackRec *rec, int a, int b, double res, int nj, double g_ab, double g_ba, double ne) {
+            const double D = res / (double)nj;
+            if (ne == 0.0) { err |= ERR_DIVZERO; return; }
             const double al = (double)nj / ne;
-            rec->gd[a * 6 + b] = (1 - al) * rec->gd[a * 6 + b] + al * D;
-            if (a != b) rec->gd[b * 6 + a] = (1 - al) * rec->gd[b * 6 + a] + al * D;
+            rec->gd[a * 6 + b] = (1 - al) * g_ab + al * D;
+            if (a != b) rec->gd[b * 6 + a] = (1 - al) * g_ba + al * D;
+        };
+        for (int it = tid; it < (T + nleaf) * 21; it += kThreads) {
+            const int u = it / 21;
+            int a, b;
+            entry(it - u * 21, a, b);
+            const bool direct = u < T;
+            const int j = direct ? u : lf[(u - T) * 3];
+            const int nj = L.cls_n[j + 1];
+            if (direct && (nj == 0 || nj > 128)) continue;
+            const int off = L.cls_off[j + 1] + (direct ? 0 : lf[(u - T) * 3 + 1]), len = direct ? nj : lf[(u - T) * 3 + 2];
+            TrackRec *rec = trk + L.slot[j];
+            double g_ab = 0.0, g_ba = 0.0, ne = 1.0;
+            if (direct) { g_ab = rec->gd[a * 6 + b]; g_ba = rec->gd[b * 6 + a]; ne = rec->n_est; }  // in flight during the sum
+            const double res = pw_leaf(L.p6 + a * NPs + off, L.p6 + b * NPs + off, L.cen[j * 6 + a], L.cen[j * 6 + b], len);
+            if (direct) blend(rec, a, b, res, nj, g_ab, g_ba, ne);
+            else leafsum[(u - T) * 21 + (it - u * 21)] = res;
+        }
+        if (ncloud > 0) {  // uniform
+            __syncthreads();
+            for (int it = tid; it < ncloud * 21; it += kThreads) {
+                const int c = it / 21, e = it - c * 21;
+                int a, b;
+                entry(e, a, b);
+                const int j = cl[c * 2], nj = L.cls_n[j + 1];
+                TrackRec *rec = trk + L.slot[j];
+                const double g_ab = rec->gd[a * 6 + b], g_ba = rec->gd[b * 6 + a], ne = rec->n_est;
+                int idx = 0;
+                const double res = pw_combine<kPwDepth>(nj, leafsum + cl[c * 2 + 1] * 21 + e, 21, idx);
+                blend(rec, a, b, res, nj, g_ab, g_ba, ne);
+            }
         }
     }
     STAMP(5);  // dispersion matrices (wave 0's share)
@@ -488,6 +575,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         for (int j = tid; j < Told; j += kThreads) { L.slot[j] = L.slot2[j]; order[j] = L.slot2[j]; }
     }
     __syncthreads();
+    PROBE(6);
     STAMP(7);  // maintenance
 
     // (_update_all, Tracking.py:598-603, runs as its own batched kernel right after this one: k_update)

@@ -204,7 +204,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.g_ring, S * (size_t)ring * max_pts * 8 * sizeof(double));
     ALLOC(c->d_posture, MMW_NKP * sizeof(float));
     ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
-    ALLOC(c->d_stats, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long));
+    ALLOC(c->d_stats, ((size_t)kStatSlots * kStatWords + 128) * sizeof(unsigned long long));  // + probe words of the diagnostic build
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
     ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
@@ -567,6 +567,15 @@ int mmw_stats_get_ext(mmw_ctx *c, uint64_t *out)
     if (!c || !out) return MMW_E_ARG;
     return read_stats(c, out, kStatWords);
 }
+#ifdef MMW_STAMPS
+int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[128]*/)
+{
+    if (!c || !out) return MMW_E_ARG;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stats + (size_t)kStatSlots * kStatWords, 128 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+#endif
 int mmw_stats_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python scripts/phase_stamps.py 2>&1 | tail -20
+timeout 300 python scripts/probe_timeline.py 2>&1 | tail -6
