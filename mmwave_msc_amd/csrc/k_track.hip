@@ -59,6 +59,7 @@ struct TrackLds {
     int *cls_off;    // [CLS+1]
     long long *seg_dst; // [CLS] where this frame's rows go: track j's ring slot (j < T), the global ring slot (j == T); in doubles
     double *wmm;     // [kWaves][24] per-wave min/max hand-over of the cluster statistics
+    double *nest;    // [t_cap] N_est after this frame's estimate (stats -> dispersion phase)
     int *ml;         // multi-leaf clouds (n > 128): [0] leaves, [1] clouds, then per leaf (track, off, len), per cloud (track, first leaf)
     int *slot;       // [t_cap]
     int *slot2;      // [t_cap]
@@ -89,6 +90,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     CARVE(cls_off, int, CLS + 1)
     CARVE(seg_dst, long long, CLS + 1)
     CARVE(wmm, double, kWaves * 24)
+    CARVE(nest, double, c.t_cap)
     CARVE(ml, int, 2 + 5 * (pw_max_leaves(NP) + 1))
     CARVE(slot, int, c.t_cap)
     CARVE(slot2, int, c.t_cap)
@@ -189,6 +191,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     const int role = (wave + s) & (kWaves - 1);
     const int NP = cfg.max_pts, CLS = cfg.t_cap + 1;
     const int NPs = NP + kTilePad;  // column stride of the point tile
+    // Everything the first phases read goes out in ONE batch of independent global loads: the scene's
+    // track order first (its completion is all the first barrier has to wait for -- vmcnt retires in
+    // order), then the points, WITHOUT waiting for the point count (rows past the count are allocated
+    // memory, loaded speculatively and ignored), each row's 8 columns straight into registers: they are
+    // gated from registers and only later parked in the LDS tile.
+    const int my_slot = tid < cfg.t_cap ? st.order[(size_t)s * cfg.t_cap + tid] : 0;
+    double2 pr[PPT][4];
+    {
+        const double2 *src2 = reinterpret_cast<const double2 *>(pts_all + (size_t)s * NP * 8);
+#pragma unroll
+        for (int q = 0; q < PPT; q++) {
+            const int i = q * kThreads + tid;
+#pragma unroll
+            for (int u = 0; u < 4; u++) pr[q][u] = (i < NP) ? src2[i * 4 + u] : double2{0.0, 0.0};
+        }
+    }
     const int n = n_pts[s];
     SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
@@ -201,7 +219,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         return;
     }
     const double dt = dt_all[s];
-    const double *pts = pts_all + (size_t)s * NP * 8;
     int32_t *order = st.order + (size_t)s * cfg.t_cap;
     TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
     int T = hdr->n_tracks;
@@ -212,23 +229,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
 #endif
     double *gate = L.work;
 
-    // ---- this thread's points (rows tid, tid+256, ...): columns 0..5 straight into registers with
-    //      16-byte loads; issued first so HBM latency hides under the track prediction below.
-    //      They are gated from registers and only then parked in the LDS tile for the statistics ----
-    double2 pr[PPT][4];
-    {
-        const double2 *src2 = reinterpret_cast<const double2 *>(pts);
-#pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            const int i = q * kThreads + tid;
-#pragma unroll
-            for (int u = 0; u < 4; u++) pr[q][u] = (i < n) ? src2[i * 4 + u] : double2{0.0, 0.0};
-        }
-    }
-    for (int j = tid; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
+    if (tid < cfg.t_cap) L.slot[tid] = my_slot;
+    for (int j = tid + kThreads; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
     if (tid == 0) { L.ml[0] = 0; L.ml[1] = 0; }
-    __syncthreads();
+    lds_barrier();
     STAMP(0);  // issue point loads
+    PROBE(0);
 
     double bestd[PPT];
     int bestj[PPT];
@@ -242,8 +248,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             const int jl = e / kGateRec, k = e - jl * kGateRec;
             gate[jl * kGateStride + k] = st.gate_buf[((size_t)s * cfg.t_cap + c0 + jl) * kGateRec + k];
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(1);  // predict + gate matrices
+        PROBE(1);
         // ---- gate every point against the chunk's tracks (Tracking.py:553-572) ----
         // (points in registers, the 6x6 inverse read from LDS as wave-uniform broadcasts: keeping it
         //  in registers as well costs 72 VGPRs and a workgroup per CU)
@@ -274,8 +281,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(2);  // gating
+        PROBE(2);
     }
     // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
     {
@@ -286,6 +294,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             const int i = q * kThreads + tid;
             const int blk = q * kWaves + wave;
             mybal[q] = 0;
+            if (q == 0) PROBE(25);
             if (blk < NB) {  // wave-uniform
                 const int cls = (i < n) ? bestj[q] + 1 : -1;
                 if (i < n && assoc_out) assoc_out[(size_t)s * NP + i] = bestj[q];
@@ -296,33 +305,52 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                 }
             }
         }
-        __syncthreads();
-        for (int c = tid; c <= T; c += kThreads) {
+        PROBE(26);
+        lds_barrier();
+        PROBE(27);
+        for (int c = tid; c <= T; c += kThreads) {  // exclusive scan over the 64-point blocks: all counts first, then the adds
+            int t[PPT * kWaves];
+#pragma unroll
+            for (int b = 0; b < PPT * kWaves; b++) t[b] = b < NB ? L.cnt[b * CLS + c] : 0;
             int run = 0;
-            for (int b = 0; b < NB; b++) { int t = L.cnt[b * CLS + c]; L.cnt[b * CLS + c] = run; run += t; }
+#pragma unroll
+            for (int b = 0; b < PPT * kWaves; b++) { if (b < NB) L.cnt[b * CLS + c] = run; run += t[b]; }
             L.cls_n[c] = run;
         }
-        __syncthreads();
-        if (tid == 0) {
+        lds_barrier();
+        PROBE(28);
+        for (int c = tid; c <= T + 1; c += kThreads) {  // class offsets: every class adds up the sizes before it
             int run = 0;
-            for (int c = 0; c <= T; c++) { L.cls_off[c] = run; run += L.cls_n[c]; }
-            L.cls_off[T + 1] = run;
+            for (int k = 0; k < c; k++) run += L.cls_n[k];
+            L.cls_off[c] = run;
         }
         // where this frame's rows go, from the ring state BEFORE this frame's push (the bookkeeping itself
         // happens after the copies): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
         for (int j = tid; j <= T; j += kThreads) {
             if (j < T) {
                 const TrackRec *rec = trk + L.slot[j];
-                const int len = rec->ring_len;
-                const int phys = len >= cfg.ring ? rec->ring_slot[0] : rec->ring_slot[len];
+                const int len = rec->ring_len;  // (length and all slots requested together: one round trip)
+                int rs[MMW_RING_MAX];
+#pragma unroll
+                for (int k = 0; k < MMW_RING_MAX; k++) rs[k] = rec->ring_slot[k];
+                int phys = rs[0];
+#pragma unroll
+                for (int k = 1; k < MMW_RING_MAX; k++) if (len < cfg.ring && k == len) phys = rs[k];
                 L.seg_dst[j] = (((long long)s * cfg.t_cap + L.slot[j]) * cfg.ring + phys) * (long long)cfg.ring_rows * 8;
             } else {
                 const int len = hdr->g_len;
-                const int phys = len >= cfg.ring ? hdr->g_slot[0] : hdr->g_slot[len];
+                int rs[MMW_RING_MAX];
+#pragma unroll
+                for (int k = 0; k < MMW_RING_MAX; k++) rs[k] = hdr->g_slot[k];
+                int phys = rs[0];
+#pragma unroll
+                for (int k = 1; k < MMW_RING_MAX; k++) if (len < cfg.ring && k == len) phys = rs[k];
                 L.seg_dst[j] = ((long long)s * cfg.ring + phys) * (long long)NP * 8;
             }
         }
-        __syncthreads();
+        PROBE(29);
+        lds_barrier();
+        PROBE(30);
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
@@ -345,7 +373,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                 }
             }
         }
-        __syncthreads();
+        PROBE(31);
+        lds_barrier();
     }
     STAMP(3);  // class split
     PROBE(3);
@@ -470,31 +499,43 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
                     if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
                     else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
                     rec->n_est = ne;
+                    L.nest[j] = ne;
                 }
             }
         }
         wave_sync();
     }
     PROBE(24);
-    __syncthreads();
+    lds_barrier();
     STAMP(4);  // centroid/min/max/spread
     PROBE(4);
     // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
-    for (int j = tid; j < T; j += kThreads) {
+    // (the LAST wave does it: the dispersion items below fill the waves from the front, and this is a chain of
+    //  global round trips)
+    for (int j = kThreads - 1 - tid; j < T; j += kThreads) {
         const int nj = L.cls_n[j + 1];
         if (nj > 0) {
             TrackRec *rec = trk + L.slot[j];
             const double v3 = L.cen[j * 6 + 3], v4 = L.cen[j * 6 + 4], v5 = L.cen[j * 6 + 5];
             rec->is_static = sqrt((v3 * v3 + v4 * v4) + v5 * v5) < cfg.tr_vel_thres ? 1 : 0;
-            // BatchedData.add_frame on the track ring (Tracking.py:43-51); the rows were written above
+            // BatchedData.add_frame on the track ring (Tracking.py:43-51); the rows were written above.
+            // ring_len, ring_n[], ring_slot[] come in together and go back together.
             int len = rec->ring_len;
+            int rn[MMW_RING_MAX], rs[MMW_RING_MAX];
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) { rn[k] = rec->ring_n[k]; rs[k] = rec->ring_slot[k]; }
             while (len >= cfg.ring) {  // pop_frame: the freed physical slot becomes the first free entry
-                const int first = rec->ring_slot[0];
-                for (int k = 1; k < len; k++) { rec->ring_slot[k - 1] = rec->ring_slot[k]; rec->ring_n[k - 1] = rec->ring_n[k]; }
-                rec->ring_slot[len - 1] = first;
+                const int first = rs[0];
+#pragma unroll
+                for (int k = 1; k < MMW_RING_MAX; k++) if (k < len) { rs[k - 1] = rs[k]; rn[k - 1] = rn[k]; }
+#pragma unroll
+                for (int k = 0; k < MMW_RING_MAX; k++) if (k == len - 1) rs[k] = first;
                 len--;
             }
-            rec->ring_n[len] = nj;
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) if (k == len) rn[k] = nj;
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) { rec->ring_n[k] = rn[k]; rec->ring_slot[k] = rs[k]; }
             rec->ring_len = len + 1;
         }
     }
@@ -503,6 +544,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     // clouds of one leaf (n <= 128), (leaf, entry) for the leaves of larger clouds, whose sums meet in LDS
     // and are combined by one lane per (track, entry) after a barrier.
     {
+        PROBE(10);
         double *leafsum = L.work + 6 * NPs;  // [leaf][21]
         const int nleaf = L.ml[0], ncloud = L.ml[1];
         const int *lf = L.ml + 2, *cl = L.ml + 2 + 3 * pw_max_leaves(NP);
@@ -524,29 +566,34 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
             if (direct && (nj == 0 || nj > 128)) continue;
             const int off = L.cls_off[j + 1] + (direct ? 0 : lf[(u - T) * 3 + 1]), len = direct ? nj : lf[(u - T) * 3 + 2];
             TrackRec *rec = trk + L.slot[j];
+            PROBE(11);
             double g_ab = 0.0, g_ba = 0.0, ne = 1.0;
-            if (direct) { g_ab = rec->gd[a * 6 + b]; g_ba = rec->gd[b * 6 + a]; ne = rec->n_est; }  // in flight during the sum
+            if (direct) { g_ab = rec->gd[a * 6 + b]; g_ba = rec->gd[b * 6 + a]; ne = L.nest[j]; }  // (loads in flight during the sum)
             const double res = pw_leaf(L.p6 + a * NPs + off, L.p6 + b * NPs + off, L.cen[j * 6 + a], L.cen[j * 6 + b], len);
+            PROBE(12);
             if (direct) blend(rec, a, b, res, nj, g_ab, g_ba, ne);
             else leafsum[(u - T) * 21 + (it - u * 21)] = res;
         }
+        PROBE(13);
         if (ncloud > 0) {  // uniform
-            __syncthreads();
+            lds_barrier();
+            PROBE(14);
             for (int it = tid; it < ncloud * 21; it += kThreads) {
                 const int c = it / 21, e = it - c * 21;
                 int a, b;
                 entry(e, a, b);
                 const int j = cl[c * 2], nj = L.cls_n[j + 1];
                 TrackRec *rec = trk + L.slot[j];
-                const double g_ab = rec->gd[a * 6 + b], g_ba = rec->gd[b * 6 + a], ne = rec->n_est;
+                const double g_ab = rec->gd[a * 6 + b], g_ba = rec->gd[b * 6 + a], ne = L.nest[j];
                 int idx = 0;
                 const double res = pw_combine<kPwDepth>(nj, leafsum + cl[c * 2 + 1] * 21 + e, 21, idx);
                 blend(rec, a, b, res, nj, g_ab, g_ba, ne);
             }
         }
+        PROBE(15);
     }
     STAMP(5);  // dispersion matrices (wave 0's share)
-    __syncthreads();
+    __syncthreads();  // full fence: maintenance reads is_static / lifetime other threads stored to the records
     STAMP(6);  // track ring rows + barrier (includes waiting for the other waves' dispersion work)
 
     // ---- _maintain_tracks (Tracking.py:513-528) ----
@@ -568,13 +615,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         }
         if (lane == 0) L.misc[0] = nk;
     }
-    __syncthreads();
+    lds_barrier();
     {
         const int Told = T;
         T = L.misc[0];
         for (int j = tid; j < Told; j += kThreads) { L.slot[j] = L.slot2[j]; order[j] = L.slot2[j]; }
     }
-    __syncthreads();
+    lds_barrier();
     PROBE(6);
     STAMP(7);  // maintenance
 
@@ -606,6 +653,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     }
     if (err) atomicOr(&hdr->err, err);
     STAMP(9);  // global ring append
+    PROBE(9);
     if (tid == 0 && st.stats) {
         // algorithmic bytes of this scene-frame: points in, assoc out, track records
         // read+written, unassigned rows appended to the global ring, rows appended to track rings

@@ -70,6 +70,15 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for phases that hand data over through LDS only.  __syncthreads() is also a fence for
+// global memory, i.e. every wave first waits until its outstanding global stores have completed (a round
+// trip of a thousand cycles and more); rows, track records and labels written for LATER kernels need no
+// such wait.  Use only where no thread reads global memory another thread of the workgroup wrote.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 6x6 partial-pivot LU, determinant and inverse (stands for np.linalg.det / np.linalg.inv at
 // Tracking.py:558-560 and filterpy's inv(S)), FOUR matrices per wave, column-parallel Gauss-Jordan
 // on the augmented matrix [A | I]: in every 16-lane group lane c < 6 holds column c of A in v[0..5],
