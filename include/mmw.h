@@ -191,13 +191,16 @@ int mmw_get_batch_ring_frame(mmw_ctx *ctx, int32_t scene, int32_t k, double *out
 int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32_t scene_base);
 
 /* Kernel timing with hipEvents on the context's stream (bench.py roofline).
- * ids: 0 track, 1 dbscan, 2 features, 3 normalize, 4 table. */
+ * ids: 0 k_track (association), 1 k_dbscan_screen + the BallTree launches of large clouds, 2 features,
+ * 3 normalize, 4 table, 5 k_predict, 6 k_post (Kalman update + BallTree DBSCAN of small clouds). */
 #define MMW_K_TRACK 0
 #define MMW_K_DBSCAN 1
 #define MMW_K_FEATURES 2
 #define MMW_K_NORMALIZE 3
 #define MMW_K_TABLE 4
-#define MMW_K_COUNT 5
+#define MMW_K_PREDICT 5
+#define MMW_K_POST 6
+#define MMW_K_COUNT 7
 /* The two Conv3D(3x3x3, same, relu) layers of define_CNN_3D (train.py:73-82) fused on the fp32 matrix
  * cores, on the current device and the given hipStream_t (NULL = default stream).  All dev pointers:
  *   feat[n][3][8][8][5]   channels-last input (what mmw_features writes)

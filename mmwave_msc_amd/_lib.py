@@ -20,7 +20,7 @@ NKP = 57
 
 MMW_OK = 0
 E_ARG, E_SINGULAR, E_DIVZERO, E_CAPACITY, E_HIP, E_NODEVICE = -1, -2, -3, -4, -5, -6
-K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE = range(5)
+K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE, K_PREDICT, K_POST = range(7)
 
 EXPORTS = [
     "mmw_config_default", "mmw_create", "mmw_destroy", "mmw_last_error", "mmw_reset", "mmw_set_stream",

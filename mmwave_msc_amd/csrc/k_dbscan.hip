@@ -26,6 +26,7 @@
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 #include "mmw_cloud.hpp"
+#include "mmw_kalman.hpp"
 
 namespace mmw {
 
@@ -813,6 +814,38 @@ __global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, in
     }
 }
 
+// k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
+//   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
+//                    <= 256 points the screen could not rule out): a handful of scenes per step, each a
+//                    latency chain of ~60 us that would otherwise leave the chip idle;
+//   the others       _update_all (Tracking.py:598-603) of four (scene, quarter) units each, one wave per unit
+//                    (update_tracks_wave, mmw_kalman.hpp) -- the bulk work the BallTree scenes hide under.
+// The two touch disjoint state: the update covers the hdr->n_upd tracks that existed before this frame's
+// clusters, the spawn appends records behind them.
+template <int DX>
+__global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
+                                              int UM_out, int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    if ((int)blockIdx.x < G0) {
+        __builtin_amdgcn_s_setprio(3);  // the latency chain goes first whenever it has an instruction ready
+        DbLds L;
+        db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
+        const int count = st.db_count[parity * 4 + 3];
+        for (int w = blockIdx.x; w < count; w += G0) {
+            const int s = st.db_list[(size_t)3 * cfg.n_scenes + w];
+            spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, labels_out, db_n_out);
+            __syncthreads();  // LDS is reused by the next scene
+        }
+        return;
+    }
+    const int wave = threadIdx.x >> 6;
+    const int unit = ((int)blockIdx.x - G0) * 4 + wave;
+    if (unit >= cfg.n_scenes * nq) return;
+    const int s = unit / nq, q = unit - s * nq;
+    update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch);
+}
+
 // Utils.apply_DBscan on caller-provided clouds: pts[S][max_n][8]
 __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const double *__restrict__ pts,
                                                     const int32_t *__restrict__ n_all, int max_n, double eps,
@@ -837,7 +870,6 @@ __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const d
 
 // ---- host side ---------------------------------------------------------------------------
 static const int kClassUM[3] = {256, 768, 1920};
-constexpr int kClass0Threads = 512;
 
 int dbscan_class_um(int cls, int UM) { return kClassUM[cls] < UM ? kClassUM[cls] : UM; }
 int dbscan_class_cl(int cls, int UM, int t_cap, int min_samples)
@@ -852,10 +884,17 @@ size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples)
 }
 size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false, nullptr, nullptr); }
 
+static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
+{
+    const size_t upd = (size_t)4 * 4 * kUpdScratch * sizeof(double), db = dbscan_lds_bytes(0, UM, t_cap, min_samples);
+    return upd > db ? upd : db;
+}
+
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_dbscan_spawn<kClass0Threads, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)dbscan_lds_bytes(0, UM, t_cap, min_samples));
+    hipError_t e = hipFuncSetAttribute((const void *)k_post<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_post<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
     size_t big = dbscan_lds_bytes(1, UM, t_cap, min_samples);
     if (dbscan_lds_bytes(2, UM, t_cap, min_samples) > big) big = dbscan_lds_bytes(2, UM, t_cap, min_samples);
@@ -864,26 +903,40 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
 }
 
-// One launch per size class that can occur (class c exists when its lower bound < UM).
-void launch_dbscan_spawn(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
+void launch_dbscan_screen(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_dbscan_screen, dim3(cfg.n_scenes), dim3(256), 0, stream, cfg, st, UM, parity, labels, db_n);
+}
+
+// _update_all + the BallTree DBSCAN of the small clouds (work list 3)
+void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int32_t *labels, int32_t *db_n,
+                 hipStream_t stream)
+{
+    int nq = (cfg.tr_max_tracks + 3) / 4;
+    if (nq < 1) nq = 1;
+    const int S = cfg.n_scenes, G0 = S < 256 ? S : 256, units = S * nq;
+    const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
+    const size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
+    const dim3 grid(G0 + (units + 3) / 4);
+    if (cfg.dx == 9) hipLaunchKernelGGL(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
+    else hipLaunchKernelGGL(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
+}
+
+// The larger clouds (work lists 1 and 2; the start-up frames of a scene): one launch per size class that
+// can occur (class c exists when its lower bound < UM).
+void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
     const int S = cfg.n_scenes;
-    hipLaunchKernelGGL(k_dbscan_screen, dim3(S), dim3(256), 0, stream, cfg, st, UM, parity, labels, db_n);
-    for (int cls = 0; cls < 3; cls++) {
-        if (cls > 0 && kClassUM[cls - 1] >= UM) break;
+    for (int cls = 1; cls < 3; cls++) {
+        if (kClassUM[cls - 1] >= UM) break;
         const int umc = dbscan_class_um(cls, UM), cl = dbscan_class_cl(cls, UM, cfg.t_cap, cfg.db_min_samples);
         const size_t lds = dbscan_lds_bytes(cls, UM, cfg.t_cap, cfg.db_min_samples);
-        // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
-        int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));
-        const int nt = cls == 0 ? kClass0Threads : 256;
-        if (per_cu > 2048 / nt) per_cu = 2048 / nt;
+        int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));  // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
+        if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
         int grid = 256 * per_cu;
         if (grid > S) grid = S;
-        if (cls == 0)
-            hipLaunchKernelGGL((k_dbscan_spawn<kClass0Threads, true>), dim3(grid), dim3(kClass0Threads), lds, stream, cfg, st, umc, cl, UM, parity, 3, labels, db_n);
-        else
-            hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(grid), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
+        hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(grid), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
     }
 }
 

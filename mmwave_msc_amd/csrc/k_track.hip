@@ -44,6 +44,9 @@ constexpr int kGateStride = 44;   // per track: Ci[36] | log|det| | hx[6] (k_pre
 // Columns of the point tile are NP + 2 doubles apart: with a power-of-two stride the same row of all six
 // columns -- what the lanes of one track read together -- would sit in one LDS bank (6-way conflicts).
 constexpr int kTilePad = 2;
+// per track: gate record in (352) + spread, N_est, group dispersion, ring state in (392) + centroid, min, max,
+// spread, group dispersion, N_est, lifetime, counters, ring state out (540)
+constexpr int kTrackBytesPerTrack = 352 + 392 + 540;
 
 // numpy's pairwise split point and the bound on leaves per frame (see pw_* below): a leaf that comes from a
 // split holds at least 57 rows, so a frame has at most max_pts/57 of them.
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
         for (int k = 0; k < MMW_RING_MAX; k++) { hdr->g_slot[k] = gs[k]; hdr->g_n[k] = k < len ? gn[k] : 0; }
         hdr->g_len = len;
         hdr->n_tracks = T;
+        hdr->n_upd = T;
         hdr->db_u = U;
         const bool need = U > 0 && T < cfg.tr_max_tracks;
         hdr->need_db = need ? 1 : 0;  // picked up by k_dbscan_screen (k_dbscan.hip)
@@ -655,12 +659,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, 
     STAMP(9);  // global ring append
     PROBE(9);
     if (tid == 0 && st.stats) {
-        // algorithmic bytes of this scene-frame: points in, assoc out, track records
-        // read+written, unassigned rows appended to the global ring, rows appended to track rings
+        // algorithmic bytes of this scene-frame: points in, assoc out, per track the gate record
+        // and the record fields this kernel reads and writes, unassigned rows appended to the global ring, rows
+        // appended to track rings
         int ring_rows = 0;
         for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
         unsigned long long *sl = stats_slot(st, s);
-        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + 2 * Tin * (int)sizeof(TrackRec) + 64 * nun + 64 * ring_rows));
+        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * nun + 64 * ring_rows));
         atomicAdd(&sl[2], 1ULL);
         atomicAdd(&sl[5], (unsigned long long)Tin);
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);

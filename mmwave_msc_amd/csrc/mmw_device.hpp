@@ -50,7 +50,8 @@ struct SceneHdr {
     int32_t err;
     int32_t db_u;
     int32_t next_uid;              // TrackBuffer.next_track_id (Tracking.py:509,588)
-    int32_t pad[2];
+    int32_t n_upd;                 // tracks after _maintain_tracks of this frame = what _update_all covers (k_track -> k_post)
+    int32_t pad;
 };
 static_assert(sizeof(SceneHdr) == 64, "SceneHdr");
 

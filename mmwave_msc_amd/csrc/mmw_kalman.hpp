@@ -1,0 +1,166 @@
+// mmw_kalman.hpp -- device code shared by k_kalman.hip (k_predict) and k_dbscan.hip (k_post: the Kalman
+// update and the BallTree DBSCAN of a frame in one launch).
+#pragma once
+
+#include <cstddef>
+
+#include "mmw_device.hpp"
+#include "mmw_math.hpp"
+
+namespace mmw {
+
+// A TrackRec starts with 152 doubles (x, P, centroid, min, max, spread, group dispersion, N_est, lifetime)
+// followed by its integers: the kernels copy that prefix into LDS as raw 8-byte words, ten independent
+// loads per lane issued back to back (one global round trip), and pick the fields out of the copy.
+constexpr int rX = 0, rP = 9, rCen = 90, rSpr = 108, rGd = 114, rNest = 150, rLife = 151, rInts = 152, kRecRaw = 154;
+static_assert(offsetof(TrackRec, P) == rP * 8 && offsetof(TrackRec, centroid) == rCen * 8 && offsetof(TrackRec, spread) == rSpr * 8 &&
+              offsetof(TrackRec, gd) == rGd * 8 && offsetof(TrackRec, n_est) == rNest * 8 && offsetof(TrackRec, lifetime) == rLife * 8 &&
+              offsetof(TrackRec, point_num) == rInts * 8, "TrackRec prefix layout");
+
+// per-track LDS scratch (doubles)
+constexpr int pA = kRecRaw, pXn = pA + 81, pS = pXn + 9, kPredScratch = pS + 2;
+constexpr int uA = kRecRaw, uK = uA + 81, uSI = uK + 54, uC1 = uSI /* C1 replaces S^-1 once K is formed */, uY = uSI + 54, uRc = uY + 6,
+              kUpdScratch = uRc + 36;
+
+__device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int c, bool live)
+{
+    const double *src = reinterpret_cast<const double *>(rec);
+    double t[10];
+#pragma unroll
+    for (int u = 0; u < 10; u++) { const int k = c + 16 * u; t[u] = (live && k < kRecRaw) ? src[k] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 10; u++) { const int k = c + 16 * u; if (live && k < kRecRaw) R[k] = t[u]; }
+}
+
+// _update_all for tracks 4q.., 4(q+nq).. of scene s by ONE wave (four 16-lane groups); `lds` = this wave's
+// 4 * kUpdScratch doubles.  Reads hdr->n_upd: the tracks that survived _maintain_tracks in k_track -- this
+// frame's new tracks (k_dbscan_spawn, possibly running in the same launch) are not updated.
+template <int DX>
+__device__ __forceinline__ void update_tracks_wave(const DevCfg &cfg, const DevState &st, const int32_t *__restrict__ n_pts, int s, int q,
+                                                   int nq, double *lds)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int n = n_pts[s];
+    if (n <= 0 || n > cfg.max_pts) return;
+    const SceneHdr *hdr = st.hdr + s;
+    const int T = hdr->n_upd;
+    if (q * 4 >= T) return;
+    const int32_t *order = st.order + (size_t)s * cfg.t_cap;
+    TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+    double *Wj = lds + g * kUpdScratch;
+    int err = 0;
+    for (int j0 = q * 4; j0 < T; j0 += nq * 4) {
+        const int j = j0 + g;
+        const bool live = j < T;
+        TrackRec *rec = trk + (live ? order[j] : 0);
+        stage_record(rec, Wj, c, live);
+        wave_sync();
+        const double *Pw = Wj + rP;
+        // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
+        {
+            const bool valid = live && c < 6;
+            double v[6], det;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;
+            if (valid) {
+                const double N = (double)reinterpret_cast<const int32_t *>(Wj + rInts)[0], nest = Wj[rNest];
+                const double den = (nest - 1) * N;
+                if (den == 0.0) err |= ERR_DIVZERO;
+                const double coef = (nest - N) / den;
+                const double hh = Wj[rSpr + c] / 2;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * Wj[rGd + i * 6 + c];
+                    Wj[uRc + i * 6 + c] = rc;
+                    v[i] = Pw[i * 9 + c] + rc;  // S = H P H^T + R
+                }
+                Wj[uY + c] = Wj[rCen + c] - Wj[rX + c];  // y = z - H x
+            }
+            const bool ok = lu6_inverse_cols(v, lane, det);
+            if (live) {
+                if (!ok) err |= ERR_SINGULAR;
+                if (c >= 6 && c < 12) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++) Wj[uSI + r * 6 + c - 6] = v[r];
+                }
+            }
+        }
+        wave_sync();
+        if (live) {
+            for (int k = c; k < DX * 6; k += 16) {  // K = P H^T S^-1
+                const int i = k / 6, cc = k - i * 6;
+                double a = Pw[i * 9] * Wj[uSI + cc];
+#pragma unroll
+                for (int m = 1; m < 6; m++) a += Pw[i * 9 + m] * Wj[uSI + m * 6 + cc];
+                Wj[uK + k] = a;
+            }
+        }
+        wave_sync();
+        if (live) {
+            const double *Kw = Wj + uK, *yw = Wj + uY, *Rcw = Wj + uRc;
+            for (int k = c; k < 81; k += 16) {  // A = (I - K H) P
+                const int i = k / 9, cc = k - i * 9;
+                if (i < DX && cc < DX) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int m = 0; m < DX; m++) {
+                        const double d = (i == m) ? 1.0 : 0.0;
+                        const double ikh = m < 6 ? d - Kw[i * 6 + m] : d;
+                        a = (m == 0) ? ikh * Pw[cc] : a + ikh * Pw[m * 9 + cc];
+                    }
+                    Wj[uA + k] = a;
+                }
+            }
+            if (c < DX) {  // x = x + K y
+                double a = Kw[c * 6] * yw[0];
+#pragma unroll
+                for (int m = 1; m < 6; m++) a += Kw[c * 6 + m] * yw[m];
+                double xnew = Wj[rX + c] + a;
+                if (c == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
+                    const double var = Wj[rCen] - xnew;
+                    if (!(var == 0.0) && Wj[rLife] == 0.0) xnew += var * 0.4;
+                }
+                rec->x[c] = xnew;
+            }
+            double c1[4];  // C1 = K R, into the S^-1 area: every lane forms its entries first, then they are stored
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = c + 16 * u;
+                c1[u] = 0.0;
+                if (k < DX * 6) {
+                    const int i = k / 6, cc = k - i * 6;
+                    double a = Kw[i * 6] * Rcw[cc];
+#pragma unroll
+                    for (int m = 1; m < 6; m++) a += Kw[i * 6 + m] * Rcw[m * 6 + cc];
+                    c1[u] = a;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int k = c + 16 * u; if (k < DX * 6) Wj[uC1 + k] = c1[u]; }
+        }
+        wave_sync();
+        if (live) {
+            const double *Aw = Wj + uA, *Kw = Wj + uK, *C1w = Wj + uC1;
+            for (int k = c; k < 81; k += 16) {  // P = A (I-KH)^T + C1 K^T
+                const int i = k / 9, cc = k - i * 9;
+                if (i < DX && cc < DX) {
+                    double b = 0.0;
+#pragma unroll
+                    for (int m = 0; m < DX; m++) {
+                        const double d = (cc == m) ? 1.0 : 0.0;
+                        const double ikh = m < 6 ? d - Kw[cc * 6 + m] : d;
+                        b = (m == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + m] * ikh;
+                    }
+                    double c2 = C1w[i * 6] * Kw[cc * 6];
+#pragma unroll
+                    for (int m = 1; m < 6; m++) c2 += C1w[i * 6 + m] * Kw[cc * 6 + m];
+                    rec->P[k] = b + c2;
+                }
+            }
+        }
+        wave_sync();
+    }
+    if (err) atomicOr(&st.hdr[s].err, err);
+}
+
+}  // namespace mmw
