@@ -647,15 +647,16 @@ __global__ __launch_bounds__(256) void k_dbscan_screen(DevCfg cfg, DevState st, 
 {
     __shared__ float4 P4[256];
     __shared__ int cnt[256];
-    __shared__ unsigned long long mm[3];
+    __shared__ unsigned long long mm[5];
     __shared__ int flag;
+    __shared__ int grid[kCloudGrid];
     const int tid = threadIdx.x;
     const int s = blockIdx.x;
     SceneHdr *hdr = st.hdr + s;
     if (!hdr->need_db) return;
     const int U = hdr->db_u;
     bool tree = true;
-    if (U <= 256) tree = !cloud_has_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, &flag);
+    if (U <= 256) tree = !cloud_has_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, &flag, grid);
     if (tree) {
         if (tid == 0) {
             const int cls = U <= 256 ? 3 : (U <= 768 ? 1 : 2);

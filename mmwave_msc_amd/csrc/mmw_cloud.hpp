@@ -76,9 +76,15 @@ __device__ __forceinline__ RowSrc ring_rows_of(const DevCfg &cfg, const DevState
 // once, |error| <= M 2^-24 per coordinate with M the largest magnitude in the cloud, i.e. at most
 // 2 sqrt(3) M 2^-24 on E (a norm), and the fp32 evaluation of the squared norm is good to a few 2^-24
 // relative.  R below carries 4 M 6e-8 absolute and 1e-5 relative slack, far more than both.
-// P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.
+//
+// Before the O(U^2) count a coarser superset is tried in O(U): the points are binned into square xy cells
+// of side h = R/2 (a hair more); everything within R of a point lies in the 5x5 cells around its own, so if
+// no 5x5 block holds min_samples points nothing can be a core point.  A ring of clutter -- the usual case
+// -- ends there.
+// P4 [256] float4, cnt [256] ints, mm [5] u64, flag [1], grid [kCloudGrid] ints are LDS scratch.
+constexpr int kCloudGrid = 1024;
 __device__ __forceinline__ bool cloud_has_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
-                                                  unsigned long long *mm, int *flag)
+                                                  unsigned long long *mm, int *flag, int *grid)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
@@ -96,16 +102,22 @@ __device__ __forceinline__ bool cloud_has_no_core(const DevCfg &cfg, const RowSr
         if (!(mag <= 1e15)) mag = __longlong_as_double(0x7ff0000000000000LL);  // NaN/inf/huge: give up below
         cnt[tid] = 0;
     }
-    if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; mm[2] = 0ULL; *flag = 0; }
+    if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; mm[2] = 0ULL; mm[3] = ~0ULL; mm[4] = 0ULL; *flag = 0; }
+    for (int i = tid; i < kCloudGrid; i += 256) grid[i] = 0;
     __syncthreads();
     double ylo = tid < U ? y : 1.7976931348623157e308, yhi = tid < U ? y : -1.7976931348623157e308;
+    double xlo = tid < U ? (double)P4[tid].x : 1.7976931348623157e308, xhi = tid < U ? (double)P4[tid].x : -1.7976931348623157e308;
     ylo = wave_min_d(ylo);
     yhi = wave_max_d(yhi);
+    xlo = wave_min_d(xlo);
+    xhi = wave_max_d(xhi);
     mag = wave_max_d(mag);
     if (lane == 0 && ylo <= yhi) {
         atomicMin(&mm[0], sortable(ylo));
         atomicMax(&mm[1], sortable(yhi));
         atomicMax(&mm[2], (unsigned long long)__double_as_longlong(mag));  // mag >= 0: bit order == value order
+        atomicMin(&mm[3], sortable(xlo));
+        atomicMax(&mm[4], sortable(xhi));
     }
     __syncthreads();
     const double ymin = unsortable(mm[0]), ymax = unsortable(mm[1]), M = __longlong_as_double((long long)mm[2]);
@@ -114,6 +126,45 @@ __device__ __forceinline__ bool cloud_has_no_core(const DevCfg &cfg, const RowSr
     if (!(wmin > 0.0) || !(M <= 1e15)) return false;  // uniform: same LDS values for every thread
     const double R = sqrt(2.0 * (eps / wmin)) * (1.0 + 1e-9) + 4.0 * M * 6e-8;
     const float R2f = (float)(R * R * (1.0 + 1e-5));
+    {   // ---- O(U) superset: 5x5 blocks of cells of side h = R/2 * (1 + 1e-3) ----
+        // |dx| <= R  =>  |dx| / h <= 2 - 2e-3, so the (fp32) cell coordinates of two such points differ by
+        // less than 2 - 1e-3 even after rounding (their error is ~1e-5 cells here) and the integer cells by
+        // at most 2.  The rounded fp32 coordinates themselves are within the slack R already carries.
+        const double h = 0.5 * R * (1.0 + 1e-3);
+        const double x0 = unsortable(mm[3]), x1 = unsortable(mm[4]);
+        const double wx = (x1 - x0) / h, wy = ((double)(float)ymax - (double)(float)ymin) / h;
+        if (h > 0.0 && wx < 500.0 && wy < 500.0) {  // (also false for NaN)
+            const int nx = (int)wx + 6, ny = (int)wy + 6;  // two guard cells on every side (+ rounding room)
+            if (nx * ny <= kCloudGrid) {  // uniform
+                const float invh = (float)(1.0 / h), fx0 = (float)x0, fy0 = (float)ymin;
+                int cx = 0, cy = 0;
+                if (tid < U) {
+                    const float4 a = P4[tid];
+                    cx = (int)((a.x - fx0) * invh) + 2;
+                    cy = (int)((a.y - fy0) * invh) + 2;
+                    cx = cx < 2 ? 2 : (cx > nx - 3 ? nx - 3 : cx);  // (rounding at the edges)
+                    cy = cy < 2 ? 2 : (cy > ny - 3 ? ny - 3 : cy);
+                    atomicAdd(&grid[cy * nx + cx], 1);
+                }
+                __syncthreads();
+                bool maybe = false;
+                if (tid < U) {
+                    int c = 0;
+#pragma unroll
+                    for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+                        for (int dx = -2; dx <= 2; dx++) c += grid[(cy + dy) * nx + cx + dx];
+                    maybe = c >= min_samples;
+                }
+                if (maybe) *flag = 1;
+                __syncthreads();
+                if (*flag == 0) return true;
+                __syncthreads();
+                if (tid == 0) *flag = 0;
+                __syncthreads();
+            }
+        }
+    }
     // tasks (point p, slice `part` of the partners), about four per thread
     int parts = 1024 / U;
     parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
