@@ -89,6 +89,11 @@ def cpu_legs(pts, cnt, dts, tracks, cores, py_scenes, py_frames, c_scenes):
 
 
 PROF_EVERY = 4  # hipEvent-timed steps inside the timed region: one in PROF_EVERY
+# algorithmic bytes per track of the two Kalman kernels: k_predict reads the 1232-byte record
+# prefix, writes P and x (720) and the gate record (352); the update half of k_post reads the prefix and
+# writes P and x
+PREDICT_BYTES_PER_TRACK = 1232 + 720 + 352
+UPDATE_BYTES_PER_TRACK = 1232 + 720
 
 
 def main():
@@ -192,7 +197,7 @@ def main():
         el = float(t.item())
     sb.check()
     stats = sb.stats()
-    prof = {k: sb.profile_get(k) for k in (_lib.K_TRACK, _lib.K_DBSCAN, _lib.K_TABLE)}
+    prof = {k: sb.profile_get(k) for k in (_lib.K_TRACK, _lib.K_DBSCAN, _lib.K_TABLE, _lib.K_PREDICT, _lib.K_POST)}
 
     # ---- secondary: the posture leg on the final state (features kernel -> MARS CNN -> keypoints).
     #      Not part of `value`; reported so configs[3]/[4] (end-to-end) have a measured number. ----
@@ -245,13 +250,20 @@ def main():
 
     if rank == 0:
         total_sf = S * world * K
-        # dominant kernel = larger share of device time
-        ms_t, n_t = prof[_lib.K_TRACK]
-        ms_d, n_d = prof[_lib.K_DBSCAN]
-        dom = _lib.K_TRACK if ms_t >= ms_d else _lib.K_DBSCAN
-        dom_ms, dom_n = prof[dom]
-        dom_bytes = float(stats[0] if dom == _lib.K_TRACK else stats[1])
-        achieved = (dom_bytes / max(dom_n, 1)) / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # per-kernel device time from the sampled HIP-event pairs (one step in PROF_EVERY); algorithmic bytes
+        # from the device counters, which cover all K steps
+        n_samp = max(prof[_lib.K_TRACK][1], 1)
+        step_ms = {k: prof[k][0] / n_samp for k in (_lib.K_PREDICT, _lib.K_TRACK, _lib.K_DBSCAN, _lib.K_POST)}
+        tracks_in = float(stats[5])  # sum over scene-frames of the tracks entering track()
+        step_bytes = {
+            _lib.K_PREDICT: tracks_in * PREDICT_BYTES_PER_TRACK / K,
+            _lib.K_TRACK: float(stats[0]) / K,
+            _lib.K_DBSCAN: float(stats[1]) / K,
+            _lib.K_POST: tracks_in * UPDATE_BYTES_PER_TRACK / K,
+        }
+        dom = max(step_ms, key=step_ms.get)
+        dom_ms, dom_bytes = step_ms[dom], step_bytes[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
@@ -278,15 +290,17 @@ def main():
                 "kernel": _lib.load().mmw_kernel_name(dom).decode(), "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(dom_bytes / max(dom_n, 1), 1),
-                "avg_launch_ms": round(dom_ms / max(dom_n, 1), 5),
+                "algorithmic_bytes_per_launch": round(dom_bytes, 1),
+                "avg_launch_ms": round(dom_ms, 5), "launches_timed": n_samp,
             },
             "kernels": {
-                "k_track": {"launches": n_t, "avg_ms": round(ms_t / max(n_t, 1), 5), "alg_bytes_per_launch": round(float(stats[0]) / max(n_t, 1), 1)},
-                "k_dbscan_spawn": {"launches": n_d, "avg_ms": round(ms_d / max(n_d, 1), 5), "alg_bytes_per_launch": round(float(stats[1]) / max(n_d, 1), 1),
-                                   "dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(float(stats[4]) / max(float(stats[3]), 1), 1)},
-                "gate_evals_per_step": round(float(stats[6]) / K, 1),
+                name: {"avg_ms": round(step_ms[k], 5), "alg_bytes_per_launch": round(step_bytes[k], 1)}
+                for k, name in ((_lib.K_PREDICT, "k_predict"), (_lib.K_TRACK, "k_track"),
+                                (_lib.K_DBSCAN, "k_dbscan_screen(+large clouds)"), (_lib.K_POST, "k_post"))
             },
+            "work": {"dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(float(stats[4]) / max(float(stats[3]), 1), 1),
+                     "gate_evals_per_step": round(float(stats[6]) / K, 1), "tracks_per_scene": round(tracks_in / max(float(stats[2]), 1), 2),
+                     "clusters_found_per_step": round(float(stats[7]) / K, 2)},
             "host": {"cores": cores, "gen_s": round(t_gen, 1)},
         }
         line.update(cpu)

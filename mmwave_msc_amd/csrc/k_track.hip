@@ -57,7 +57,7 @@ struct TrackLds {
     double *p6;      // [6][NP + kTilePad] point columns x,y,z,vx,vy,vz, class-sorted (see the split)
     double *work;    // union: gate[kGateChunk][kGateStride] | point tile + pairwise stack
     double *cen;     // [t_cap][6] centroid of this frame's cloud per track
-    int *cnt;        // [NB][CLS]
+    unsigned short *cnt;  // [NB][CLS] per 64-point block: class counts, then their exclusive prefix (< max_pts <= 1024)
     int *cls_n;      // [CLS]
     int *cls_off;    // [CLS+1]
     long long *seg_dst; // [CLS] where this frame's rows go: track j's ring slot (j < T), the global ring slot (j == T); in doubles
@@ -88,15 +88,21 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     if constexpr (WRITE) L->p6 = (double *)(base + off);
     CARVE(work, double, work_a > work_b ? work_a : work_b)
     CARVE(cen, double, c.t_cap * 6)
-    CARVE(cnt, int, NB *CLS)
+    {   // two lives of one region: [cnt | seg_dst] until the points are parked, [wmm | nest | slot2] afterwards
+        const size_t base_off = off;
+        CARVE(cnt, unsigned short, NB *CLS)
+        CARVE(seg_dst, long long, CLS + 1)
+        const size_t end_a = off;
+        off = base_off;
+        CARVE(wmm, double, kWaves * 24)
+        CARVE(nest, double, c.t_cap)
+        CARVE(slot2, int, c.t_cap)
+        off = off > end_a ? off : end_a;
+    }
     CARVE(cls_n, int, CLS)
     CARVE(cls_off, int, CLS + 1)
-    CARVE(seg_dst, long long, CLS + 1)
-    CARVE(wmm, double, kWaves * 24)
-    CARVE(nest, double, c.t_cap)
     CARVE(ml, int, 2 + 5 * (pw_max_leaves(NP) + 1))
     CARVE(slot, int, c.t_cap)
-    CARVE(slot2, int, c.t_cap)
     CARVE(misc, int, 16)
 #undef CARVE
     return off;
@@ -178,7 +184,7 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 // PPT = points per thread = ceil(max_pts / 256): a template so that per-point registers are not
 // reserved for points a configuration can never have.
 template <int PPT>
-__global__ __launch_bounds__(kThreads, 4) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+__global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out, int parity)
 {

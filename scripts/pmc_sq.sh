@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
   rm -rf gpurun_out/$name
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --scenes 2048 --steps 6 --warmup 6 > $GRAFT_REPO_ROOT/gpurun_out/$name.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --scenes 4096 --steps 6 --warmup 6 > $GRAFT_REPO_ROOT/gpurun_out/$name.log 2>&1)
 }
 PASSES=${@:-sq1 sq2 sq3 sq4 sq5}
 want() { [[ " $PASSES " == *" $1 "* ]]; }
