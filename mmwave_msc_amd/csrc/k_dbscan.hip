@@ -239,14 +239,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     // ---- _recursive_build, level by level (_binary_tree.pxi.tp:1040-1084) ----
     int *idx = L.idx, *idx2 = L.idx2;
     if (ALL8) {
-        // Thread-per-point build: min/max by fire-and-forget LDS atomics, rank by a scan of the
-        // node's keys, stable partition by ballots in lane (= point index) order.
+        // Thread-per-point build: min/max by fire-and-forget LDS atomics, the median split by ONE bitonic sort
+        // of the whole level, stable partition by ballots in lane (= point index) order.
         const int wave = tid >> 6;
-        // spare threads help: thread t works for point (t mod U) on slice (t / U) of `parts` slices
-        const int parts = NT / U > 0 ? NT / U : 1;
-        const int hpart = tid / U, hi = tid - hpart * U;
-        const bool helper = hpart < parts;
-        int *rankc = L.front;   // per-position rank counters (free until labelling)
+        unsigned long long *xh = reinterpret_cast<unsigned long long *>(L.key);  // cross-wave exchange of the sort
+        unsigned *xl = reinterpret_cast<unsigned *>(L.front);                     // (key[] / front[] are free here)
+        unsigned char *leftflag = L.core;                                          // (free until the queries)
         int *posarr = L.next;   // point index -> tree position
         if (tid < U) posarr[tid] = tid;
         for (int level = 0; level + 1 < n_levels; level++) {
@@ -283,34 +281,50 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             if (act) {
                 const int sd = L.sdim[node - first];
                 kp = sd == 0 ? f0 : sd == 1 ? f1 : sd == 2 ? f2 : sd == 3 ? f3 : sd == 4 ? f4 : sd == 5 ? f5 : sd == 6 ? f6 : f7;
-                L.key[mypos] = kp;
-                rankc[mypos] = 0;
                 s = L.nstart[node];
                 e = L.nend[node];
             }
-            __syncthreads();
             DSTAMP(7);  // (diagnostic) split dim + keys
             // partition_node_indices: the n_mid smallest under (value, index) go left
             // (_partition_nodes.pyx:35-39); both halves keep ascending point-index order.
-            bool left = false;
-            if (helper) {  // slice `hpart` of the node of point `hi`
-                const int hp = posarr[hi];
-                const int hnode = node_of(L, hp, level);
-                const int hs = L.nstart[hnode], he = L.nend[hnode], len = he - hs;
-                const int q0 = hs + (int)(((long long)len * hpart) / parts), q1 = hs + (int)(((long long)len * (hpart + 1)) / parts);
-                const double hk = L.key[hp];
-                int c = 0;
-#pragma unroll 4
-                for (int q = q0; q < q1; q++) {
-                    const double kq = L.key[q];
-                    const int iq = idx[q];
-                    c += (kq < hk || (kq == hk && iq < hi)) ? 1 : 0;
+            // Rank under (value, index) inside the node = position after sorting the whole level by
+            // (node, value, index), minus the node's start (the nodes of a level are consecutive position
+            // ranges in node order).  96-bit sort key: node(16) | order-preserving value bits(64) | point(16);
+            // a bitonic network over the NT thread slots, cross-lane inside a wave, through LDS across waves.
+            unsigned long long hi64 = ~0ULL;  // idle slots sort to the end
+            unsigned lo32 = ~0u;
+            if (act) {
+                const unsigned long long sk = sortable(kp);
+                hi64 = ((unsigned long long)node << 48) | (sk >> 16);
+                lo32 = ((unsigned)(sk & 0xffffULL) << 16) | (unsigned)tid;
+            }
+#pragma unroll
+            for (int k = 2; k <= NT; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    unsigned long long ph;
+                    unsigned pl;
+                    if (j >= 64) {
+                        xh[tid] = hi64; xl[tid] = lo32;
+                        __syncthreads();
+                        ph = xh[tid ^ j]; pl = xl[tid ^ j];
+                        __syncthreads();
+                    } else {
+                        ph = __shfl_xor(hi64, j); pl = __shfl_xor(lo32, j);
+                    }
+                    const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+                    const bool pless = ph < hi64 || (ph == hi64 && pl < lo32);  // partner sorts before me
+                    if ((lower == up) ? pless : !pless) { hi64 = ph; lo32 = pl; }  // lower slot keeps the smaller one when ascending
                 }
-                if (parts == 1) rankc[hp] = c; else atomicAdd(&rankc[hp], c);
+            }
+            if (hi64 != ~0ULL) {  // slot `tid` now holds the tid-th element of the level
+                const int snode = (int)(hi64 >> 48), owner = (int)(lo32 & 0xffffu);
+                const int ss = L.nstart[snode], ee = L.nend[snode];
+                leftflag[owner] = (tid - ss) < (ee - ss) / 2 ? 1 : 0;
             }
             __syncthreads();
-            if (act) left = rankc[mypos] < (e - s) / 2;
-            DSTAMP(8);  // (diagnostic) rank scan
+            const bool left = act && leftflag[tid] != 0;
+            DSTAMP(8);  // (diagnostic) rank
             unsigned long long mine = 0;
             for (int nd = 0; nd < nn; nd++) {
                 const unsigned long long b = __ballot(act && left && node == first + nd);
