@@ -89,6 +89,7 @@ def cpu_legs(pts, cnt, dts, tracks, cores, py_scenes, py_frames, c_scenes):
 
 
 PROF_EVERY = 4  # hipEvent-timed steps inside the timed region: one in PROF_EVERY
+OTHER_KERNELS = (5, 1, 6)  # _lib.K_PREDICT, K_DBSCAN, K_POST
 # algorithmic bytes per track of the two Kalman kernels: k_predict reads the 1232-byte record
 # prefix, writes P and x (720) and the gate record (352); the update half of k_post reads the prefix and
 # writes P and x
@@ -180,9 +181,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for f in range(W, F):
-        # HIP-event pairs around the kernels of every 4th step only: each pair costs the stream ~10 us of
-        # idle time, so the live kernel durations come from a sample of the timed launches (>= 10 of them)
-        sb.profile((f - W) % PROF_EVERY == 0)
+        # A HIP-event pair costs the stream ~10 us of idle time, so the live kernel durations come from a
+        # sample of the timed launches: every PROF_EVERY-th step times k_track and, in rotation, one of the
+        # other three kernels of the step
+        if (f - W) % PROF_EVERY == 0:
+            sb.profile(True, kernels=(_lib.K_TRACK, OTHER_KERNELS[((f - W) // PROF_EVERY) % len(OTHER_KERNELS)]))
+        else:
+            sb.profile(False)
         step(f)
     sb.profile(True)
     sb.track_table_dev(d_table.data_ptr(), slots, scene_base=rank * S)
@@ -253,7 +258,9 @@ def main():
         # per-kernel device time from the sampled HIP-event pairs (one step in PROF_EVERY); algorithmic bytes
         # from the device counters, which cover all K steps
         n_samp = max(prof[_lib.K_TRACK][1], 1)
-        step_ms = {k: prof[k][0] / n_samp for k in (_lib.K_PREDICT, _lib.K_TRACK, _lib.K_DBSCAN, _lib.K_POST)}
+        # (k_dbscan_screen and the large-cloud launches are two event pairs of one id per timed step)
+        step_ms = {k: prof[k][0] / max(prof[k][1] / (2 if k == _lib.K_DBSCAN else 1), 1)
+                   for k in (_lib.K_PREDICT, _lib.K_TRACK, _lib.K_DBSCAN, _lib.K_POST)}
         tracks_in = float(stats[5])  # sum over scene-frames of the tracks entering track()
         step_bytes = {
             _lib.K_PREDICT: tracks_in * PREDICT_BYTES_PER_TRACK / K,

@@ -218,6 +218,7 @@ int mmw_stats_reset(mmw_ctx *ctx);
 /* [0..7] as mmw_stats_get; [8..31] per-phase cycle sums, non-zero only in the diagnostic build
  * (make -C mmwave_msc_amd/csrc STAMPS=1), see scripts/phase_stamps.py. */
 int mmw_stats_get_ext(mmw_ctx *ctx, uint64_t *out /*[32]*/);
+/* on = 0: off; 1: every kernel id; otherwise a mask, bit (k + 1) selects kernel id k.  Does not synchronise. */
 int mmw_profile_enable(mmw_ctx *ctx, int32_t on);
 int mmw_profile_reset(mmw_ctx *ctx);
 int mmw_profile_get(mmw_ctx *ctx, int32_t kernel_id, double *total_ms, int64_t *launches);   /* sync */

@@ -240,8 +240,15 @@ class SceneBatch:
     def stats_reset(self):
         self._chk(self.L.mmw_stats_reset(self.h))
 
-    def profile(self, on: bool):
-        self._chk(self.L.mmw_profile_enable(self.h, 1 if on else 0))
+    def profile(self, on, kernels=None):
+        """HIP-event timing of the kernels: all of them (on=True), none (on=False), or the ids in `kernels`."""
+        mask = 0
+        if kernels is not None:
+            for k in kernels:
+                mask |= 2 << int(k)
+        elif on:
+            mask = 1
+        self._chk(self.L.mmw_profile_enable(self.h, mask))
 
     def profile_reset(self):
         self._chk(self.L.mmw_profile_reset(self.h))

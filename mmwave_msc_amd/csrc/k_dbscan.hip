@@ -811,24 +811,6 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
     }
 }
 
-// Persistent over work list `cls` (0..2 = size classes filled by k_track, 3 = class-0 scenes that the
-// screen could not rule out): workgroups that find nothing to do leave at once, so an empty or short
-// list costs one small wave of workgroups instead of n_scenes large-LDS ones.
-template <int NT, bool ALL8>
-__global__ __launch_bounds__(NT) void k_dbscan_spawn(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int cls,
-                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    DbLds L;
-    db_lds_layout<true>(UMc, CL, ALL8, lds_raw, &L);
-    const int count = st.db_count[parity * 4 + cls];
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
-        spawn_scene<NT, ALL8>(cfg, st, L, s, UMc, CL, UM_out, cls == 3, labels_out, db_n_out);
-        __syncthreads();  // LDS is reused by the next scene
-    }
-}
-
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
 //   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
 //                    <= 256 points the screen could not rule out): a handful of scenes per step, each a
@@ -859,6 +841,26 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     if (unit >= cfg.n_scenes * nq) return;
     const int s = unit / nq, q = unit - s * nq;
     update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch);
+}
+
+// Work lists 1 and 2 (clouds of more than 256 points: the start-up frames of a scene) in one launch: blocks
+// [0, g1) take list 1 with the class-1 LDS carve-up, the others list 2.  In the steady state both lists
+// are empty and this is one small wave of workgroups that leave at once.
+__global__ __launch_bounds__(256) void k_dbscan_big(DevCfg cfg, DevState st, int g1, int UMc1, int CL1, int UMc2, int CL2, int UM_out,
+                                                    int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const bool first = (int)blockIdx.x < g1;
+    const int cls = first ? 1 : 2, UMc = first ? UMc1 : UMc2, CL = first ? CL1 : CL2;
+    const int b0 = first ? blockIdx.x : blockIdx.x - g1, nb = first ? g1 : (int)gridDim.x - g1;
+    DbLds L;
+    db_lds_layout<true>(UMc, CL, false, lds_raw, &L);
+    const int count = st.db_count[parity * 4 + cls];
+    for (int w = b0; w < count; w += nb) {
+        const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
+        spawn_scene<256, false>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
+        __syncthreads();  // LDS is reused by the next scene
+    }
 }
 
 // Utils.apply_DBscan on caller-provided clouds: pts[S][max_n][8]
@@ -913,7 +915,7 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     if (e != hipSuccess) return e;
     size_t big = dbscan_lds_bytes(1, UM, t_cap, min_samples);
     if (dbscan_lds_bytes(2, UM, t_cap, min_samples) > big) big = dbscan_lds_bytes(2, UM, t_cap, min_samples);
-    e = hipFuncSetAttribute((const void *)k_dbscan_spawn<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+    e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
 }
@@ -937,22 +939,22 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
     else hipLaunchKernelGGL(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
 }
 
-// The larger clouds (work lists 1 and 2; the start-up frames of a scene): one launch per size class that
-// can occur (class c exists when its lower bound < UM).
+// The larger clouds (work lists 1 and 2; the start-up frames of a scene): k_dbscan_big.
 void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
+    if (kClassUM[0] >= UM) return;  // no cloud can exceed the small class
     const int S = cfg.n_scenes;
-    for (int cls = 1; cls < 3; cls++) {
-        if (kClassUM[cls - 1] >= UM) break;
-        const int umc = dbscan_class_um(cls, UM), cl = dbscan_class_cl(cls, UM, cfg.t_cap, cfg.db_min_samples);
-        const size_t lds = dbscan_lds_bytes(cls, UM, cfg.t_cap, cfg.db_min_samples);
-        int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));  // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
-        int grid = 256 * per_cu;
-        if (grid > S) grid = S;
-        hipLaunchKernelGGL((k_dbscan_spawn<256, false>), dim3(grid), dim3(256), lds, stream, cfg, st, umc, cl, UM, parity, cls, labels, db_n);
-    }
+    const bool two = kClassUM[1] < UM;
+    const int um1 = dbscan_class_um(1, UM), cl1 = dbscan_class_cl(1, UM, cfg.t_cap, cfg.db_min_samples);
+    const int um2 = dbscan_class_um(2, UM), cl2 = dbscan_class_cl(2, UM, cfg.t_cap, cfg.db_min_samples);
+    const size_t lds1 = dbscan_lds_bytes(1, UM, cfg.t_cap, cfg.db_min_samples), lds2 = two ? dbscan_lds_bytes(2, UM, cfg.t_cap, cfg.db_min_samples) : 0;
+    const size_t lds = lds1 > lds2 ? lds1 : lds2;
+    int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));  // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    int g = 256 * per_cu;
+    if (g > S) g = S;
+    hipLaunchKernelGGL(k_dbscan_big, dim3(two ? 2 * g : g), dim3(256), lds, stream, cfg, st, g, um1, cl1, um2, cl2, UM, parity, labels, db_n);
 }
 
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,

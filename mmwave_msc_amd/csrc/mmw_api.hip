@@ -62,7 +62,7 @@ struct mmw_ctx {
     int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr;
     mmw_track_record *d_export = nullptr; int export_cap = 0;
     // profiling
-    bool prof = false;
+    unsigned prof_mask = 0;           // bit k: time kernel id k (mmw_profile_enable)
     std::vector<EventPair> pending;
     std::vector<EventPair> pool;
     double tot_ms[MMW_K_COUNT] = {0};
@@ -89,7 +89,8 @@ static int fail(mmw_ctx *ctx, int code, const char *fmt, ...)
 
 static void prof_begin(mmw_ctx *c, int kid, EventPair &ep)
 {
-    if (!c->prof) return;
+    ep.kid = -1;
+    if (!((c->prof_mask >> kid) & 1u)) return;
     if (!c->pool.empty()) { ep = c->pool.back(); c->pool.pop_back(); }
     else { hipEventCreate(&ep.a); hipEventCreate(&ep.b); }
     ep.kid = kid;
@@ -107,7 +108,7 @@ static void prof_fold(mmw_ctx *c)
 }
 static void prof_end(mmw_ctx *c, EventPair &ep)
 {
-    if (!c->prof) return;
+    if (ep.kid < 0) return;
     hipEventRecord(ep.b, c->stream);
     c->pending.push_back(ep);
     if (c->pending.size() >= 2048) prof_fold(c);
@@ -595,8 +596,7 @@ int mmw_stats_reset(mmw_ctx *c)
 int mmw_profile_enable(mmw_ctx *c, int32_t on)
 {
     if (!c) return MMW_E_ARG;
-    if (!on) { hipStreamSynchronize(c->stream); prof_fold(c); }
-    c->prof = on != 0;
+    c->prof_mask = (on & 1) ? ~0u : ((unsigned)on >> 1);  // no synchronisation here: mmw_profile_get folds the pending pairs
     return MMW_OK;
 }
 int mmw_profile_reset(mmw_ctx *c)
