@@ -650,46 +650,6 @@ __device__ __forceinline__ void finish_scene_stats(const DevState &st, int s, in
     }
 }
 
-// First stage of apply_DBscan for every scene k_track flagged (hdr->need_db), one small workgroup per
-// scene.  Clouds of U <= 256 points (the steady state: a ring of clutter) get the exact "no point can be
-// a core point" test (cloud_has_no_core, mmw_cloud.hpp) in a small-footprint kernel (5 KiB LDS, 8
-// workgroups per CU), so that the BallTree kernel with its 512 threads and large LDS carve-up only
-// starts for scenes that may really hold a cluster.  Scenes that pass are finished here (labels -1,
-// need_db cleared); the others go to work list 3, larger clouds to the work list of their size class.
-__global__ __launch_bounds__(256) void k_dbscan_screen(DevCfg cfg, DevState st, int UM_out, int parity,
-                                                      int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
-{
-    __shared__ float4 P4[256];
-    __shared__ int cnt[256];
-    __shared__ unsigned long long mm[5];
-    __shared__ int flag;
-    __shared__ int grid[kCloudGrid];
-    const int tid = threadIdx.x;
-    const int s = blockIdx.x;
-    SceneHdr *hdr = st.hdr + s;
-    if (!hdr->need_db) return;
-    const int U = hdr->db_u;
-    bool tree = true;
-    if (U <= 256) tree = !cloud_has_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, &flag, grid);
-    if (tree) {
-        if (tid == 0) {
-            const int cls = U <= 256 ? 3 : (U <= 768 ? 1 : 2);
-            const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
-            st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
-        }
-        return;
-    }
-    if (labels_out && tid < U) labels_out[(size_t)s * UM_out + tid] = -1;
-    if (tid == 0) {
-        if (db_n_out) db_n_out[s] = U;
-        hdr->need_db = 0;
-        finish_scene_stats(st, s, U, 0);
-#ifdef MMW_STAMPS
-        if (st.stats) atomicAdd(&stats_slot(st, s)[31], 1ULL);
-#endif
-    }
-}
-
 template <int NT, bool ALL8>
 __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &st, const DbLds &L, int s, int UMc, int CL, int UM_out,
                                             bool screened, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
@@ -813,8 +773,9 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
 
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
 //   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
-//                    <= 256 points the screen could not rule out): a handful of scenes per step, each a
-//                    latency chain of ~60 us that would otherwise leave the chip idle;
+//                    <= 256 points k_track's cell count could not rule out): the exact pair count, then for
+//                    the handful of scenes per step that survive it the BallTree, a latency chain of ~60 us
+//                    that would otherwise leave the chip idle;
 //   the others       _update_all (Tracking.py:598-603) of four (scene, quarter) units each, one wave per unit
 //                    (update_tracks_wave, mmw_kalman.hpp) -- the bulk work the BallTree scenes hide under.
 // The two touch disjoint state: the update covers the hdr->n_upd tracks that existed before this frame's
@@ -829,9 +790,21 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
         DbLds L;
         db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
         const int count = st.db_count[parity * 4 + 3];
+        // screen scratch behind the BallTree carve-up (post_lds_bytes reserves it)
+        char *scr = lds_raw + db_align16(db_lds_layout<false>(UMc, CL, true, nullptr, nullptr));
+        float4 *P4 = reinterpret_cast<float4 *>(scr);
+        int *cnt = reinterpret_cast<int *>(scr + 4096), *grid = cnt + 256, *flag = grid + kCloudGrid;
+        unsigned long long *mm = reinterpret_cast<unsigned long long *>(flag + 2);
         for (int w = blockIdx.x; w < count; w += G0) {
             const int s = st.db_list[(size_t)3 * cfg.n_scenes + w];
-            spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, labels_out, db_n_out);
+            SceneHdr *hdr = st.hdr + s;
+            const int U = hdr->db_u;
+            // k_track's cell count left this cloud undecided: the exact pair count first (mmw_cloud.hpp), the
+            // BallTree only if a core point is still possible
+            if (cloud_has_no_core<2>(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag, grid))
+                cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
+            else
+                spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, labels_out, db_n_out);
             __syncthreads();  // LDS is reused by the next scene
         }
         return;
@@ -903,7 +876,8 @@ size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false,
 
 static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
 {
-    const size_t upd = (size_t)4 * 4 * kUpdScratch * sizeof(double), db = dbscan_lds_bytes(0, UM, t_cap, min_samples);
+    const size_t upd = (size_t)4 * 4 * kUpdScratch * sizeof(double);
+    const size_t db = db_align16(dbscan_lds_bytes(0, UM, t_cap, min_samples)) + 4096 + (256 + kCloudGrid + 2) * 4 + 5 * 8 + 16;  // + screen scratch
     return upd > db ? upd : db;
 }
 
@@ -918,11 +892,6 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
-}
-
-void launch_dbscan_screen(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_dbscan_screen, dim3(cfg.n_scenes), dim3(256), 0, stream, cfg, st, UM, parity, labels, db_n);
 }
 
 // _update_all + the BallTree DBSCAN of the small clouds (work list 3)

@@ -14,6 +14,7 @@
 
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
+#include "mmw_cloud.hpp"
 
 namespace mmw {
 
@@ -77,7 +78,7 @@ template <bool WRITE>
 __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
 {
     const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
-    // One region, three lives: (1) gate matrices + per-wave scratch while tracks are predicted and
+    // One region, four lives: (1) gate matrices + per-wave scratch while tracks are predicted and
     // points gated (points sit in registers then); (2) the SoA point tile + the pairwise-sum stack
     // while cluster statistics are formed; (3) per-wave scratch again for the Kalman update.
     const int work_a = kGateChunk * kGateStride, work_b = 6 * (NP + kTilePad) + pw_max_leaves(NP) * 21;
@@ -86,7 +87,9 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     if constexpr (WRITE) L->field = (type *)(base + off);    \
     off = align16(off + sizeof(type) * (size_t)(count));
     if constexpr (WRITE) L->p6 = (double *)(base + off);
-    CARVE(work, double, work_a > work_b ? work_a : work_b)
+    const int work_c = (4096 + kCloudGrid * 4 + 64) / 8;  // (4) the DBSCAN cell-count screen at the very end
+    const int work_ab = work_a > work_b ? work_a : work_b;
+    CARVE(work, double, work_ab > work_c ? work_ab : work_c)
     CARVE(cen, double, c.t_cap * 6)
     {   // two lives of one region: [cnt | seg_dst] until the points are parked, [wmm | nest | slot2] afterwards
         const size_t base_off = off;
@@ -186,7 +189,8 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 template <int PPT>
 __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
-                                                    int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out, int parity)
+                                                    int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out,
+                                                    int32_t *__restrict__ db_labels_out, int UM_out, int parity)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     TrackLds L;
@@ -386,6 +390,30 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
         lds_barrier();
     }
     STAMP(3);  // class split
+    // ---- batch.add_frame(unassigned) on the global ring (Tracking.py:689-691), early: the DBSCAN screen at the
+    //      end of the kernel wants the older frames' rows, and their loads can be in flight during the phases
+    //      in between.  (The split above was the last reader of the ring state before this frame.) ----
+    if (tid == kThreads - 1) {
+        int len = hdr->g_len;
+        int *gs = L.misc + 4, *gn = L.misc + 8;  // small indexed arrays live in LDS, not in scratch
+        for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
+        while (len >= cfg.ring) {
+            const int first = gs[0];
+            for (int k = 1; k < len; k++) { gs[k - 1] = gs[k]; gn[k - 1] = gn[k]; }
+            gs[len - 1] = first;
+            len--;
+        }
+        gn[len] = L.cls_n[0];
+        L.misc[1] = gs[len];
+        len++;
+        int U = 0;
+        for (int k = 0; k < len; k++) U += gn[k];
+        for (int k = 0; k < MMW_RING_MAX; k++) { hdr->g_slot[k] = gs[k]; hdr->g_n[k] = k < len ? gn[k] : 0; }
+        hdr->g_len = len;
+        hdr->db_u = U;
+        L.misc[3] = len;
+        L.misc[13] = U;
+    }
     PROBE(3);
 
     // ---- associate_pointcloud (Tracking.py:314-341): PointCluster stats, N_est, spread_est.
@@ -518,6 +546,28 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
     lds_barrier();
     STAMP(4);  // centroid/min/max/spread
     PROBE(4);
+    // this thread's point of the DBSCAN cloud (the global ring, oldest frame first), for the screen at the end:
+    // older frames from global memory (requested now), this frame's unassigned rows from the tile, where
+    // they are the first run
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    {
+        const int Ucl = L.misc[13], nun = L.cls_n[0];
+        if (Ucl <= 256 && tid < Ucl) {
+            const int old_n = Ucl - nun;  // rows of the older frames
+            if (tid >= old_n) {
+                const int k = tid - old_n;
+                sx = L.p6[0 * NPs + k]; sy = L.p6[1 * NPs + k]; sz = L.p6[2 * NPs + k];
+            } else {
+                const int *gs = L.misc + 4, *gn = L.misc + 8;
+                int f = 0, base = 0;  // frame of row `tid`
+#pragma unroll
+                for (int k = 0; k < MMW_RING_MAX - 1; k++) if (tid >= base + gn[f] && f < L.misc[3] - 2) { base += gn[f]; f++; }
+                const double *r = st.g_ring + ((size_t)s * cfg.ring + gs[f]) * (size_t)NP * 8 + (size_t)(tid - base) * 8;
+                const double2 a = *reinterpret_cast<const double2 *>(r);
+                sx = a.x; sy = a.y; sz = r[2];
+            }
+        }
+    }
     // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136)
     // (the LAST wave does it: the dispersion items below fill the waves from the front, and this is a chain of
     //  global round trips)
@@ -603,6 +653,11 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
     }
     STAMP(5);  // dispersion matrices (wave 0's share)
     __syncthreads();  // full fence: maintenance reads is_static / lifetime other threads stored to the records
+    {   // the point tile is dead from here on: clear the cell grid of the DBSCAN screen at the end of the kernel
+        int *grid = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 4096);
+        for (int i = tid; i < kCloudGrid; i += kThreads) grid[i] = 0;
+        if (tid == 0) { grid[kCloudGrid] = 0; grid[kCloudGrid + 1] = 0; L.misc[12] = 0; }  // (mm[0] behind the grid)
+    }
     STAMP(6);  // track ring rows + barrier (includes waiting for the other waves' dispersion work)
 
     // ---- _maintain_tracks (Tracking.py:513-528) ----
@@ -636,33 +691,39 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
 
     // (_update_all, Tracking.py:598-603, runs as its own batched kernel right after this one: k_update)
     STAMP(8);  // update
-    // ---- batch.add_frame(unassigned) on the global ring + DBSCAN trigger (Tracking.py:689-697) ----
-    const int nun = L.cls_n[0];
+    // ---- DBSCAN trigger (Tracking.py:693-697) ----
     if (tid == 0) {
-        int len = hdr->g_len;
-        int *gs = L.misc + 4, *gn = L.misc + 8;  // small indexed arrays live in LDS, not in scratch
-        for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
-        while (len >= cfg.ring) {
-            const int first = gs[0];
-            for (int k = 1; k < len; k++) { gs[k - 1] = gs[k]; gn[k - 1] = gn[k]; }
-            gs[len - 1] = first;
-            len--;
-        }
-        gn[len] = nun;
-        L.misc[1] = gs[len];
-        len++;
-        int U = 0;
-        for (int k = 0; k < len; k++) U += gn[k];
-        for (int k = 0; k < MMW_RING_MAX; k++) { hdr->g_slot[k] = gs[k]; hdr->g_n[k] = k < len ? gn[k] : 0; }
-        hdr->g_len = len;
+        const int U = L.misc[13];
         hdr->n_tracks = T;
         hdr->n_upd = T;
-        hdr->db_u = U;
         const bool need = U > 0 && T < cfg.tr_max_tracks;
-        hdr->need_db = need ? 1 : 0;  // picked up by k_dbscan_screen (k_dbscan.hip)
+        hdr->need_db = need ? 1 : 0;
+        L.misc[2] = need ? U : 0;
     }
     if (err) atomicOr(&hdr->err, err);
     STAMP(9);  // global ring append
+    // ---- apply_DBscan, first stage (Tracking.py:697, Utils.py:250-291).  The steady state is a ring of
+    //      clutter in which no point can be a core point; for most scenes an O(U) cell count proves it
+    //      (cloud_cells_prove_no_core, mmw_cloud.hpp) on the rows this workgroup has just appended, and the scene is
+    //      finished with all labels -1.  The others go to the work lists of k_post / k_dbscan_big. ----
+    lds_barrier();
+    const int Udb = L.misc[2];
+    if (Udb > 0) {  // uniform
+        bool listed = true;
+        if (Udb <= 256) {
+            int *grid = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 4096);  // (cleared after the fence above)
+            listed = !cloud_cells_prove_no_core(cfg, Udb, sx, sy, sz, reinterpret_cast<unsigned long long *>(grid + kCloudGrid), &L.misc[12], grid);
+        }
+        if (listed) {
+            if (tid == 0) {  // work list 3: clouds <= 256 points (k_post), 1 and 2: larger ones (k_dbscan_big)
+                const int cls = Udb <= 256 ? 3 : (Udb <= 768 ? 1 : 2);
+                const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
+                st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
+            }
+        } else {
+            cloud_finish_empty(st, hdr, s, Udb, UM_out, db_labels_out, db_n_out);
+        }
+    }
     PROBE(9);
     if (tid == 0 && st.stats) {
         // algorithmic bytes of this scene-frame: points in, assoc out, per track the gate record
@@ -671,7 +732,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
         int ring_rows = 0;
         for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
         unsigned long long *sl = stats_slot(st, s);
-        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * nun + 64 * ring_rows));
+        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * L.cls_n[0] + 64 * ring_rows));
         atomicAdd(&sl[2], 1ULL);
         atomicAdd(&sl[5], (unsigned long long)Tin);
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);
@@ -680,18 +741,19 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
 
 template <int PPT>
 static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
-                           int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream)
+                           int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_track<PPT>), dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, parity);
+    hipLaunchKernelGGL((k_track<PPT>), dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
+                       db_labels, UM, parity);
 }
 
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
-                  int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream)
+                  int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
     const int ppt = (cfg.max_pts + kThreads - 1) / kThreads;
-    if (ppt <= 1) launch_track_t<1>(cfg, st, pts, n_pts, dt, assoc, db_n, parity, stream);
-    else if (ppt == 2) launch_track_t<2>(cfg, st, pts, n_pts, dt, assoc, db_n, parity, stream);
-    else launch_track_t<4>(cfg, st, pts, n_pts, dt, assoc, db_n, parity, stream);
+    if (ppt <= 1) launch_track_t<1>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else if (ppt == 2) launch_track_t<2>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else launch_track_t<4>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
 }
 
 hipError_t prepare_track(const DevCfg &cfg)

@@ -17,11 +17,10 @@ hipError_t prepare_track(const DevCfg &cfg);
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, hipStream_t stream);
 void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
-                  int32_t *assoc, int32_t *db_n, int parity, hipStream_t stream);
+                  int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
 size_t dbscan_only_lds_bytes(int UM);
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples);
-void launch_dbscan_screen(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
@@ -120,7 +119,7 @@ const char *mmw_version(void) { return "mmw-hip 0.1 (gfx950)"; }
 
 const char *mmw_kernel_name(int32_t k)
 {
-    static const char *names[MMW_K_COUNT] = {"k_track", "k_dbscan_screen", "k_features", "k_normalize", "k_table", "k_predict", "k_post"};
+    static const char *names[MMW_K_COUNT] = {"k_track", "k_dbscan_big", "k_features", "k_normalize", "k_table", "k_predict", "k_post"};
     return (k >= 0 && k < MMW_K_COUNT) ? names[k] : "?";
 }
 
@@ -329,15 +328,12 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     if (((uintptr_t)pts & 15) != 0) return fail(c, MMW_E_ARG, "mmw_step: pts must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
-    // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream (+ one per large-cloud class):
+    // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
     prof_begin(c, MMW_K_PREDICT, ep);
     launch_predict(c->dc, c->st, n_pts, dt, c->stream);
     prof_end(c, ep);
     prof_begin(c, MMW_K_TRACK, ep);
-    launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, c->step_parity, c->stream);
-    prof_end(c, ep);
-    prof_begin(c, MMW_K_DBSCAN, ep);
-    launch_dbscan_screen(c->dc, c->st, c->UM, c->step_parity, db_labels, db_n, c->stream);
+    launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
     prof_end(c, ep);
     prof_begin(c, MMW_K_POST, ep);
     launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, db_labels, db_n, c->stream);
