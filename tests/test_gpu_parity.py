@@ -114,6 +114,60 @@ def test_multi_scene_vs_oracle():
     sb.close()
 
 
+@pytest.mark.parametrize("case", [
+    dict(db_min_samples=4, db_eps=0.05),                       # cores appear and vanish inside plain clutter
+    dict(db_min_samples=6, db_eps=0.12),
+    dict(db_min_samples=12, db_eps=0.3, db_z_weight=0.0),      # z ignored by the metric
+    dict(db_min_samples=8, db_eps=0.2, db_range_weight=-0.02), # the weight grows with range
+    dict(db_min_samples=5, db_eps=0.1, scale=6.0),             # clutter spread over tens of metres: the cell torus wraps
+    dict(db_min_samples=3, db_eps=0.02, tr_max_tracks=2),
+])
+def test_dbscan_screen_decisions_vs_oracle(case):
+    """The no-core-point screens (cell count in k_track, pair count in k_post) only ever skip a BallTree run
+    whose result is "all noise".  Configurations that put many scenes right at the boundary between "a core
+    point exists" and "none does": labels, cluster spawns and every later frame must equal the oracle."""
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    case = dict(case)
+    scale = case.pop("scale", 1.0)
+    S, N, F = 48, 128, 10
+    kw = dict(tr_max_tracks=3)
+    kw.update(case)
+    sb = _mk(S, N, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    pts = np.zeros((F, S, N, 8), np.float32)
+    cnt = np.zeros((F, S), np.int32)
+    dts = np.zeros((F, S))
+    for s in range(S):
+        p, c, d = make_batch([9100 + s], F, N, s % 3, ragged=(s % 4 == 1))
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    if scale != 1.0:
+        pts[..., 0] *= scale
+        pts[..., 1] = np.minimum(pts[..., 1] * scale, 30.0).astype(np.float32)  # keep 1 - range_w * y positive
+    n_db = n_clustered = 0
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=16)
+        for s in range(S):
+            c = cnt[f, s]
+            oa, ol = scenes[s].track(pts[f, s, :c].astype(np.float64), dts[f, s])
+            assert np.array_equal(assoc[s, :c], oa), (f, s)
+            assert (ol is None) == (dbn[s] < 0), (f, s)
+            if ol is not None:
+                n_db += 1
+                n_clustered += int(ol.max() >= 0)
+                assert dbn[s] == len(ol), (f, s)
+                assert np.array_equal(labels[s, : dbn[s]], ol), (f, s, case)
+            assert ntr[s] == scenes[s].n_tracks, (f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
+    sb.check()
+    sb.close()
+    # the case is only meaningful if both outcomes occur
+    assert n_db > 50 and 0 < n_clustered < n_db, (n_db, n_clustered)
+
+
 def test_normalize_golden_and_oracle():
     from oracle import c_oracle as co
     z = np.load(os.path.join(GOLDEN, "normalize.npz"))
