@@ -258,8 +258,7 @@ def main():
         # per-kernel device time from the sampled HIP-event pairs (one step in PROF_EVERY); algorithmic bytes
         # from the device counters, which cover all K steps
         n_samp = max(prof[_lib.K_TRACK][1], 1)
-        # (k_dbscan_screen and the large-cloud launches are two event pairs of one id per timed step)
-        step_ms = {k: prof[k][0] / max(prof[k][1] / (2 if k == _lib.K_DBSCAN else 1), 1)
+        step_ms = {k: prof[k][0] / max(prof[k][1], 1)
                    for k in (_lib.K_PREDICT, _lib.K_TRACK, _lib.K_DBSCAN, _lib.K_POST)}
         tracks_in = float(stats[5])  # sum over scene-frames of the tracks entering track()
         step_bytes = {
@@ -303,7 +302,7 @@ def main():
             "kernels": {
                 name: {"avg_ms": round(step_ms[k], 5), "alg_bytes_per_launch": round(step_bytes[k], 1)}
                 for k, name in ((_lib.K_PREDICT, "k_predict"), (_lib.K_TRACK, "k_track"),
-                                (_lib.K_DBSCAN, "k_dbscan_screen(+large clouds)"), (_lib.K_POST, "k_post"))
+                                (_lib.K_DBSCAN, "k_dbscan_big"), (_lib.K_POST, "k_post"))
             },
             "work": {"dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(float(stats[4]) / max(float(stats[3]), 1), 1),
                      "gate_evals_per_step": round(float(stats[6]) / K, 1), "tracks_per_scene": round(tracks_in / max(float(stats[2]), 1), 2),

@@ -191,7 +191,7 @@ int mmw_get_batch_ring_frame(mmw_ctx *ctx, int32_t scene, int32_t k, double *out
 int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32_t scene_base);
 
 /* Kernel timing with hipEvents on the context's stream (bench.py roofline).
- * ids: 0 k_track (association), 1 k_dbscan_screen + the BallTree launches of large clouds, 2 features,
+ * ids: 0 k_track (association + DBSCAN cell-count screen), 1 k_dbscan_big (BallTree DBSCAN of large clouds), 2 features,
  * 3 normalize, 4 table, 5 k_predict, 6 k_post (Kalman update + BallTree DBSCAN of small clouds). */
 #define MMW_K_TRACK 0
 #define MMW_K_DBSCAN 1
