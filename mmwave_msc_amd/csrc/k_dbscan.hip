@@ -787,6 +787,31 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     if ((int)blockIdx.x < G0) {
         __builtin_amdgcn_s_setprio(3);  // the latency chain goes first whenever it has an instruction ready
+        if ((int)blockIdx.x == G0 - 1) {
+            // (the worker least likely to have a scene) next frame's schedule for k_track: scenes by descending
+            // track count -- a counting sort over the scene headers; the order inside a count is irrelevant
+            int *hist = reinterpret_cast<int *>(lds_raw);  // [t_cap + 2]
+            const int nb = cfg.t_cap + 1;
+            for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
+            __syncthreads();
+            for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
+                int t = st.hdr[s].n_tracks;
+                t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
+                atomicAdd(&hist[nb - 1 - t], 1);  // bin 0 = most tracks
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int run = 0;
+                for (int b = 0; b < nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
+            }
+            __syncthreads();
+            for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
+                int t = st.hdr[s].n_tracks;
+                t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
+                st.perm[atomicAdd(&hist[nb - 1 - t], 1)] = s;
+            }
+            __syncthreads();
+        }
         DbLds L;
         db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
         const int count = st.db_count[parity * 4 + 3];
@@ -812,7 +837,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     const int wave = threadIdx.x >> 6;
     const int unit = ((int)blockIdx.x - G0) * 4 + wave;
     if (unit >= cfg.n_scenes * nq) return;
-    const int s = unit / nq, q = unit - s * nq;
+    const int s = unit / nq, q = unit - s * nq;  // (not st.perm: a worker block of this launch is rewriting it)
     update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch);
 }
 

@@ -209,6 +209,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
     ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
+    ALLOC(c->st.perm, S * sizeof(int32_t));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
     c->st.stats = c->d_stats;
@@ -239,7 +240,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
