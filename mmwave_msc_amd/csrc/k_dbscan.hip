@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
                 int t = st.hdr[s].n_tracks;
                 t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
-                st.perm[atomicAdd(&hist[nb - 1 - t], 1)] = s;
+                st.perm[(size_t)(parity ^ 1) * cfg.n_scenes + atomicAdd(&hist[nb - 1 - t], 1)] = s;
             }
             __syncthreads();
         }
@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     const int wave = threadIdx.x >> 6;
     const int unit = ((int)blockIdx.x - G0) * 4 + wave;
     if (unit >= cfg.n_scenes * nq) return;
-    const int s = unit / nq, q = unit - s * nq;  // (not st.perm: a worker block of this launch is rewriting it)
+    const int us = unit / nq, q = unit - us * nq;
+    const int s = st.perm[(size_t)parity * cfg.n_scenes + us];  // this step's schedule (the worker above writes the next one)
     update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch);
 }
 

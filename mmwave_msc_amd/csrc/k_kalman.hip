@@ -23,10 +23,11 @@ namespace mmw {
 // that every dot product below is fully unrolled with constant LDS offsets.
 template <int DX>
 __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts,
-                                                const double *__restrict__ dt_all, int nq)
+                                                const double *__restrict__ dt_all, int nq, int parity)
 {
     __shared__ double lds[4 * kPredScratch];
-    const int s = blockIdx.x / nq, q = blockIdx.x - s * nq;
+    const int us = blockIdx.x / nq, q = blockIdx.x - us * nq;
+    const int s = st.perm[(size_t)parity * cfg.n_scenes + us];  // heaviest scenes first (see k_track)
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int n = n_pts[s];
     if (n <= 0 || n > cfg.max_pts) return;  // offline_main.py:56: empty frames never reach track()
@@ -123,11 +124,11 @@ static int waves_per_scene(const DevCfg &cfg)
     return nq < 1 ? 1 : nq;
 }
 
-void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, hipStream_t stream)
+void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream)
 {
     const int nq = waves_per_scene(cfg);
-    if (cfg.dx == 9) hipLaunchKernelGGL(k_predict<9>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq);
-    else hipLaunchKernelGGL(k_predict<6>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq);
+    if (cfg.dx == 9) hipLaunchKernelGGL(k_predict<9>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
+    else hipLaunchKernelGGL(k_predict<6>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
 }
 
 }  // namespace mmw

@@ -260,6 +260,7 @@ __global__ void k_reset(DevCfg cfg, DevState st)
         h->next_uid = 0;
         h->n_upd = 0;
         st.perm[g] = g;
+        st.perm[cfg.n_scenes + g] = g;
     }
     const size_t tot = (size_t)cfg.n_scenes * cfg.t_cap;
     for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);

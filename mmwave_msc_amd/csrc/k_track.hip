@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, 
 
     // Workgroups are dispatched in index order, so the order of the scenes is a schedule: st.perm lists the
     // scenes with the most tracks (the longest workgroups) first, which shortens the tail of the launch.
-    const int s = st.perm[blockIdx.x];
+    const int s = st.perm[(size_t)parity * cfg.n_scenes + blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     // The single-wave job below (track maintenance) goes to wave `role == 0`, rotated by scene so that the

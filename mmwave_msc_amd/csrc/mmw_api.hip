@@ -14,7 +14,7 @@
 namespace mmw {
 size_t track_lds_bytes(const DevCfg &c);
 hipError_t prepare_track(const DevCfg &cfg);
-void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, hipStream_t stream);
+void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream);
 void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
@@ -209,7 +209,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
     ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
-    ALLOC(c->st.perm, S * sizeof(int32_t));
+    ALLOC(c->st.perm, 2 * S * sizeof(int32_t));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
     c->st.stats = c->d_stats;
@@ -331,7 +331,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     EventPair ep;
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
     prof_begin(c, MMW_K_PREDICT, ep);
-    launch_predict(c->dc, c->st, n_pts, dt, c->stream);
+    launch_predict(c->dc, c->st, n_pts, dt, c->step_parity, c->stream);
     prof_end(c, ep);
     prof_begin(c, MMW_K_TRACK, ep);
     launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);

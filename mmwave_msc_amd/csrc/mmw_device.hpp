@@ -87,7 +87,7 @@ struct DevState {
     unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
     int32_t *db_list;              // [4][S] scenes whose apply_DBscan needs the BallTree this step: size classes 0..2 (list 3 = class 0), built by k_dbscan_screen
     int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
-    int32_t *perm;                 // [S] scene handled by workgroup b of k_track: heaviest scenes (most tracks) first (k_post builds it)
+    int32_t *perm;                 // [2][S] by step parity: scene handled by unit b of k_predict / k_track / k_post, heaviest scenes (most tracks) first; k_post builds the next step's
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
 };
 
