@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
         // screen scratch behind the BallTree carve-up (post_lds_bytes reserves it)
         char *scr = lds_raw + db_align16(db_lds_layout<false>(UMc, CL, true, nullptr, nullptr));
         float4 *P4 = reinterpret_cast<float4 *>(scr);
-        int *cnt = reinterpret_cast<int *>(scr + 4096), *grid = cnt + 256, *flag = grid + kCloudGrid;
+        int *cnt = reinterpret_cast<int *>(scr + 4096), *flag = cnt + 256;
         unsigned long long *mm = reinterpret_cast<unsigned long long *>(flag + 2);
         for (int w = blockIdx.x; w < count; w += G0) {
             const int s = st.db_list[(size_t)3 * cfg.n_scenes + w];
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             const int U = hdr->db_u;
             // k_track's cell count left this cloud undecided: the exact pair count first (mmw_cloud.hpp), the
             // BallTree only if a core point is still possible
-            if (cloud_has_no_core<2>(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag, grid))
+            if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
                 cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
             else
                 spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, labels_out, db_n_out);
@@ -903,7 +903,7 @@ size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false,
 static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
 {
     const size_t upd = (size_t)4 * 4 * kUpdScratch * sizeof(double);
-    const size_t db = db_align16(dbscan_lds_bytes(0, UM, t_cap, min_samples)) + 4096 + (256 + kCloudGrid + 2) * 4 + 5 * 8 + 16;  // + screen scratch
+    const size_t db = db_align16(dbscan_lds_bytes(0, UM, t_cap, min_samples)) + 4096 + (256 + 2) * 4 + 3 * 8 + 16;  // + pair-count scratch
     return upd > db ? upd : db;
 }
 

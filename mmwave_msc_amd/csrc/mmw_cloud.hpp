@@ -88,31 +88,77 @@ __device__ __forceinline__ void cloud_finish_empty(const DevState &st, SceneHdr 
     }
 }
 
-// Exact screen for clouds of U <= 256 points, 256 threads (all of them must call; barriers inside).
-// Returns true (uniformly) when NO point can be a core point of sklearn's BallTree DBSCAN, i.e. every
-// label is -1 (Utils.py:268-275 then returns no clusters).
+// ---- The "no point can be a core point" screen of apply_DBscan, for clouds of U <= 256 points ------------------
+// Both stages return true (uniformly over the 256 calling threads) only when NO point can be a core point of
+// sklearn's BallTree DBSCAN, i.e. every label is -1 (Utils.py:268-275 then returns no clusters).
 //
 // Bound (proof in dbscan_core, k_dbscan.hip): every BallTree neighbour q of p has
-//   E(p,q)^2 = dx^2 + dy^2 + z_w dz^2 <= 2 eps / wmin,   wmin = min over the cloud of 1 - range_w * y.
-// The count of points inside that ellipsoid is a SUPERSET count, so it may be formed in fp32 as long as
-// the radius is widened by everything fp32 can lose: coordinates (z pre-scaled by sqrt(z_w)) are rounded
-// once, |error| <= M 2^-24 per coordinate with M the largest magnitude in the cloud, i.e. at most
-// 2 sqrt(3) M 2^-24 on E (a norm), and the fp32 evaluation of the squared norm is good to a few 2^-24
-// relative.  R below carries 4 M 6e-8 absolute and 1e-5 relative slack, far more than both.
-//
-// Before the O(U^2) count a coarser superset is tried in O(U): the points are binned into square xy cells
-// of side h = R/2 (a hair more); everything within R of a point lies in the 5x5 cells around its own, so if
-// no 5x5 block holds min_samples points nothing can be a core point.  A ring of clutter -- the usual case
-// -- ends there.
-// MODE 0: cell count, then the pair count if that is inconclusive.  MODE 1: cell count only (true = proven,
-// false = undecided; `cnt` unused) -- what k_track does for every scene on the rows it has just appended.
-// MODE 2: pair count only -- what k_post does for the scenes the cell count left undecided.
-// P4 [256] float4, cnt [256] ints, mm [5] u64, flag [1], grid [kCloudGrid] ints are LDS scratch.
+//   E(p,q)^2 = dx^2 + dy^2 + z_w dz^2 <= 2 eps / wmin =: R^2,   wmin = min over the cloud of 1 - range_w * y.
+// Counting the points inside that ellipsoid is a SUPERSET count, so it may be formed in fp32 as long as the
+// radius is widened by everything fp32 can lose: coordinates (z pre-scaled by sqrt(z_w)) are rounded once,
+// |error| <= M 2^-24 per coordinate with M the largest magnitude in the cloud, i.e. at most 2 sqrt(3) M 2^-24
+// on E (a norm), and the fp32 evaluation of the squared norm is good to a few 2^-24 relative.  R below carries
+// 4 M 6e-8 absolute and 1e-5 relative slack, far more than both.
 constexpr int kCloudGrid = 1024;
-// (px, py, pz) = point `tid` of the cloud (threads tid >= U pass anything).
-template <int MODE>
-__device__ __forceinline__ bool cloud_has_no_core_xyz(const DevCfg &cfg, int U, double px, double py, double pz, float4 *P4, int *cnt,
-                                                      unsigned long long *mm, int *flag, int *grid)
+
+// Stage 1, O(U): the cell count, as k_track runs it on registers at the end of its frame (false = undecided).
+// The points are binned into square xy cells of side h = R/2 (a hair more); everything within R of a point
+// lies in the 5x5 cells around its own, so if no 5x5 block holds min_samples points nothing can be a core
+// point.  Two more relaxations, both on the safe side of a superset count: wmin is bounded by
+// 1 - |range_w| * M instead of the exact y range (one reduction instead of three), and the cells live on a
+// 32 x 32 torus (cell = floor(coordinate / h) mod 32), so no bounding box is needed and far apart points can
+// only ADD to each other's blocks.  (px, py, pz) = point `tid` of the cloud (threads tid >= U pass anything).
+// `grid` [1024], mm[0] and *flag must be zero on entry (the caller does that before an earlier barrier);
+// three barriers inside.
+__device__ __forceinline__ bool cloud_cells_prove_no_core(const DevCfg &cfg, int U, double px, double py, double pz,
+                                                          unsigned long long *mm, int *flag, int *grid)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
+    const int min_samples = cfg.db_min_samples;
+    if (!(min_samples > 1 && zw >= 0.0 && eps >= 0.0)) return false;
+    double mag = 0.0;
+    if (tid < U) {
+        mag = fmax(fmax(fabs(px), fabs(py)), fabs(pz * sqrt(zw)));
+        if (!(mag <= 1e15)) mag = __longlong_as_double(0x7ff0000000000000LL);  // NaN/inf/huge: give up below
+    }
+    mag = wave_max_d(mag);
+    if (lane == 0) atomicMax(&mm[0], (unsigned long long)__double_as_longlong(mag));  // mag >= 0: bit order == value order
+    lds_barrier();
+    const double M = __longlong_as_double((long long)mm[0]);
+    const double wmin = 1.0 - fabs(rw) * M;
+    if (!(wmin > 0.0) || !(M <= 1e15)) return false;  // uniform
+    const double R = sqrt(2.0 * (eps / wmin)) * (1.0 + 1e-9) + 4.0 * M * 6e-8;
+    // |dx| <= R  =>  |dx| / h <= 2 - 2e-3, so the fp32 cell coordinates of two such points differ by less than
+    // 2 - 1e-3 even after rounding (error ~1e-3 cells at most, enforced by M / h < 1e4) and the cells by at most 2
+    const double h = 0.5 * R * (1.0 + 1e-3);
+    if (!(h > 0.0) || !(M / h < 1e4)) return false;
+    const float invh = (float)(1.0 / h);
+    int cx = 0, cy = 0;
+    if (tid < U) {
+        cx = (int)floorf((float)px * invh) & 31;
+        cy = (int)floorf((float)py * invh) & 31;
+        atomicAdd(&grid[cy * 32 + cx], 1);
+    }
+    lds_barrier();
+    bool maybe = false;
+    if (tid < U) {
+        int c = 0;
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+            for (int dx = -2; dx <= 2; dx++) c += grid[((cy + dy) & 31) * 32 + ((cx + dx) & 31)];
+        maybe = c >= min_samples;
+    }
+    if (maybe) *flag = 1;
+    lds_barrier();
+    return *flag == 0;
+}
+
+// Stage 2, O(U^2): the exact superset count over all pairs, for the clouds stage 1 left undecided (k_post),
+// read from the scene's global ring.  P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.
+__device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
+                                                          unsigned long long *mm, int *flag)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
@@ -121,31 +167,25 @@ __device__ __forceinline__ bool cloud_has_no_core_xyz(const DevCfg &cfg, int U, 
     const double sqzw = sqrt(zw);
     double y = 0.0, mag = 0.0;
     if (tid < U) {
-        const double2 a = double2{px, py};
-        const double zs = pz * sqzw;
+        const double *r = src.row(tid);
+        const double2 a = *reinterpret_cast<const double2 *>(r);
+        const double zs = r[2] * sqzw;
         y = a.y;
         P4[tid] = make_float4((float)a.x, (float)a.y, (float)zs, 0.f);
         mag = fmax(fmax(fabs(a.x), fabs(a.y)), fabs(zs));
         if (!(mag <= 1e15)) mag = __longlong_as_double(0x7ff0000000000000LL);  // NaN/inf/huge: give up below
-        if constexpr (MODE != 1) cnt[tid] = 0;
+        cnt[tid] = 0;
     }
-    if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; mm[2] = 0ULL; mm[3] = ~0ULL; mm[4] = 0ULL; *flag = 0; }
-    if constexpr (MODE != 2)
-        for (int i = tid; i < kCloudGrid; i += 256) grid[i] = 0;
+    if (tid == 0) { mm[0] = ~0ULL; mm[1] = 0ULL; mm[2] = 0ULL; *flag = 0; }
     lds_barrier();
     double ylo = tid < U ? y : 1.7976931348623157e308, yhi = tid < U ? y : -1.7976931348623157e308;
-    double xlo = tid < U ? (double)P4[tid].x : 1.7976931348623157e308, xhi = tid < U ? (double)P4[tid].x : -1.7976931348623157e308;
     ylo = wave_min_d(ylo);
     yhi = wave_max_d(yhi);
-    xlo = wave_min_d(xlo);
-    xhi = wave_max_d(xhi);
     mag = wave_max_d(mag);
     if (lane == 0 && ylo <= yhi) {
         atomicMin(&mm[0], sortable(ylo));
         atomicMax(&mm[1], sortable(yhi));
         atomicMax(&mm[2], (unsigned long long)__double_as_longlong(mag));  // mag >= 0: bit order == value order
-        atomicMin(&mm[3], sortable(xlo));
-        atomicMax(&mm[4], sortable(xhi));
     }
     lds_barrier();
     const double ymin = unsortable(mm[0]), ymax = unsortable(mm[1]), M = __longlong_as_double((long long)mm[2]);
@@ -154,46 +194,6 @@ __device__ __forceinline__ bool cloud_has_no_core_xyz(const DevCfg &cfg, int U, 
     if (!(wmin > 0.0) || !(M <= 1e15)) return false;  // uniform: same LDS values for every thread
     const double R = sqrt(2.0 * (eps / wmin)) * (1.0 + 1e-9) + 4.0 * M * 6e-8;
     const float R2f = (float)(R * R * (1.0 + 1e-5));
-    if constexpr (MODE != 2) {  // ---- O(U) superset: 5x5 blocks of cells of side h = R/2 * (1 + 1e-3) ----
-        // |dx| <= R  =>  |dx| / h <= 2 - 2e-3, so the (fp32) cell coordinates of two such points differ by
-        // less than 2 - 1e-3 even after rounding (their error is ~1e-5 cells here) and the integer cells by
-        // at most 2.  The rounded fp32 coordinates themselves are within the slack R already carries.
-        const double h = 0.5 * R * (1.0 + 1e-3);
-        const double x0 = unsortable(mm[3]), x1 = unsortable(mm[4]);
-        const double wx = (x1 - x0) / h, wy = ((double)(float)ymax - (double)(float)ymin) / h;
-        if (h > 0.0 && wx < 500.0 && wy < 500.0) {  // (also false for NaN)
-            const int nx = (int)wx + 6, ny = (int)wy + 6;  // two guard cells on every side (+ rounding room)
-            if (nx * ny <= kCloudGrid) {  // uniform
-                const float invh = (float)(1.0 / h), fx0 = (float)x0, fy0 = (float)ymin;
-                int cx = 0, cy = 0;
-                if (tid < U) {
-                    const float4 a = P4[tid];
-                    cx = (int)((a.x - fx0) * invh) + 2;
-                    cy = (int)((a.y - fy0) * invh) + 2;
-                    cx = cx < 2 ? 2 : (cx > nx - 3 ? nx - 3 : cx);  // (rounding at the edges)
-                    cy = cy < 2 ? 2 : (cy > ny - 3 ? ny - 3 : cy);
-                    atomicAdd(&grid[cy * nx + cx], 1);
-                }
-                lds_barrier();
-                bool maybe = false;
-                if (tid < U) {
-                    int c = 0;
-#pragma unroll
-                    for (int dy = -2; dy <= 2; dy++)
-#pragma unroll
-                        for (int dx = -2; dx <= 2; dx++) c += grid[(cy + dy) * nx + cx + dx];
-                    maybe = c >= min_samples;
-                }
-                if (maybe) *flag = 1;
-                lds_barrier();
-                if (*flag == 0) return true;
-                lds_barrier();
-                if (tid == 0) *flag = 0;
-                lds_barrier();
-            }
-        }
-    }
-    if constexpr (MODE == 1) return false;
     // tasks (point p, slice `part` of the partners), about four per thread
     int parts = 1024 / U;
     parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
@@ -218,69 +218,6 @@ __device__ __forceinline__ bool cloud_has_no_core_xyz(const DevCfg &cfg, int U, 
     if (tid < U && cnt[tid] >= min_samples) *flag = 1;
     lds_barrier();
     return *flag == 0;
-}
-
-// The cell count alone, as k_track runs it on registers at the end of its frame (true = proven: no core point;
-// false = undecided).  Differences to the general routine above, all on the safe side of a SUPERSET count:
-// wmin is bounded by 1 - |range_w| * M (M = largest coordinate magnitude) instead of the exact y range, and the
-// cells live on a 32 x 32 torus (cell = floor(coordinate / h) mod 32), so no bounding box is needed and far
-// apart points can only ADD to each other's blocks.  `grid` [1024], mm[0] and *flag must be zero on entry (the
-// caller does that before an earlier barrier); three barriers inside.
-__device__ __forceinline__ bool cloud_cells_prove_no_core(const DevCfg &cfg, int U, double px, double py, double pz,
-                                                          unsigned long long *mm, int *flag, int *grid)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
-    const int min_samples = cfg.db_min_samples;
-    if (!(min_samples > 1 && zw >= 0.0 && eps >= 0.0)) return false;
-    double mag = 0.0;
-    if (tid < U) {
-        mag = fmax(fmax(fabs(px), fabs(py)), fabs(pz * sqrt(zw)));
-        if (!(mag <= 1e15)) mag = __longlong_as_double(0x7ff0000000000000LL);
-    }
-    mag = wave_max_d(mag);
-    if (lane == 0) atomicMax(&mm[0], (unsigned long long)__double_as_longlong(mag));  // mag >= 0: bit order == value order
-    lds_barrier();
-    const double M = __longlong_as_double((long long)mm[0]);
-    const double wmin = 1.0 - fabs(rw) * M;
-    if (!(wmin > 0.0) || !(M <= 1e15)) return false;  // uniform
-    const double R = sqrt(2.0 * (eps / wmin)) * (1.0 + 1e-9) + 4.0 * M * 6e-8;
-    const double h = 0.5 * R * (1.0 + 1e-3);  // |dx| <= R  =>  cell coordinates differ by < 2 - 1e-3 (see above)
-    if (!(h > 0.0) || !(M / h < 1e4)) return false;  // fp32 cell coordinates good to ~1e-3 cells
-    const float invh = (float)(1.0 / h);
-    int cx = 0, cy = 0;
-    if (tid < U) {
-        cx = (int)floorf((float)px * invh) & 31;
-        cy = (int)floorf((float)py * invh) & 31;
-        atomicAdd(&grid[cy * 32 + cx], 1);
-    }
-    lds_barrier();
-    bool maybe = false;
-    if (tid < U) {
-        int c = 0;
-#pragma unroll
-        for (int dy = -2; dy <= 2; dy++)
-#pragma unroll
-            for (int dx = -2; dx <= 2; dx++) c += grid[((cy + dy) & 31) * 32 + ((cx + dx) & 31)];
-        maybe = c >= min_samples;
-    }
-    if (maybe) *flag = 1;
-    lds_barrier();
-    return *flag == 0;
-}
-
-// the same with the points read from the scene's global ring
-template <int MODE>
-__device__ __forceinline__ bool cloud_has_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
-                                                  unsigned long long *mm, int *flag, int *grid)
-{
-    double px = 0.0, py = 0.0, pz = 0.0;
-    if ((int)threadIdx.x < U) {
-        const double *r = src.row(threadIdx.x);
-        const double2 a = *reinterpret_cast<const double2 *>(r);
-        px = a.x; py = a.y; pz = r[2];
-    }
-    return cloud_has_no_core_xyz<MODE>(cfg, U, px, py, pz, P4, cnt, mm, flag, grid);
 }
 
 }  // namespace mmw
