@@ -299,6 +299,10 @@ def main():
                 "algorithmic_bytes_per_launch": round(dom_bytes, 1),
                 "avg_launch_ms": round(dom_ms, 5), "launches_timed": n_samp,
             },
+            # all four launches of a step together, per SURVEY.md §8(d): algorithmic bytes of the step / step time
+            "roofline_whole_step": {"bound": "hbm", "achieved": round(sum(step_bytes.values()) / (el / K) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(sum(step_bytes.values()) / (el / K) / 1e9 / HBM_PEAK_GBS, 6),
+                                    "algorithmic_bytes_per_step": round(sum(step_bytes.values()), 1)},
             "kernels": {
                 name: {"avg_ms": round(step_ms[k], 5), "alg_bytes_per_launch": round(step_bytes[k], 1)}
                 for k, name in ((_lib.K_PREDICT, "k_predict"), (_lib.K_TRACK, "k_track"),

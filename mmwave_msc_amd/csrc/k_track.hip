@@ -187,7 +187,7 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 // PPT = points per thread = ceil(max_pts / 256): a template so that per-point registers are not
 // reserved for points a configuration can never have.
 template <int PPT>
-__global__ __launch_bounds__(kThreads, 5) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+__global__ __launch_bounds__(kThreads, (PPT <= 2 ? 5 : 3)) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out,
                                                     int32_t *__restrict__ db_labels_out, int UM_out, int parity)
