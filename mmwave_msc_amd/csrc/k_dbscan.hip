@@ -27,6 +27,7 @@
 #include "mmw_math.hpp"
 #include "mmw_cloud.hpp"
 #include "mmw_kalman.hpp"
+#include "mmw_launch.hpp"
 
 namespace mmw {
 
@@ -930,8 +931,8 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
     const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
     const size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
     const dim3 grid(G0 + (units + 3) / 4);
-    if (cfg.dx == 9) hipLaunchKernelGGL(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
-    else hipLaunchKernelGGL(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
+    if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
+    else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
 }
 
 // The larger clouds (work lists 1 and 2; the start-up frames of a scene): k_dbscan_big.
@@ -949,7 +950,7 @@ void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity
     if (per_cu < 1) per_cu = 1;
     int g = 256 * per_cu;
     if (g > S) g = S;
-    hipLaunchKernelGGL(k_dbscan_big, dim3(two ? 2 * g : g), dim3(256), lds, stream, cfg, st, g, um1, cl1, um2, cl2, UM, parity, labels, db_n);
+    mmw_launch(k_dbscan_big, dim3(two ? 2 * g : g), dim3(256), lds, stream, cfg, st, g, um1, cl1, um2, cl2, UM, parity, labels, db_n);
 }
 
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,

@@ -15,6 +15,7 @@
 //
 // The arithmetic per matrix element is unchanged (same operations in the same order as the CPU oracle).
 #include "mmw_kalman.hpp"
+#include "mmw_launch.hpp"
 
 namespace mmw {
 
@@ -127,8 +128,8 @@ static int waves_per_scene(const DevCfg &cfg)
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream)
 {
     const int nq = waves_per_scene(cfg);
-    if (cfg.dx == 9) hipLaunchKernelGGL(k_predict<9>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
-    else hipLaunchKernelGGL(k_predict<6>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
+    if (cfg.dx == 9) mmw_launch(k_predict<9>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
+    else mmw_launch(k_predict<6>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
 }
 
 }  // namespace mmw

@@ -15,6 +15,7 @@
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 #include "mmw_cloud.hpp"
+#include "mmw_launch.hpp"
 
 namespace mmw {
 
@@ -745,7 +746,7 @@ template <int PPT>
 static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                            int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_track<PPT>), dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
+    mmw_launch(k_track<PPT>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
                        db_labels, UM, parity);
 }
 

@@ -10,8 +10,10 @@
 #include <vector>
 
 #include "mmw_device.hpp"
+#include "mmw_launch.hpp"
 
 namespace mmw {
+thread_local LaunchProf g_launch_prof;
 size_t track_lds_bytes(const DevCfg &c);
 hipError_t prepare_track(const DevCfg &cfg);
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream);
@@ -94,6 +96,27 @@ static void prof_begin(mmw_ctx *c, int kid, EventPair &ep)
     else { hipEventCreate(&ep.a); hipEventCreate(&ep.b); }
     ep.kid = kid;
     hipEventRecord(ep.a, c->stream);
+}
+// for an id that is exactly ONE launch: the events ride on the kernel's own packet (mmw_launch.hpp)
+static void prof_arm(mmw_ctx *c, int kid, EventPair &ep)
+{
+    ep.kid = -1;
+    if (!((c->prof_mask >> kid) & 1u)) return;
+    if (!c->pool.empty()) { ep = c->pool.back(); c->pool.pop_back(); }
+    else { hipEventCreate(&ep.a); hipEventCreate(&ep.b); }
+    ep.kid = kid;
+    g_launch_prof.a = ep.a;
+    g_launch_prof.b = ep.b;
+}
+static void prof_armed_done(mmw_ctx *c, EventPair &ep)
+{
+    if (ep.kid < 0) return;
+    if (g_launch_prof.a) {  // nothing was launched (e.g. no large-cloud class exists): nothing to time
+        g_launch_prof = LaunchProf{};
+        c->pool.push_back(ep);
+        return;
+    }
+    c->pending.push_back(ep);  // (folded by mmw_profile_get / the event-pair path)
 }
 static void prof_fold(mmw_ctx *c)
 {
@@ -330,18 +353,19 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
-    prof_begin(c, MMW_K_PREDICT, ep);
+    prof_arm(c, MMW_K_PREDICT, ep);
     launch_predict(c->dc, c->st, n_pts, dt, c->step_parity, c->stream);
-    prof_end(c, ep);
-    prof_begin(c, MMW_K_TRACK, ep);
+    prof_armed_done(c, ep);
+    prof_arm(c, MMW_K_TRACK, ep);
     launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
-    prof_end(c, ep);
-    prof_begin(c, MMW_K_POST, ep);
+    prof_armed_done(c, ep);
+    prof_arm(c, MMW_K_POST, ep);
     launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, db_labels, db_n, c->stream);
-    prof_end(c, ep);
-    prof_begin(c, MMW_K_DBSCAN, ep);
+    prof_armed_done(c, ep);
+    prof_arm(c, MMW_K_DBSCAN, ep);
     launch_dbscan_big(c->dc, c->st, c->UM, c->step_parity, db_labels, db_n, c->stream);
-    prof_end(c, ep);
+    prof_armed_done(c, ep);
+    if (c->pending.size() >= 2048) prof_fold(c);
     c->step_parity ^= 1;
     HIPCHK(c, hipGetLastError());
     return MMW_OK;
