@@ -461,7 +461,19 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         const int node = leaf0 + t / 3, c = t % 3;
         const double *col = c == 0 ? L.X : (c == 1 ? L.Y : L.Z);
         double acc = 0.0;
-        for (int p = L.nstart[node]; p < L.nend[node]; p++) acc += col[idx[p]];
+        int p = L.nstart[node];
+        const int pe = L.nend[node];
+        for (; p + 8 <= pe; p += 8) {  // (index loads, then value loads, then the adds in index order)
+            int ii[8];
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ii[u] = idx[p + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = col[ii[u]];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; p < pe; p++) acc += col[idx[p]];
         L.nsum[node * 3 + c] = acc;
     }
     for (int p = tid; p < U; p += NT) L.leafpos[p] = (unsigned char)(node_of(L, p, n_levels - 1) - leaf0);
@@ -605,11 +617,20 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 const int lq = L.leafpos[q];
                 const double qx = L.X[q], qy = L.Y[q], qz = L.Z[q];
                 bool hit = false;
-                for (int f = 0; f < fcount && !hit; f++) {
-                    const int pp = front[f];
-                    const int stt = (int)((L.mask[pp] >> (2 * lq)) & 3ULL);
-                    if (stt == 1) hit = true;
-                    else if (stt == 2) hit = alt_dist(L.X[pp], L.Y[pp], L.Z[pp], qx, qy, qz, rw, zw) <= eps;
+                for (int f = 0; f < fcount && !hit; f += 4) {  // four frontier points per round trip to LDS
+                    int pp[4];
+                    unsigned long long mk[4];
+                    double fx[4], fy[4], fz[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pp[u] = front[f + u < fcount ? f + u : f];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { mk[u] = L.mask[pp[u]]; fx[u] = L.X[pp[u]]; fy[u] = L.Y[pp[u]]; fz[u] = L.Z[pp[u]]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int stt = (int)((mk[u] >> (2 * lq)) & 3ULL);
+                        if (stt == 1) hit = true;
+                        else if (stt == 2 && alt_dist(fx[u], fy[u], fz[u], qx, qy, qz, rw, zw) <= eps) hit = true;
+                    }
                 }
                 if (hit) {
                     L.lab[q] = n_clusters;
