@@ -133,6 +133,58 @@ __device__ __forceinline__ int node_of(const DbLds &L, int p, int level)
     return node;
 }
 
+// ---- bitonic network over the NT thread slots of a workgroup, 96-bit keys (hi64, lo32) --------------------
+// Partner exchange for distance J: DPP inside quads (J = 1, 2) and inside rows of 16 (J = 4, 8: the two row
+// shifts, picked by the lane's bit J), ds_bpermute for 16 and 32, LDS + barriers across waves.
+template <int J>
+__device__ __forceinline__ unsigned xor_lane32(unsigned v, int lane)
+{
+    if constexpr (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (J == 4 || J == 8) {
+        const unsigned up = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + J, 0xF, 0xF, true);  // row_shl: lane i <- i + J
+        const unsigned dn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + J, 0xF, 0xF, true);  // row_shr: lane i <- i - J
+        return (lane & J) ? dn : up;
+    } else return (unsigned)__shfl_xor((int)v, J);
+}
+
+template <int K, int J, int NT>
+__device__ __forceinline__ void bitonic_round(unsigned long long &hi64, unsigned &lo32, int tid, unsigned long long *xh, unsigned *xl)
+{
+    unsigned long long ph;
+    unsigned pl;
+    if constexpr (J >= 64) {
+        xh[tid] = hi64; xl[tid] = lo32;
+        __syncthreads();
+        ph = xh[tid ^ J]; pl = xl[tid ^ J];
+        __syncthreads();
+    } else {
+        const int lane = tid & 63;
+        const unsigned a = xor_lane32<J>((unsigned)hi64, lane), b = xor_lane32<J>((unsigned)(hi64 >> 32), lane);
+        ph = ((unsigned long long)b << 32) | a;
+        pl = xor_lane32<J>(lo32, lane);
+    }
+    const bool up = (tid & K) == 0, lower = (tid & J) == 0;
+    const bool pless = ph < hi64 || (ph == hi64 && pl < lo32);  // partner sorts before me
+    if ((lower == up) ? pless : !pless) { hi64 = ph; lo32 = pl; }  // lower slot keeps the smaller one when ascending
+}
+template <int K, int J, int NT>
+struct BitonicJ {
+    static __device__ __forceinline__ void run(unsigned long long &h, unsigned &l, int tid, unsigned long long *xh, unsigned *xl)
+    {
+        bitonic_round<K, J, NT>(h, l, tid, xh, xl);
+        if constexpr (J > 1) BitonicJ<K, J / 2, NT>::run(h, l, tid, xh, xl);
+    }
+};
+template <int K, int NT>
+struct BitonicK {
+    static __device__ __forceinline__ void run(unsigned long long &h, unsigned &l, int tid, unsigned long long *xh, unsigned *xl)
+    {
+        BitonicJ<K, K / 2, NT>::run(h, l, tid, xh, xl);
+        if constexpr (K < NT) BitonicK<K * 2, NT>::run(h, l, tid, xh, xl);
+    }
+};
+
 // The whole of DBSCAN.fit_predict for one cloud.  On return L.idx2[i] = label of
 // point i (-1 noise) and the number of clusters is returned (uniform).
 template <int NT, bool ALL8>
@@ -299,25 +351,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 hi64 = ((unsigned long long)node << 48) | (sk >> 16);
                 lo32 = ((unsigned)(sk & 0xffffULL) << 16) | (unsigned)tid;
             }
-#pragma unroll
-            for (int k = 2; k <= NT; k <<= 1) {
-#pragma unroll
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    unsigned long long ph;
-                    unsigned pl;
-                    if (j >= 64) {
-                        xh[tid] = hi64; xl[tid] = lo32;
-                        __syncthreads();
-                        ph = xh[tid ^ j]; pl = xl[tid ^ j];
-                        __syncthreads();
-                    } else {
-                        ph = __shfl_xor(hi64, j); pl = __shfl_xor(lo32, j);
-                    }
-                    const bool up = (tid & k) == 0, lower = (tid & j) == 0;
-                    const bool pless = ph < hi64 || (ph == hi64 && pl < lo32);  // partner sorts before me
-                    if ((lower == up) ? pless : !pless) { hi64 = ph; lo32 = pl; }  // lower slot keeps the smaller one when ascending
-                }
-            }
+            BitonicK<2, NT>::run(hi64, lo32, tid, xh, xl);
             if (hi64 != ~0ULL) {  // slot `tid` now holds the tid-th element of the level
                 const int snode = (int)(hi64 >> 48), owner = (int)(lo32 & 0xffffu);
                 const int ss = L.nstart[snode], ee = L.nend[snode];
