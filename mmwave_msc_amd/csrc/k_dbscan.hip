@@ -83,6 +83,10 @@ __host__ __device__ inline int db_levels(int U)
 }
 
 // WRITE=false only sizes the layout (see k_track.hip: no null test on the private struct).
+// ALL8 build: private copies of the per-node min/max keys (picked by lane & 7), merged after the atomics -- all
+// lanes of a wave hitting the same sixteen LDS words serialise 64-fold
+constexpr int kMmCopies = 8;
+
 template <bool WRITE>
 __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool all8, char *base, DbLds *L)
 {
@@ -109,7 +113,7 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(nsum, double, nodes * 3)
     CARVE(ncen, double, nodes * 3)
     CARVE(nrad, unsigned long long, nodes + 1)
-    CARVE(mm, unsigned long long, half * 16)
+    CARVE(mm, unsigned long long, half * 16 * (all8 ? kMmCopies : 1))
     CARVE(sdim, int, half)
     CARVE(lbase, int, half)
     CARVE(blk, int, (NB + 1) > 64 ? (NB + 1) : 64)
@@ -302,12 +306,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         if (tid < U) posarr[tid] = tid;
         for (int level = 0; level + 1 < n_levels; level++) {
             const int first = (1 << level) - 1, nn = 1 << level;
-            for (int e = tid; e < nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;
+            for (int e = tid; e < kMmCopies * nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;
             __syncthreads();
             const bool act = tid < U;
             const int node = act ? node_of(L, mypos, level) : -1;
             if (act) {  // find_node_split_dim over all 8 features (_binary_tree.pxi.tp:598-645)
-                unsigned long long *m = &L.mm[(node - first) * 16];
+                unsigned long long *m = &L.mm[((lane & (kMmCopies - 1)) * nn + (node - first)) * 16];
                 atomicMin(&m[0], sortable(f0)); atomicMax(&m[1], sortable(f0));
                 atomicMin(&m[2], sortable(f1)); atomicMax(&m[3], sortable(f1));
                 atomicMin(&m[4], sortable(f2)); atomicMax(&m[5], sortable(f2));
@@ -318,12 +322,26 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 atomicMin(&m[14], sortable(f7)); atomicMax(&m[15], sortable(f7));
             }
             __syncthreads();
+            if (tid < nn * 16) {  // merge the private copies into copy 0
+                unsigned long long v[kMmCopies];
+#pragma unroll
+                for (int q = 0; q < kMmCopies; q++) v[q] = L.mm[q * nn * 16 + tid];
+                unsigned long long r = v[0];
+#pragma unroll
+                for (int q = 1; q < kMmCopies; q++) r = (tid & 1) ? (v[q] > r ? v[q] : r) : (v[q] < r ? v[q] : r);
+                L.mm[tid] = r;
+            }
+            __syncthreads();
             DSTAMP(6);  // (diagnostic) min/max
             if (tid < nn) {
+                double lo[8], hi[8];
+#pragma unroll
+                for (int f = 0; f < 8; f++) { lo[f] = unsortable(L.mm[(tid * 8 + f) * 2]); hi[f] = unsortable(L.mm[(tid * 8 + f) * 2 + 1]); }
                 int jmax = 0;
                 double best = 0;
+#pragma unroll
                 for (int f = 0; f < 8; f++) {
-                    const double spread = unsortable(L.mm[(tid * 8 + f) * 2 + 1]) - unsortable(L.mm[(tid * 8 + f) * 2]);
+                    const double spread = hi[f] - lo[f];
                     if (spread > best) { best = spread; jmax = f; }
                 }
                 L.sdim[tid] = jmax;
