@@ -4,7 +4,8 @@
 //   k_predict  _predict_all (Tracking.py:591-596; filterpy predict, motion model constants.py:195-215)
 //              + the gate matrix of _calc_dist_fun (Tracking.py:549-560): inverse and log|det| of
 //              P[:6,:6] + diag((spread/2)^2) + group_disp_est, handed to k_track through `gate_buf`.
-//   k_update   _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy's
+//   update_tracks_wave (mmw_kalman.hpp; launched as part of k_post, k_dbscan.hip)
+//              _update_all (Tracking.py:598-603): update_state 387-398, _get_Rc 299-312, filterpy's
 //              Joseph-form update.
 //
 // Why separate kernels: inside the one-workgroup-per-scene kernel these were latency chains (a global

@@ -1,15 +1,14 @@
-// k_track.hip -- one workgroup (256 threads = 4 wave64) per scene: everything of
-// TrackBuffer.track (Tracking.py:664-703) up to and including batch.add_frame(unassigned):
-//   _predict_all -> _calc_dist_fun gating/association -> associate_pointcloud estimators
-//   -> _maintain_tracks -> _update_all -> global ring append; queues the scene for k_dbscan.
+// k_track.hip -- one workgroup (256 threads = 4 wave64) per scene: the association part of
+// TrackBuffer.track (Tracking.py:664-703), between the two batched Kalman kernels (k_kalman.hip, k_post):
+//   _calc_dist_fun gating/association (gate matrices from k_predict) -> _get_gated_clouds ->
+//   associate_pointcloud estimators -> _maintain_tracks -> batch.add_frame(unassigned) on the global ring
+//   -> first stage of the apply_DBscan screen; scenes that may hold a cluster go to the BallTree work lists.
 //
-// Data movement per scene-frame: the frame's points are read ONCE from HBM (coalesced 8-B
-// lanes over the row-major [n][8] block) and transposed into an LDS SoA tile (6 columns);
-// track records (1.5 KB each) live in HBM/L2.  Per-track algebra (9x9 predict, 6x6 LU, Joseph
-// update) runs one wave per track with wave-local ordering only -- the four waves of the
-// workgroup work on four tracks independently and meet at workgroup barriers only around the
-// phases that touch all points.  All arithmetic fp64 with a fixed operation order (see
-// mmw_math.hpp) -- the order the parity oracle restates from the reference.
+// Data movement per scene-frame: the frame's points are read ONCE from HBM (16-byte loads of whole rows
+// into registers), gated from registers, then parked class-sorted in an LDS SoA tile (6 columns) for the
+// cluster statistics; rows go from registers to their ring; track records (1.5 KB each) live in HBM/L2.
+// All arithmetic fp64 with a fixed operation order (see mmw_math.hpp) -- the order the parity oracle
+// restates from the reference.  Phase list, LDS budget and what the probes say: DESIGN.md §5.
 #include <cstdlib>
 
 #include "mmw_device.hpp"
@@ -79,16 +78,16 @@ template <bool WRITE>
 __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
 {
     const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
-    // One region, four lives: (1) gate matrices + per-wave scratch while tracks are predicted and
-    // points gated (points sit in registers then); (2) the SoA point tile + the pairwise-sum stack
-    // while cluster statistics are formed; (3) per-wave scratch again for the Kalman update.
+    // One region, three lives: (1) the gate records of a chunk of tracks while the points are gated (points
+    // sit in registers then); (2) the SoA point tile + the leaf sums of the pairwise recursion while cluster
+    // statistics are formed; (3) the cell grid of the DBSCAN screen at the very end.
     const int work_a = kGateChunk * kGateStride, work_b = 6 * (NP + kTilePad) + pw_max_leaves(NP) * 21;
     size_t off = 0;
 #define CARVE(field, type, count)                            \
     if constexpr (WRITE) L->field = (type *)(base + off);    \
     off = align16(off + sizeof(type) * (size_t)(count));
     if constexpr (WRITE) L->p6 = (double *)(base + off);
-    const int work_c = (4096 + kCloudGrid * 4 + 64) / 8;  // (4) the DBSCAN cell-count screen at the very end
+    const int work_c = (4096 + kCloudGrid * 4 + 64) / 8;  // (3)
     const int work_ab = work_a > work_b ? work_a : work_b;
     CARVE(work, double, work_ab > work_c ? work_ab : work_c)
     CARVE(cen, double, c.t_cap * 6)
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(kThreads, (PPT <= 2 ? 5 : 3)) void k_track(DevCfg c
     PROBE(6);
     STAMP(7);  // maintenance
 
-    // (_update_all, Tracking.py:598-603, runs as its own batched kernel right after this one: k_update)
+    // (_update_all, Tracking.py:598-603, is batched over all tracks in the next launch: k_post)
     STAMP(8);  // update
     // ---- DBSCAN trigger (Tracking.py:693-697) ----
     if (tid == 0) {

@@ -85,7 +85,7 @@ struct DevState {
     double *g_ring;       // [S][ring][max_pts][8]
     const float *default_posture;  // [57]
     unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
-    int32_t *db_list;              // [4][S] scenes whose apply_DBscan needs the BallTree this step: size classes 0..2 (list 3 = class 0), built by k_dbscan_screen
+    int32_t *db_list;              // [4][S] scenes whose apply_DBscan the cell count could not finish this step: list 3 = clouds <= 256 points (k_post), 1 and 2 = larger ones (k_dbscan_big); filled by k_track
     int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
     int32_t *perm;                 // [2][S] by step parity: scene handled by unit b of k_predict / k_track / k_post, heaviest scenes (most tracks) first; k_post builds the next step's
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)

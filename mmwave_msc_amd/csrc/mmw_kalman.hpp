@@ -34,7 +34,7 @@ __device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int
 
 // _update_all for tracks 4q.., 4(q+nq).. of scene s by ONE wave (four 16-lane groups); `lds` = this wave's
 // 4 * kUpdScratch doubles.  Reads hdr->n_upd: the tracks that survived _maintain_tracks in k_track -- this
-// frame's new tracks (k_dbscan_spawn, possibly running in the same launch) are not updated.
+// frame's new tracks (spawn_scene, running in worker blocks of the same launch) are not updated.
 template <int DX>
 __device__ __forceinline__ void update_tracks_wave(const DevCfg &cfg, const DevState &st, const int32_t *__restrict__ n_pts, int s, int q,
                                                    int nq, double *lds)
