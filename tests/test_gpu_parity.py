@@ -168,6 +168,65 @@ def test_dbscan_screen_decisions_vs_oracle(case):
     assert n_db > 50 and 0 < n_clustered < n_db, (n_db, n_clustered)
 
 
+def _grid_scene(seed, n_frames, n_pts, n_targets):
+    """Targets on a 1.3 m grid (4 rows in y), 24 points each per frame, the rest clutter; fp32-representable."""
+    rng = np.random.default_rng(seed)
+    cols = (n_targets + 3) // 4
+    centres = np.array([[-0.65 * (cols - 1) + 1.3 * (k // 4), 1.5 + 1.3 * (k % 4)] for k in range(n_targets)])
+    vel = rng.normal(0.0, 0.08, size=(n_targets, 2))
+    out = np.zeros((n_frames, n_pts, 8))
+    per = 24
+    for f in range(n_frames):
+        c = centres + vel * 0.1 * f
+        rows = []
+        for k in range(n_targets):
+            r = np.zeros((per, 8))
+            r[:, 0:2] = c[k] + rng.normal(0.0, 0.08, size=(per, 2))
+            r[:, 2] = rng.uniform(0.3, 1.5, size=per)
+            r[:, 3:5] = vel[k] + rng.normal(0.0, 0.03, size=(per, 2))
+            r[:, 5] = rng.normal(0.0, 0.03, size=per)
+            rows.append(r)
+        ncl = n_pts - per * n_targets
+        cl = np.zeros((ncl, 8))
+        cl[:, 0] = rng.uniform(-6.0, 6.0, size=ncl); cl[:, 1] = rng.uniform(0.3, 7.5, size=ncl); cl[:, 2] = rng.uniform(0.05, 2.4, size=ncl)
+        cl[:, 3:6] = rng.normal(0.0, 0.05, size=(ncl, 3))
+        fr = np.concatenate(rows + [cl])
+        fr[:, 6] = rng.normal(0.0, 0.3, size=n_pts); fr[:, 7] = rng.gamma(1.0, 30.0, size=n_pts)
+        out[f] = fr[rng.permutation(n_pts)]
+    return out.astype(np.float32)
+
+
+def test_many_tracks_vs_oracle():
+    """More than 16 tracks per scene: the gate-record chunks of k_track, the second statistics round, the track
+    loops of the batched Kalman kernels (tracks beyond 4 * waves-per-scene) and the per-track ring bookkeeping."""
+    from oracle import c_oracle as co
+    S, N, F = 4, 640, 10
+    kw = dict(tr_max_tracks=28, db_min_samples=12)
+    sb = _mk(S, N, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    pts = np.stack([_grid_scene(4300 + s, F, N, 18 + 2 * s) for s in range(S)], axis=1)  # [F][S][N][8]
+    cnt = np.full((F, S), N, np.int32)
+    dts = np.full((F, S), 0.1)
+    most = 0
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=64)
+        for s in range(S):
+            oa, ol = scenes[s].track(pts[f, s].astype(np.float64), dts[f, s])
+            assert np.array_equal(assoc[s], oa), (f, s)
+            assert (ol is None) == (dbn[s] < 0), (f, s)
+            if ol is not None:
+                assert np.array_equal(labels[s, : dbn[s]], ol), (f, s)
+            assert ntr[s] == scenes[s].n_tracks, (f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
+            most = max(most, int(ntr[s]))
+    sb.check()
+    sb.close()
+    assert most > 16, most
+
+
 def test_normalize_golden_and_oracle():
     from oracle import c_oracle as co
     z = np.load(os.path.join(GOLDEN, "normalize.npz"))
