@@ -74,6 +74,8 @@ struct DbLds {
 
 __host__ __device__ inline size_t db_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+__host__ __device__ inline int db_pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
 __host__ __device__ inline int db_levels(int U)
 {
     // BinaryTree.__init__: n_levels = int(log2(max(1,(n-1)/leaf_size)) + 1)  (_binary_tree.pxi.tp:876-878)
@@ -100,11 +102,11 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(Y, double, UM)
     CARVE(Z, double, UM)
     if constexpr (WRITE) L->mask = (unsigned long long *)(base + off);
-    CARVE(key, double, UM)
+    CARVE(key, double, all8 ? UM : db_pow2ceil(UM))   // (generic build: also the 64-bit half of the sort keys, one per slot)
     CARVE(idx, int, UM)
     CARVE(idx2, int, UM)
     CARVE(lab, int, UM)
-    CARVE(front, int, UM)
+    CARVE(front, int, all8 ? UM : db_pow2ceil(UM))    // (generic build: the 32-bit half of the sort keys)
     CARVE(next, int, UM)
     CARVE(core, unsigned char, UM)
     CARVE(leafpos, unsigned char, UM)
@@ -447,29 +449,50 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             L.sdim[tid] = jmax;
         }
         __syncthreads();
-        for (int p = tid; p < U; p += NT) {
-            const int node = node_of(L, p, level);
-            L.key[p] = feature(idx[p], L.sdim[node - first]);
-        }
-        __syncthreads();
         // partition_node_indices: the n_mid smallest under (value, index) go left
         // (_partition_nodes.pyx:35-39); both halves keep ascending point-index order.
+        // Rank inside the node = slot after sorting the whole level by (node, value, point index), minus the
+        // node's start (see the ALL8 branch).  Here the 96-bit keys live in LDS, one slot per position, and the
+        // bitonic network runs over them: every thread owns pairs (i, i + j), so one barrier per round.
+        {
+            unsigned long long *xh = reinterpret_cast<unsigned long long *>(L.key);
+            unsigned *xl = reinterpret_cast<unsigned *>(L.front);
+            unsigned char *leftflag = L.core;  // by point index (free until the queries)
+            const int Upad = db_pow2ceil(U);
+            for (int p = tid; p < Upad; p += NT) {
+                unsigned long long h = ~0ULL;  // padding sorts to the end
+                unsigned l = ~0u;
+                if (p < U) {
+                    const int node = node_of(L, p, level), i = idx[p];
+                    const unsigned long long sk = sortable(feature(i, L.sdim[node - first]));
+                    h = ((unsigned long long)node << 48) | (sk >> 16);
+                    l = ((unsigned)(sk & 0xffffULL) << 16) | (unsigned)i;
+                }
+                xh[p] = h; xl[p] = l;
+            }
+            __syncthreads();
+            for (int k = 2; k <= Upad; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < Upad / 2; t += NT) {
+                        const int i = 2 * j * (t / j) + (t % j), q = i + j;
+                        const unsigned long long ah = xh[i], bh = xh[q];
+                        const unsigned al = xl[i], bl = xl[q];
+                        const bool b_first = bh < ah || (bh == ah && bl < al);  // element q sorts before element i
+                        if (b_first == ((i & k) == 0)) { xh[i] = bh; xl[i] = bl; xh[q] = ah; xl[q] = al; }
+                    }
+                    __syncthreads();
+                }
+            for (int t = tid; t < U; t += NT) {  // slot t holds the t-th element of the level
+                const int snode = (int)(xh[t] >> 48), owner = (int)(xl[t] & 0xffffu);
+                const int ss = L.nstart[snode], ee = L.nend[snode];
+                leftflag[owner] = (t - ss) < (ee - ss) / 2 ? 1 : 0;
+            }
+            __syncthreads();
+        }
         const int NBLK = (U + 63) / 64;
         for (int p0 = 0; p0 < U; p0 += NT) {
             const int p = p0 + tid;
-            bool left = false;
-            if (p < U) {
-                const int node = node_of(L, p, level);
-                const int s = L.nstart[node], e = L.nend[node];
-                const double kp = L.key[p];
-                const int ip = idx[p];
-                int c = 0;
-                for (int q = s; q < e; q++) {
-                    const double kq = L.key[q];
-                    c += (kq < kp || (kq == kp && idx[q] < ip)) ? 1 : 0;
-                }
-                left = c < (e - s) / 2;
-            }
+            const bool left = p < U && L.core[idx[p]] != 0;
             const unsigned long long b = __ballot(left);
             if (p0 + (tid & ~63) < U && lane == 0) L.blk[(p0 + tid) >> 6] = __popcll(b);
             // stash (rank of p among the lefts of its 64-block) | left flag in lab[] (restored to -1 below)
