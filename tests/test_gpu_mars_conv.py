@@ -28,3 +28,25 @@ def test_hip_convs_match_torch_and_oracle(batch):
     assert np.abs(got - ref).max() <= 1e-4, np.abs(got - ref).max()
     assert np.abs(got - ref_t).max() <= 1e-4
     assert np.abs(kp - mars_forward_np(w, x)).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_trained_weights_drop_into_the_hip_inference_path():
+    """mmwave_msc_amd/train.py on the GPU: a few steps of the reference's training loop, then the exported
+    Keras-layout tensors through MarsCNN (fused HIP Conv3D kernel + folded BatchNorms) against the trained
+    network in eval mode."""
+    import numpy as np
+    import torch
+    from mmwave_msc_amd import train as T
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(256, 3, 8, 8, 5)).astype(np.float32)
+    y = rng.normal(0.5, 0.3, size=(256, 57)).astype(np.float32)
+    net = T.MarsTrainNet(3)
+    h = T.fit(net, x, y, x[:32], y[:32], batch_size=64, epochs=3, device="cuda")
+    assert h["loss"][-1] < h["loss"][0]
+    ref = T.predict(net, x, "cuda")
+    inf = T.to_inference(net).to("cuda")
+    assert inf.use_hip_conv
+    got = inf.predict_numpy(x)
+    assert np.max(np.abs(got - ref)) < 1e-3, np.max(np.abs(got - ref))
