@@ -195,3 +195,30 @@ def format_single_frame(track_cloud, mean=None, std_dev=None) -> np.ndarray:
     sb._chk(sb.L.mmw_format_frames(sb.h, b_rows.ptr, b_cnt.ptr, b_ref.ptr, b_out.ptr, 1))
     out = b_out.download((ring, 8, 8, 5), np.float32)
     return out[0] if ring == 1 else out
+
+
+# ---- dataset-side formatters (training-data preparation; host numpy, not on the per-frame path) ------------
+def format_batched_frames(frame_clouds) -> np.ndarray:
+    """The 3 x 64 row block preprocessing saves per track (Utils.py:523-549): frames newest first, per frame the
+    columns (x, y, z, doppler, intensity), cut or zero-padded to 64 rows, NOT sorted; always (192, 5)."""
+    full = np.zeros((3 * 64, 5))
+    for k, cloud in enumerate(reversed(list(frame_clouds))):
+        rows = np.asarray(cloud, dtype=np.float64)[:64][:, [0, 1, 2, -2, -1]]
+        full[k * 64: k * 64 + rows.shape[0]] = rows
+    return full
+
+
+def format_single_frame_mode(track_cloud: np.ndarray, mean, std_dev, batch_size, fuse=False) -> np.ndarray:
+    """A saved (192, 5) block into CNN input (Utils.py:552-574).  Like the reference it normalises the intensity
+    column of `track_cloud` IN PLACE.  fuse=False: the first `batch_size` frames as (batch_size, 8, 8, 5);
+    fuse=True: the non-zero rows of those frames merged into ONE frame -- cut / padded to 64, sorted by x --
+    as (8, 8, 5)."""
+    track_cloud[:, 4] = (track_cloud[:, 4] - mean) / std_dev
+    limited = track_cloud[: 64 * batch_size]
+    if not fuse:
+        return limited.reshape((batch_size, 8, 8, 5))
+    rows = limited[np.any(limited != 0, axis=1)][:64]
+    frame = np.zeros((64, 5))
+    frame[: rows.shape[0]] = rows
+    return frame[np.argsort(frame[:, 0])].reshape((8, 8, 5))
+

@@ -242,6 +242,31 @@ def gen_offline():
           f"1-point frames at {[s[1] for s in seq if s[0] and s[2] == 1]}")
 
 
+def gen_formatters():
+    """Dataset-side formatters (Utils.py:523-574): format_batched_frames, format_single_frame_mode."""
+    const, utils, _ = load_reference()
+    rng = np.random.default_rng(77)
+    out = {}
+    for case, sizes in enumerate([(70, 64, 12), (5, 40), (0, 64, 3), (100,)]):
+        frames = []
+        for n in sizes:
+            f = np.zeros((n, 8))
+            f[:, 0:3] = rng.normal(0, 1, size=(n, 3))
+            f[:, 3:6] = rng.normal(0, 0.3, size=(n, 3))
+            f[:, 6] = rng.normal(0, 0.3, size=n)
+            f[:, 7] = rng.gamma(1.0, 30.0, size=n)
+            frames.append(f.astype(np.float32).astype(np.float64))
+        blk = utils.format_batched_frames([fr.copy() for fr in frames])
+        out[f"c{case}_n"] = np.array(sizes, dtype=np.int32)
+        out[f"c{case}_in"] = np.concatenate(frames) if sum(sizes) else np.zeros((0, 8))
+        out[f"c{case}_block"] = blk
+        for bs in (1, 2, 3):
+            out[f"c{case}_mode{bs}"] = utils.format_single_frame_mode(blk.copy(), 93.0, 40.0, bs, fuse=False)
+            out[f"c{case}_fuse{bs}"] = utils.format_single_frame_mode(blk.copy(), 93.0, 40.0, bs, fuse=True)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "formatters.npz"), meta=_meta(), **out)
+    print("  formatters: 4 cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -260,6 +285,8 @@ def main():
         gen_dbscan()
     if not args.only or args.only == "offline":
         gen_offline()
+    if not args.only or args.only == "formatters":
+        gen_formatters()
     return 0
 
 

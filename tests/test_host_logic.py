@@ -84,3 +84,26 @@ def test_synth_is_deterministic_and_fp32_exact():
     for f in range(4):
         for s in range(3):
             assert np.all(p[f, s, c[f, s]:] == 0)
+
+
+def test_dataset_formatters_match_reference_goldens():
+    """format_batched_frames / format_single_frame_mode (Utils.py:523-574) against outputs recorded from the
+    reference (tests/golden/formatters.npz, oracle/gen_golden.py): pure numpy, bit-equal."""
+    import os
+    import numpy as np
+    from mmwave_msc_amd.utils import format_batched_frames, format_single_frame_mode
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "formatters.npz"), allow_pickle=True)
+    for case in range(4):
+        sizes = g[f"c{case}_n"]
+        flat = g[f"c{case}_in"]
+        frames, o = [], 0
+        for n in sizes:
+            frames.append(flat[o:o + n].copy()); o += n
+        blk = format_batched_frames(frames)
+        assert np.array_equal(blk, g[f"c{case}_block"]), case
+        for bs in (1, 2, 3):
+            b = blk.copy()
+            got = format_single_frame_mode(b, 93.0, 40.0, bs, fuse=False)
+            assert np.array_equal(got, g[f"c{case}_mode{bs}"]), (case, bs)
+            assert not np.array_equal(b[:, 4], blk[:, 4]) or np.all(blk[:, 4] == (blk[:, 4] - 93.0) / 40.0)  # normalised in place
+            assert np.array_equal(format_single_frame_mode(blk.copy(), 93.0, 40.0, bs, fuse=True), g[f"c{case}_fuse{bs}"]), (case, bs)
