@@ -222,3 +222,38 @@ def format_single_frame_mode(track_cloud: np.ndarray, mean, std_dev, batch_size,
     frame[: rows.shape[0]] = rows
     return frame[np.argsort(frame[:, 0])].reshape((8, 8, 5))
 
+
+# ---- output step after the path (what the reference's visualiser computes per track) ------------------------
+def calc_projection_points(x_origin, y_origin, z_origin):
+    """Where the line from the monitoring point (const.M_X, M_Y, M_Z) to a point cuts the screen plane y = 0
+    (Utils.py:180-219): (x, z) on the screen.  Scalars or arrays (one value per track)."""
+    x_o, y_o, z_o = (np.asarray(v, dtype=np.float64) for v in (x_origin, y_origin, z_origin))
+    x_d, y_d, z_d = x_o - const.M_X, y_o - const.M_Y, z_o - const.M_Z
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x_p = np.where(x_d == 0, x_o, -const.M_Y / (y_d / np.where(x_d == 0, 1.0, x_d)) + const.M_X)
+        z_p = np.where(z_d == 0, z_o, -const.M_Y / (y_d / np.where(z_d == 0, 1.0, z_d)) + const.M_Z)
+    if x_p.ndim == 0:
+        return float(x_p), float(z_p)
+    return x_p, z_p
+
+
+def calc_fade_square(track):
+    """Centre and size of the square the smart window fades behind a person (Visualizer.py:14-29): the head
+    keypoint (x index 3, y index 41, z index 22 of the 57-vector) relative to the track position, projected onto
+    the screen; the size shrinks with range.  `track` is anything with `.state.x` and `.keypoints`."""
+    x, kp = track.state.x, track.keypoints
+    centre = calc_projection_points(float(x[0]) + float(kp[3]), float(x[1]) + float(kp[41]), float(kp[22]))
+    size = max(const.V_SCREEN_FADE_SIZE_MIN,
+               min(const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_SIZE_MAX - (float(x[1]) + float(kp[12])) * const.V_SCREEN_FADE_WEIGHT))
+    return centre, size
+
+
+def fade_squares(state_x: np.ndarray, keypoints: np.ndarray):
+    """calc_fade_square for a whole track table at once: state_x[..., >=2], keypoints[..., 57] ->
+    (x_proj[...], z_proj[...], size[...]); what a consumer of the all-gathered table (dist.py) calls."""
+    sx, kp = np.asarray(state_x, dtype=np.float64), np.asarray(keypoints, dtype=np.float64)
+    x_p, z_p = calc_projection_points(sx[..., 0] + kp[..., 3], sx[..., 1] + kp[..., 41], kp[..., 22])
+    size = np.clip(const.V_SCREEN_FADE_SIZE_MAX - (sx[..., 1] + kp[..., 12]) * const.V_SCREEN_FADE_WEIGHT,
+                   const.V_SCREEN_FADE_SIZE_MIN, const.V_SCREEN_FADE_SIZE_MAX)
+    return x_p, z_p, size
+

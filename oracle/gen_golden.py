@@ -263,6 +263,13 @@ def gen_formatters():
         for bs in (1, 2, 3):
             out[f"c{case}_mode{bs}"] = utils.format_single_frame_mode(blk.copy(), 93.0, 40.0, bs, fuse=False)
             out[f"c{case}_fuse{bs}"] = utils.format_single_frame_mode(blk.copy(), 93.0, 40.0, bs, fuse=True)
+    # calc_projection_points (Utils.py:180-219), incl. the x_dist == 0 / z_dist == 0 branches
+    pp = rng.uniform(-3, 6, size=(40, 3))
+    pp[0, 0] = const.M_X
+    pp[1, 2] = const.M_Z
+    pp[2] = [const.M_X, 2.0, const.M_Z]
+    out["proj_in"] = pp
+    out["proj_out"] = np.array([utils.calc_projection_points(*row) for row in pp])
     np.savez_compressed(os.path.join(GOLDEN_DIR, "formatters.npz"), meta=_meta(), **out)
     print("  formatters: 4 cases")
 

@@ -107,3 +107,27 @@ def test_dataset_formatters_match_reference_goldens():
             assert np.array_equal(got, g[f"c{case}_mode{bs}"]), (case, bs)
             assert not np.array_equal(b[:, 4], blk[:, 4]) or np.all(blk[:, 4] == (blk[:, 4] - 93.0) / 40.0)  # normalised in place
             assert np.array_equal(format_single_frame_mode(blk.copy(), 93.0, 40.0, bs, fuse=True), g[f"c{case}_fuse{bs}"]), (case, bs)
+
+
+def test_projection_and_fade_square():
+    """calc_projection_points against values recorded from the reference (Utils.py:180-219); calc_fade_square
+    (Visualizer.py:14-29, not importable here: Qt) against its formula, scalar and table forms agreeing."""
+    import os
+    import types
+    import numpy as np
+    from mmwave_msc_amd import constants as const
+    from mmwave_msc_amd.utils import calc_fade_square, calc_projection_points, fade_squares
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "formatters.npz"), allow_pickle=True)
+    for row, want in zip(g["proj_in"], g["proj_out"]):
+        assert np.array_equal(np.array(calc_projection_points(*row)), want), row
+    xs, zs = calc_projection_points(g["proj_in"][:, 0], g["proj_in"][:, 1], g["proj_in"][:, 2])
+    assert np.array_equal(np.stack([xs, zs], axis=1), g["proj_out"])
+    rng = np.random.default_rng(5)
+    sx = rng.uniform(-2, 6, size=(12, 9))
+    kp = rng.normal(0, 0.5, size=(12, 57))
+    px, pz, size = fade_squares(sx, kp)
+    for t in range(12):
+        tr = types.SimpleNamespace(state=types.SimpleNamespace(x=sx[t]), keypoints=kp[t])
+        (cx, cz), sz = calc_fade_square(tr)
+        assert cx == px[t] and cz == pz[t] and sz == size[t]
+        assert const.V_SCREEN_FADE_SIZE_MIN <= sz <= const.V_SCREEN_FADE_SIZE_MAX
