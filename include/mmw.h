@@ -209,6 +209,25 @@ int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32
 int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2,
                     float *out, int32_t n);
 
+/* ReadIWR14xx.read (ReadDataIWR1443.py:27-201) on a byte buffer, host only (no context, no GPU work): the input
+ * step before mmw_normalize.  Looks for the LAST 8-byte magic word 02 01 04 03 06 05 08 07 in buf[0 .. len-8),
+ * needs more than 16 bytes from there and the whole packet (little-endian u32 totalPacketLen at offset 12).
+ * If the header announces objects and the first TLV is MMWDEMO_UART_MSG_DETECTED_POINTS (type 1), the objects
+ * (u16 count, u16 Q format, then int16 rangeIdx, dopplerIdx, peakVal, x, y, z each) become raw[n][5] =
+ * (x, y, z, doppler, peakVal) -- the row layout mmw_normalize takes -- with x,y,z / 2^Q, doppler =
+ * dopplerIdx * doppler_resolution_mps after the reference's wrap of indices above num_doppler_bins/2 - 1
+ * (it subtracts 65535, in int16), and range_out[n] = rangeIdx * range_idx_to_meters (may be NULL).
+ * Returns 1 (points parsed), 0 (no complete packet, no objects or another TLV first) or MMW_E_ARG;
+ * *packet_start / *packet_len (0 when no complete packet) tell the caller what to drop from its buffer. */
+typedef struct mmw_uart_cfg {
+    double range_idx_to_meters;
+    double doppler_resolution_mps;
+    int32_t num_doppler_bins;
+    int32_t reserved;
+} mmw_uart_cfg;
+int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, double *raw /*[max_obj][5]*/, double *range_out /*[max_obj]*/,
+                   int32_t max_obj, int32_t *n_obj, uint32_t *frame_number, size_t *packet_start, size_t *packet_len);
+
 /* Work counters accumulated by the kernels since the last reset (sync):
  * [0] k_track algorithmic bytes  [1] k_dbscan algorithmic bytes  [2] scene-frames stepped
  * [3] apply_DBscan calls  [4] sum of U over those calls  [5] sum of tracks entering track()

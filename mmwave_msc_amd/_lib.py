@@ -29,6 +29,7 @@ EXPORTS = [
     "mmw_get_num_tracks", "mmw_get_tracks", "mmw_get_batch_ring", "mmw_get_track_ring_frame",
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
+    "mmw_parse_uart",
 ]
 
 
@@ -154,6 +155,7 @@ def load():
         "mmw_stats_reset": (C.c_int, [vp]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
         "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),
+        "mmw_parse_uart": (C.c_int, [vp, C.c_size_t, vp, vp, vp, i32, vp, vp, vp, vp]),
         "mmw_format_frames": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)

@@ -588,6 +588,59 @@ static int read_stats(mmw_ctx *c, uint64_t *out, int words)
     return MMW_OK;
 }
 
+int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, double *raw, double *range_out, int32_t max_obj,
+                   int32_t *n_obj, uint32_t *frame_number, size_t *packet_start, size_t *packet_len)
+{
+    if (!buf || !cfg || !raw || !n_obj || max_obj < 0) return MMW_E_ARG;
+    static const uint8_t magic[8] = {2, 1, 4, 3, 6, 5, 8, 7};
+    auto u32 = [&](size_t o) { return (uint32_t)buf[o] | ((uint32_t)buf[o + 1] << 8) | ((uint32_t)buf[o + 2] << 16) | ((uint32_t)buf[o + 3] << 24); };
+    auto u16 = [&](size_t o) { return (uint32_t)buf[o] | ((uint32_t)buf[o + 1] << 8); };
+    *n_obj = 0;
+    if (frame_number) *frame_number = 0;
+    if (packet_start) *packet_start = 0;
+    if (packet_len) *packet_len = 0;
+    if (len <= 16) return 0;
+    size_t start = len;  // the last magic word that starts in buf[0 .. len-8)
+    for (size_t loc = len - 8; loc-- > 0;)
+        if (memcmp(buf + loc, magic, 8) == 0) { start = loc; break; }
+    if (start == len) return 0;
+    if (packet_start) *packet_start = start;
+    const size_t rem = len - start;
+    if (rem <= 16) return 0;
+    const uint8_t *base = buf + start;
+    buf = base;  // offsets below are relative to the packet
+    const size_t total = u32(12);
+    if (rem < total || total < 36) return 0;
+    if (packet_len) *packet_len = total;
+    if (frame_number) *frame_number = u32(20);
+    const uint32_t num_det = u32(28);
+    if (num_det == 0 || total < 36 + 8 + 4) return 0;
+    size_t idx = 36;
+    const uint32_t tlv_type = u32(idx);
+    idx += 8;  // type, length
+    if (tlv_type != 1) return 0;
+    const uint32_t num = u16(idx), qfmt = u16(idx + 2);
+    idx += 4;
+    if ((int64_t)num > (int64_t)max_obj) return MMW_E_ARG;
+    if (idx + (size_t)num * 12 > rem) return 0;
+    const double q = ldexp(1.0, (int)qfmt);
+    const double half = cfg->num_doppler_bins / 2.0 - 1;
+    for (uint32_t o = 0; o < num; o++, idx += 12) {
+        const int16_t range_idx = (int16_t)u16(idx), peak = (int16_t)u16(idx + 4);
+        int16_t dop = (int16_t)u16(idx + 2);
+        const int16_t x = (int16_t)u16(idx + 6), y = (int16_t)u16(idx + 8), z = (int16_t)u16(idx + 10);
+        if ((double)dop > half) dop = (int16_t)((int32_t)dop - 65535);  // ReadDataIWR1443.py:150-157 (wraps in int16)
+        raw[o * 5 + 0] = (double)x / q;
+        raw[o * 5 + 1] = (double)y / q;
+        raw[o * 5 + 2] = (double)z / q;
+        raw[o * 5 + 3] = (double)dop * cfg->doppler_resolution_mps;
+        raw[o * 5 + 4] = (double)peak;
+        if (range_out) range_out[o] = (double)range_idx * cfg->range_idx_to_meters;
+    }
+    *n_obj = (int32_t)num;
+    return 1;
+}
+
 int mmw_stats_get(mmw_ctx *c, uint64_t *out)
 {
     if (!c || !out) return MMW_E_ARG;

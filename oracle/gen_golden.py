@@ -274,6 +274,85 @@ def gen_formatters():
     print("  formatters: 4 cases")
 
 
+def _uart_packet(frame, objs, qfmt=9, tlv_type=1, num_det=None):
+    """One TI mmWave demo UART packet (header 36 B + one TLV) carrying `objs` = rows of int16
+    (rangeIdx, dopplerIdx, peakVal, x, y, z)."""
+    import struct
+    body = struct.pack("<HH", len(objs), qfmt) + b"".join(struct.pack("<6h", *[int(v) for v in o]) for o in objs)
+    tlv = struct.pack("<II", tlv_type, len(body)) + body
+    total = 36 + len(tlv)
+    hdr = bytes([2, 1, 4, 3, 6, 5, 8, 7]) + struct.pack("<IIIIIII", 0x01020304, total, 0xA1443, frame, 123456,
+                                                        len(objs) if num_det is None else num_det, 1)
+    return hdr + tlv
+
+
+def gen_uart():
+    """ReadIWR14xx.read (ReadDataIWR1443.py:27-201) on synthetic byte streams: the module is imported with the
+    pyserial stand-in, __init__ (which opens ports) is bypassed, a fake Dataport delivers the chunks."""
+    import importlib
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "serial_shim"))
+    load_reference()
+    mod = importlib.import_module("ReadDataIWR1443")
+
+    class Port:
+        def __init__(self):
+            self.q = b""
+        @property
+        def in_waiting(self):
+            return len(self.q)
+        def read(self, n):
+            d, self.q = self.q[:n], self.q[n:]
+            return d
+        def write(self, *_):
+            pass
+        def close(self):
+            pass
+
+    cfgp = {"rangeIdxToMeters": 0.0436, "dopplerResolutionMps": 0.1252, "numDopplerBins": 16.0}
+    rd = object.__new__(mod.ReadIWR14xx)
+    rd.MMWDEMO_UART_MSG_DETECTED_POINTS = 1
+    rd.maxBufferSize = 2 ** 15
+    rd.magicWord = [2, 1, 4, 3, 6, 5, 8, 7]
+    rd.byteBuffer = np.zeros(2 ** 15, dtype="uint8")
+    rd.byteBufferLength = 0
+    rd.configParameters = cfgp
+    rd.Dataport = Port()
+    rd.CLIport = Port()
+    rng = np.random.default_rng(11)
+
+    def objs(n):
+        o = np.zeros((n, 6), dtype=np.int64)
+        o[:, 0] = rng.integers(0, 200, n)
+        # (non-negative int16 only: under numpy >= 2 the reference raises OverflowError when it stores a u16 above
+        #  32767 into its int16 arrays; with its pinned numpy 1.26 such values wrap, which is what the C parser does)
+        o[:, 1] = rng.integers(0, 16, n)         # doppler bins on both sides of numDopplerBins/2 - 1
+        o[:, 2] = rng.integers(0, 3000, n)
+        o[:, 3:6] = rng.integers(0, 2500, size=(n, 3))
+        return o
+
+    # Only packets whose first TLV is NOT decoded (no objects, or another TLV type): under numpy >= 2 the
+    # reference's decode branch raises OverflowError at `dopplerIdx[...] - 65535` (ReadDataIWR1443.py:150-157)
+    # for every detected-points packet, so that branch cannot be recorded here.  What IS recorded: the byte
+    # buffer discipline (garbage before the magic word, packets split over reads, several packets per read --
+    # the LAST magic word wins --, the "remove processed data" rule) and the header fields.
+    p1, p2, p3 = _uart_packet(7, objs(0)), _uart_packet(8, objs(3), tlv_type=2), _uart_packet(9, objs(0))
+    p4, p5 = _uart_packet(10, objs(6), tlv_type=6), _uart_packet(11, objs(0), num_det=0)
+    chunks = [b"\x00\x11\x02\x01garbage" + p1, p2, p3[:30], p3[30:], p4 + p5, b"\x05" * 10, _uart_packet(13, objs(2), tlv_type=3),
+              b"\x02\x01\x04", p1[:20], p1[20:] + p2[:10], p2[10:]]
+    out = {"n_chunks": np.int32(len(chunks)), "cfg": np.array([cfgp["rangeIdxToMeters"], cfgp["dopplerResolutionMps"], cfgp["numDopplerBins"]])}
+    for i, ch in enumerate(chunks):
+        rd.Dataport.q = ch
+        ok, fn, det = rd.read()
+        out[f"chunk{i}"] = np.frombuffer(ch, dtype=np.uint8)
+        out[f"ok{i}"] = np.int32(ok)
+        out[f"frame{i}"] = np.int64(fn)
+        out[f"buflen{i}"] = np.int64(rd.byteBufferLength)
+        if ok:
+            out[f"det{i}"] = np.stack([np.asarray(det[k], dtype=np.float64) for k in ("x", "y", "z", "doppler", "peakVal", "range")], axis=1)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "uart.npz"), meta=_meta(), **out)
+    print(f"  uart: {len(chunks)} chunks, ok = {[int(out[f'ok{i}']) for i in range(len(chunks))]}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -294,6 +373,8 @@ def main():
         gen_offline()
     if not args.only or args.only == "formatters":
         gen_formatters()
+    if not args.only or args.only == "uart":
+        gen_uart()
     return 0
 
 
