@@ -886,13 +886,16 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
         __builtin_amdgcn_s_setprio(3);  // the latency chain goes first whenever it has an instruction ready
         if ((int)blockIdx.x == G0 - 1) {
             // (the worker least likely to have a scene) next frame's schedule for k_track: scenes by descending
-            // track count -- a counting sort over the scene headers; the order inside a count is irrelevant
+            // track count -- a counting sort over the scene headers; the order inside a count is irrelevant.
+            // The key is n_upd, which nothing in this launch writes: n_tracks may be raised by a spawning worker
+            // between the two passes, and a scene counted in one bin but scattered into another would break the
+            // permutation.
             int *hist = reinterpret_cast<int *>(lds_raw);  // [t_cap + 2]
             const int nb = cfg.t_cap + 1;
             for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
             __syncthreads();
             for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
-                int t = st.hdr[s].n_tracks;
+                int t = st.hdr[s].n_upd;
                 t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
                 atomicAdd(&hist[nb - 1 - t], 1);  // bin 0 = most tracks
             }
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             }
             __syncthreads();
             for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
-                int t = st.hdr[s].n_tracks;
+                int t = st.hdr[s].n_upd;
                 t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
                 st.perm[(size_t)(parity ^ 1) * cfg.n_scenes + atomicAdd(&hist[nb - 1 - t], 1)] = s;
             }

@@ -304,6 +304,19 @@ __global__ __launch_bounds__(kThreads, (PPT <= 2 ? 5 : 3)) void k_track(DevCfg c
     {
         const int NB = (n + 63) / 64;
         unsigned long long mybal[PPT];
+        // ring state of track `tid` (thread T: of the global ring), needed after the scans below: requested now so
+        // that the global round trip runs under the ballots and scans (T <= t_cap <= 64 < 256 threads)
+        int sd_len = 0, sd_rs[MMW_RING_MAX] = {0, 0, 0, 0};
+        if (tid < T) {
+            const TrackRec *rec = trk + L.slot[tid];
+            sd_len = rec->ring_len;
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = rec->ring_slot[k];
+        } else if (tid == T) {
+            sd_len = hdr->g_len;
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = hdr->g_slot[k];
+        }
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
@@ -339,31 +352,15 @@ __global__ __launch_bounds__(kThreads, (PPT <= 2 ? 5 : 3)) void k_track(DevCfg c
             for (int k = 0; k < c; k++) run += L.cls_n[k];
             L.cls_off[c] = run;
         }
-        // where this frame's rows go, from the ring state BEFORE this frame's push (the bookkeeping itself
-        // happens after the copies): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
-        for (int j = tid; j <= T; j += kThreads) {
-            if (j < T) {
-                const TrackRec *rec = trk + L.slot[j];
-                const int len = rec->ring_len;  // (length and all slots requested together: one round trip)
-                int rs[MMW_RING_MAX];
+        // where this frame's rows go, from the ring state BEFORE this frame's push (requested at the start of the
+        // split, see there): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
+        if (tid <= T) {
+            int phys = sd_rs[0];
 #pragma unroll
-                for (int k = 0; k < MMW_RING_MAX; k++) rs[k] = rec->ring_slot[k];
-                int phys = rs[0];
-#pragma unroll
-                for (int k = 1; k < MMW_RING_MAX; k++) if (len < cfg.ring && k == len) phys = rs[k];
-                L.seg_dst[j] = (((long long)s * cfg.t_cap + L.slot[j]) * cfg.ring + phys) * (long long)cfg.ring_rows * 8;
-            } else {
-                const int len = hdr->g_len;
-                int rs[MMW_RING_MAX];
-#pragma unroll
-                for (int k = 0; k < MMW_RING_MAX; k++) rs[k] = hdr->g_slot[k];
-                int phys = rs[0];
-#pragma unroll
-                for (int k = 1; k < MMW_RING_MAX; k++) if (len < cfg.ring && k == len) phys = rs[k];
-                L.seg_dst[j] = ((long long)s * cfg.ring + phys) * (long long)NP * 8;
-            }
+            for (int k = 1; k < MMW_RING_MAX; k++) if (sd_len < cfg.ring && k == sd_len) phys = sd_rs[k];
+            L.seg_dst[tid] = tid < T ? (((long long)s * cfg.t_cap + L.slot[tid]) * cfg.ring + phys) * (long long)cfg.ring_rows * 8
+                                     : ((long long)s * cfg.ring + phys) * (long long)NP * 8;
         }
-        PROBE(29);
         lds_barrier();
         PROBE(30);
 #pragma unroll
