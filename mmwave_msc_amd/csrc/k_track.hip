@@ -187,7 +187,7 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 // PPT = points per thread = ceil(max_pts / 256): a template so that per-point registers are not
 // reserved for points a configuration can never have.
 template <int PPT>
-__global__ __launch_bounds__(kThreads, (PPT <= 2 ? 5 : 3)) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+__global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out,
                                                     int32_t *__restrict__ db_labels_out, int UM_out, int parity)
@@ -709,9 +709,21 @@ __global__ __launch_bounds__(kThreads, (PPT <= 2 ? 5 : 3)) void k_track(DevCfg c
     const int Udb = L.misc[2];
     if (Udb > 0) {  // uniform
         bool listed = true;
+        int *grid = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 4096);  // (cleared after the fence above)
+        unsigned long long *mm = reinterpret_cast<unsigned long long *>(grid + kCloudGrid);
         if (Udb <= 256) {
-            int *grid = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 4096);  // (cleared after the fence above)
-            listed = !cloud_cells_prove_no_core(cfg, Udb, sx, sy, sz, reinterpret_cast<unsigned long long *>(grid + kCloudGrid), &L.misc[12], grid);
+            listed = !cloud_cells_prove_no_core(cfg, Udb, sx, sy, sz, mm, &L.misc[12], grid);
+        } else {  // large clouds (no tracks yet, or lost): rows from the global ring (the fence above made this frame's visible)
+            const int *gs = L.misc + 4, *gn = L.misc + 8;
+            const int nfr = L.misc[3], big = 0x7fffffff;
+            RowSrc src;
+            src.gb = st.g_ring + (size_t)s * cfg.ring * (size_t)NP * 8;
+            src.stride = (size_t)NP * 8;
+            src.slots = (unsigned)gs[0] | ((unsigned)gs[1] << 8) | ((unsigned)gs[2] << 16) | ((unsigned)gs[3] << 24);
+            src.c1 = nfr > 1 ? gn[0] : big;
+            src.c2 = nfr > 2 ? gn[0] + gn[1] : big;
+            src.c3 = nfr > 3 ? gn[0] + gn[1] + gn[2] : big;
+            listed = !cloud_cells_prove_no_core_rows(cfg, src, Udb, mm, &L.misc[12], grid);
         }
         if (listed) {
             if (tid == 0) {  // work list 3: clouds <= 256 points (k_post), 1 and 2: larger ones (k_dbscan_big)

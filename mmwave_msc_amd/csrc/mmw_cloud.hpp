@@ -67,12 +67,13 @@ __device__ __forceinline__ RowSrc ring_rows_of(const DevCfg &cfg, const DevState
 
 
 // apply_DBscan found (or can find) nothing: labels -1, bookkeeping as after a full run with 0 clusters
-// (all threads of a 256-thread workgroup call; U <= 256)
+// (all threads of the workgroup call)
 __device__ __forceinline__ void cloud_finish_empty(const DevState &st, SceneHdr *hdr, int s, int U, int UM_out,
                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
     const int tid = threadIdx.x;
-    if (labels_out && tid < U) labels_out[(size_t)s * UM_out + tid] = -1;
+    if (labels_out)
+        for (int i = tid; i < U; i += blockDim.x) labels_out[(size_t)s * UM_out + i] = -1;
     if (tid == 0) {
         if (db_n_out) db_n_out[s] = U;
         hdr->need_db = 0;
@@ -149,6 +150,57 @@ __device__ __forceinline__ bool cloud_cells_prove_no_core(const DevCfg &cfg, int
 #pragma unroll
             for (int dx = -2; dx <= 2; dx++) c += grid[((cy + dy) & 31) * 32 + ((cx + dx) & 31)];
         maybe = c >= min_samples;
+    }
+    if (maybe) *flag = 1;
+    lds_barrier();
+    return *flag == 0;
+}
+
+// Stage 1 for clouds of more than 256 points (up to 8 per thread: U <= 2048), rows read from the scene's global
+// ring: a scene without tracks keeps three full frames of clutter in the ring, and without this its apply_DBscan
+// would pay the O(U^2) pair count of dbscan_core in every frame.  Same contract as above.
+__device__ __forceinline__ bool cloud_cells_prove_no_core_rows(const DevCfg &cfg, const RowSrc src, int U, unsigned long long *mm,
+                                                               int *flag, int *grid)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
+    const int min_samples = cfg.db_min_samples;
+    if (!(min_samples > 1 && zw >= 0.0 && eps >= 0.0) || U > 8 * 256) return false;
+    const double sqzw = sqrt(zw);
+    double mag = 0.0;
+    for (int p = tid; p < U; p += 256) {
+        const double *r = src.row(p);
+        const double2 a = *reinterpret_cast<const double2 *>(r);
+        double m = fmax(fmax(fabs(a.x), fabs(a.y)), fabs(r[2] * sqzw));
+        if (!(m <= 1e15)) m = __longlong_as_double(0x7ff0000000000000LL);
+        mag = fmax(mag, m);
+    }
+    mag = wave_max_d(mag);
+    if (lane == 0) atomicMax(&mm[0], (unsigned long long)__double_as_longlong(mag));
+    lds_barrier();
+    const double M = __longlong_as_double((long long)mm[0]);
+    const double wmin = 1.0 - fabs(rw) * M;
+    if (!(wmin > 0.0) || !(M <= 1e15)) return false;  // uniform
+    const double R = sqrt(2.0 * (eps / wmin)) * (1.0 + 1e-9) + 4.0 * M * 6e-8;
+    const double h = 0.5 * R * (1.0 + 1e-3);
+    if (!(h > 0.0) || !(M / h < 1e4)) return false;
+    const float invh = (float)(1.0 / h);
+    for (int p = tid; p < U; p += 256) {
+        const double2 a = *reinterpret_cast<const double2 *>(src.row(p));
+        const int cx = (int)floorf((float)a.x * invh) & 31, cy = (int)floorf((float)a.y * invh) & 31;
+        atomicAdd(&grid[cy * 32 + cx], 1);
+    }
+    lds_barrier();
+    bool maybe = false;
+    for (int p = tid; p < U; p += 256) {  // (rows again: they are in L2, and eight cell indices per thread would spill)
+        const double2 a = *reinterpret_cast<const double2 *>(src.row(p));
+        const int cx = (int)floorf((float)a.x * invh) & 31, cy = (int)floorf((float)a.y * invh) & 31;
+        int c = 0;
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+            for (int dx = -2; dx <= 2; dx++) c += grid[((cy + dy) & 31) * 32 + ((cx + dx) & 31)];
+        maybe = maybe || c >= min_samples;
     }
     if (maybe) *flag = 1;
     lds_barrier();

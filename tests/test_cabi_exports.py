@@ -56,3 +56,27 @@ def test_track_record_dtype_matches_c_struct():
     # x9 P81 c6 mn6 mx6 sp6 gd36 n_est lifetime = 152 doubles; 8 ints; 57 floats (+pad to 8)
     assert _lib.TRACK_DTYPE.itemsize == 152 * 8 + 8 * 4 + 57 * 4 + 4
     assert _lib.SUMMARY_DTYPE.itemsize == 5 * 4 + 4 + (9 + 6 + 57) * 4
+
+
+def test_step_kernels_compile_without_scratch():
+    """The association kernel synchronises its phases with an LDS-only barrier written in inline assembly
+    (mmw_math.hpp lds_barrier).  A build of k_track that spilled registers around it once produced spurious
+    error bits on the GPU; all three points-per-thread variants are kept spill-free, and this checks the compiler's
+    own resource report so that a later change cannot reintroduce spills silently."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmwave_msc_amd", "csrc", "k_track.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                          "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
+                         capture_output=True, text=True, timeout=600)
+    rep = out.stderr
+    names = re.findall(r"Function Name: (\S*k_track\S*)", rep)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", rep)]
+    assert len(names) >= 3 and len(scratch) >= 3, rep[-2000:]
+    assert all(v == 0 for v in scratch[:len(names)]), list(zip(names, scratch))
