@@ -76,7 +76,11 @@ __device__ __forceinline__ void wave_sync()
 // such wait.  Use only where no thread reads global memory another thread of the workgroup wrote.
 __device__ __forceinline__ void lds_barrier()
 {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // release / acquire at workgroup scope for the LDS address space only: the compiler emits
+    // s_waitcnt lgkmcnt(0) ; s_barrier and leaves outstanding global stores (vmcnt) alone
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // 6x6 partial-pivot LU, determinant and inverse (stands for np.linalg.det / np.linalg.inv at

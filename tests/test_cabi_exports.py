@@ -59,10 +59,10 @@ def test_track_record_dtype_matches_c_struct():
 
 
 def test_step_kernels_compile_without_scratch():
-    """The association kernel synchronises its phases with an LDS-only barrier written in inline assembly
-    (mmw_math.hpp lds_barrier).  A build of k_track that spilled registers around it once produced spurious
-    error bits on the GPU; all three points-per-thread variants are kept spill-free, and this checks the compiler's
-    own resource report so that a later change cannot reintroduce spills silently."""
+    """All three points-per-thread variants of the association kernel are kept free of register spills (a build
+    that spilled, while its LDS-only barrier was still inline assembly, once produced spurious error bits on the
+    GPU; the barrier is compiler builtins now, the no-spill rule stays).  This reads the compiler's own resource
+    report so that a later change cannot reintroduce spills silently."""
     import os
     import re
     import shutil
