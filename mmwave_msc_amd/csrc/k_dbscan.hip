@@ -823,10 +823,23 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
         const int c = t / 6, m = t % 6;
         const int n = L.cl_n[c], off = L.cl_off[c];
         TrackRec *rec = trk + order[T0 + c];
+        // (rows come from the global ring -- the LDS x,y,z are in tree-position order by now --: eight loads in
+        //  flight per round trip, the sum itself stays sequential in row order)
         double sum = 0.0, mn = 0.0, mx = 0.0;
-        for (int r = 0; r < n; r++) {
-            const int i = memb[off + r];
-            const double v = src.row(i)[m];  // (LDS x,y,z are in tree-position order by now)
+        int r = 0;
+        for (; r + 8 <= n; r += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src.row(memb[off + r + u])[m];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                sum += v[u];
+                mn = (r + u == 0 || v[u] < mn) ? v[u] : mn;
+                mx = (r + u == 0 || v[u] > mx) ? v[u] : mx;
+            }
+        }
+        for (; r < n; r++) {
+            const double v = src.row(memb[off + r])[m];
             sum += v;
             mn = (r == 0 || v < mn) ? v : mn;
             mx = (r == 0 || v > mx) ? v : mx;
