@@ -108,16 +108,17 @@ __device__ __forceinline__ bool lu6_inverse_cols(double (&v)[6], int lane, doubl
         for (int i = 0; i < 6; i++) v[i] = (c - 6 == i) ? 1.0 : 0.0;
     }
     bool neg = false, ok = true;
-    double rp[6];
+    double rp[6], d = 1.0;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         // this lane's column as if it were column k: pivot row, 1/pivot, swapped column, multipliers
         int p = k;
-        double best = fabs(v[k]), pv = v[k];
+        double pv = v[k];
 #pragma unroll
         for (int r2 = k + 1; r2 < 6; r2++) {
-            const double t = fabs(v[r2]);
-            if (t > best) { best = t; p = r2; pv = v[r2]; }
+            const bool gt = fabs(v[r2]) > fabs(pv);  // first maximum of |column|
+            p = gt ? r2 : p;
+            pv = gt ? v[r2] : pv;
         }
         const double rpl = 1.0 / pv;
         double l[6];
@@ -125,36 +126,33 @@ __device__ __forceinline__ bool lu6_inverse_cols(double (&v)[6], int lane, doubl
         for (int i = k + 1; i < 6; i++) l[i] = ((p == i) ? v[k] : v[i]) * rpl;  // row i after the swap k <-> p
         // what lane k found, for the whole group
         p = __shfl(p, gb + k);
-        best = __shfl(best, gb + k);
+        pv = __shfl(pv, gb + k);
         rp[k] = __shfl(rpl, gb + k);
 #pragma unroll
         for (int i = k + 1; i < 6; i++) l[i] = __shfl(l[i], gb + k);
-        if (!(best > 0.0)) ok = false;
+        if (!(fabs(pv) > 0.0)) ok = false;
         if (p != k) neg = !neg;
+        d = (k == 0) ? pv : d * pv;  // the pivots in order
         {  // rows k <-> p of this lane's column
             const double tk = v[k];
 #pragma unroll
             for (int r2 = k + 1; r2 < 6; r2++)
                 if (p == r2) { v[k] = v[r2]; v[r2] = tk; }
         }
+        // every lane eliminates: in columns <= k this only overwrites entries below the diagonal (the L
+        // factors), which nothing reads again -- the right-hand sides see the row operations as they happen
 #pragma unroll
-        for (int i = k + 1; i < 6; i++) {
-            const double e = v[i] - l[i] * v[k];
-            v[i] = (c == k) ? l[i] : ((c > k) ? e : v[i]);  // column k keeps L, finished columns stay
-        }
+        for (int i = k + 1; i < 6; i++) v[i] = v[i] - l[i] * v[k];
     }
-    // U above the diagonal and the pivots, all at once
-    double u[6][6], piv[6];
+    det = neg ? -d : d;
+    // U above the diagonal, all at once (one cross-lane round trip); after that the lanes that held U may
+    // overwrite it -- only lanes 6..11 carry a result
+    double u[6][6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        piv[k] = __shfl(v[k], gb + k);
+    for (int k = 1; k < 6; k++) {
 #pragma unroll
         for (int r = 0; r < k; r++) u[r][k] = __shfl(v[r], gb + k);
     }
-    double d = piv[0];
-#pragma unroll
-    for (int k = 1; k < 6; k++) d = d * piv[k];
-    det = neg ? -d : d;
 #pragma unroll
     for (int k = 5; k >= 0; k--) {
         v[k] = v[k] * rp[k];
