@@ -70,6 +70,7 @@ struct DbLds {
     int *cnt;                      // [NB][CL+1] cluster member counting (spawn)
     int *cl_n, *cl_off;            // [CL+2]
     double *ccen;                  // [CL+1][6]
+    double *fst;                   // [kFrontChunk][4] frontier staging of the labelling: mask bits, x, y, z
 };
 
 __host__ __device__ inline size_t db_align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -88,6 +89,7 @@ __host__ __device__ inline int db_levels(int U)
 // ALL8 build: private copies of the per-node min/max keys (picked by lane & 7), merged after the atomics -- all
 // lanes of a wave hitting the same sixteen LDS words serialise 64-fold
 constexpr int kMmCopies = 8;
+constexpr int kFrontChunk = 32;
 
 template <bool WRITE>
 __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool all8, char *base, DbLds *L)
@@ -124,6 +126,7 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(cl_n, int, CL + 2)
     CARVE(cl_off, int, CL + 2)
     CARVE(ccen, double, (CL + 1) * 6)
+    CARVE(fst, double, kFrontChunk * 4)
 #undef CARVE
     return off;
 }
@@ -459,6 +462,25 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             unsigned *xl = reinterpret_cast<unsigned *>(L.front);
             unsigned char *leftflag = L.core;  // by point index (free until the queries)
             const int Upad = db_pow2ceil(U);
+            if (Upad <= NT && db_pow2ceil(UMc) >= NT) {  // (the exchange arrays hold pow2ceil(UMc) slots)
+                // one slot per thread: the register network of the ALL8 build (cross-lane inside a wave, LDS only
+                // for partner distances >= 64) -- 6 exchange rounds through LDS instead of 45 for 512 slots
+                unsigned long long h = ~0ULL;  // padding sorts to the end
+                unsigned l = ~0u;
+                if (tid < U) {
+                    const int node = node_of(L, tid, level), i = idx[tid];
+                    const unsigned long long sk = sortable(feature(i, L.sdim[node - first]));
+                    h = ((unsigned long long)node << 48) | (sk >> 16);
+                    l = ((unsigned)(sk & 0xffffULL) << 16) | (unsigned)i;
+                }
+                BitonicK<2, NT>::run(h, l, tid, xh, xl);
+                if (tid < U) {  // slot tid holds the tid-th element of the level
+                    const int snode = (int)(h >> 48), owner = (int)(l & 0xffffu);
+                    const int ss = L.nstart[snode], ee = L.nend[snode];
+                    leftflag[owner] = (tid - ss) < (ee - ss) / 2 ? 1 : 0;
+                }
+                __syncthreads();
+            } else {
             for (int p = tid; p < Upad; p += NT) {
                 unsigned long long h = ~0ULL;  // padding sorts to the end
                 unsigned l = ~0u;
@@ -488,6 +510,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 leftflag[owner] = (t - ss) < (ee - ss) / 2 ? 1 : 0;
             }
             __syncthreads();
+            }
         }
         const int NBLK = (U + 63) / 64;
         for (int p0 = 0; p0 < U; p0 += NT) {
@@ -687,29 +710,53 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         __syncthreads();
         int fcount = 1;
         while (fcount > 0) {
-            for (int q = tid; q < U; q += NT) {
-                if (L.lab[q] >= 0) continue;
-                const int lq = L.leafpos[q];
-                const double qx = L.X[q], qy = L.Y[q], qz = L.Z[q];
-                bool hit = false;
-                for (int f = 0; f < fcount && !hit; f += 4) {  // four frontier points per round trip to LDS
-                    int pp[4];
-                    unsigned long long mk[4];
-                    double fx[4], fy[4], fz[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) pp[u] = front[f + u < fcount ? f + u : f];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { mk[u] = L.mask[pp[u]]; fx[u] = L.X[pp[u]]; fy[u] = L.Y[pp[u]]; fz[u] = L.Z[pp[u]]; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int stt = (int)((mk[u] >> (2 * lq)) & 3ULL);
-                        if (stt == 1) hit = true;
-                        else if (stt == 2 && alt_dist(fx[u], fy[u], fz[u], qx, qy, qz, rw, zw) <= eps) hit = true;
-                    }
+            // The frontier goes through a contiguous staging array, kFrontChunk points at a time: every thread
+            // then reads the same addresses (LDS broadcast) that depend on nothing it loaded before, so one
+            // round trip brings four entries instead of a position load followed by four dependent gathers.
+            for (int f0 = 0; f0 < fcount; f0 += kFrontChunk) {
+                const int fc = fcount - f0 < kFrontChunk ? fcount - f0 : kFrontChunk;
+                if (f0 > 0) __syncthreads();  // the previous chunk has been consumed
+                if (tid < fc) {
+                    const int pp = front[f0 + tid];
+                    L.fst[tid * 4 + 0] = __longlong_as_double((long long)L.mask[pp]);
+                    L.fst[tid * 4 + 1] = L.X[pp];
+                    L.fst[tid * 4 + 2] = L.Y[pp];
+                    L.fst[tid * 4 + 3] = L.Z[pp];
                 }
-                if (hit) {
-                    L.lab[q] = n_clusters;
-                    if (L.core[q]) next[atomicAdd(&L.misc[2], 1)] = q;
+                __syncthreads();
+                for (int q = tid; q < U; q += NT) {
+                    if (L.lab[q] >= 0) continue;
+                    const int lq = L.leafpos[q];
+                    const double qx = L.X[q], qy = L.Y[q], qz = L.Z[q];
+                    bool hit = false;
+                    for (int f = 0; f < fc && !hit; f += 4) {
+                        double4 en[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const double2 *e2 = reinterpret_cast<const double2 *>(L.fst + (f + u < fc ? f + u : f) * 4);
+                            const double2 a = e2[0], b = e2[1];
+                            en[u] = make_double4(a.x, a.y, b.x, b.y);
+                        }
+                        // leaf states first: most (point, frontier point) pairs are PRUNE, and a wave's 64 points
+                        // sit in one or two leaves, so the distance block below is skipped by whole waves
+                        int stt[4];
+                        bool test = false;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            stt[u] = (int)(((unsigned long long)__double_as_longlong(en[u].x) >> (2 * lq)) & 3ULL);
+                            hit = hit || stt[u] == 1;
+                            test = test || stt[u] == 2;
+                        }
+                        if (test && !hit) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++)
+                                if (stt[u] == 2 && alt_dist(en[u].y, en[u].z, en[u].w, qx, qy, qz, rw, zw) <= eps) hit = true;
+                        }
+                    }
+                    if (hit) {
+                        L.lab[q] = n_clusters;
+                        if (L.core[q]) next[atomicAdd(&L.misc[2], 1)] = q;
+                    }
                 }
             }
             __syncthreads();
@@ -958,7 +1005,8 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
 // Work lists 1 and 2 (clouds of more than 256 points: the start-up frames of a scene) in one launch: blocks
 // [0, g1) take list 1 with the class-1 LDS carve-up, the others list 2.  In the steady state both lists
 // are empty and this is one small wave of workgroups that leave at once.
-__global__ __launch_bounds__(256) void k_dbscan_big(DevCfg cfg, DevState st, int g1, int UMc1, int CL1, int UMc2, int CL2, int UM_out,
+constexpr int kBigThreads = 512;
+__global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState st, int g1, int UMc1, int CL1, int UMc2, int CL2, int UM_out,
                                                     int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -970,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_dbscan_big(DevCfg cfg, DevState st, int
     const int count = st.db_count[parity * 4 + cls];
     for (int w = b0; w < count; w += nb) {
         const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
-        spawn_scene<256, false>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
+        spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
         __syncthreads();  // LDS is reused by the next scene
     }
 }
@@ -1058,11 +1106,11 @@ void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity
     const size_t lds1 = dbscan_lds_bytes(1, UM, cfg.t_cap, cfg.db_min_samples), lds2 = two ? dbscan_lds_bytes(2, UM, cfg.t_cap, cfg.db_min_samples) : 0;
     const size_t lds = lds1 > lds2 ? lds1 : lds2;
     int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));  // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 2048 / kBigThreads) per_cu = 2048 / kBigThreads;
     if (per_cu < 1) per_cu = 1;
     int g = 256 * per_cu;
     if (g > S) g = S;
-    mmw_launch(k_dbscan_big, dim3(two ? 2 * g : g), dim3(256), lds, stream, cfg, st, g, um1, cl1, um2, cl2, UM, parity, labels, db_n);
+    mmw_launch(k_dbscan_big, dim3(two ? 2 * g : g), dim3(kBigThreads), lds, stream, cfg, st, g, um1, cl1, um2, cl2, UM, parity, labels, db_n);
 }
 
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
