@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: the lone big-cloud BallTree chain (k_dbscan_big with a handful of scenes, i.e. one workgroup per CU
 and nothing else on the chip), per start-up frame: duration from the launch-attached events and, with
-MMW_LIB_NAME=libmmw_hip_stamps.so, the per-phase cycle shares.  usage: exp_big_chain.py [scenes]"""
+MMW_LIB_NAME=libmmw_hip_stamps.so, the per-phase cycle shares.  usage: exp_big_chain.py [scenes [points [targets]]] -- 8 512 8 is the big chain, 8 128 2 the small one (k_post worker)"""
 import os
 import sys
 
@@ -13,9 +13,11 @@ from mmwave_msc_amd import _lib  # noqa: E402
 from mmwave_msc_amd.batch import SceneBatch  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-N, T, F = 512, 8, 6
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+F = 6
 stamps = "stamps" in os.environ.get("MMW_LIB_NAME", "")
-ids = np.arange(S) * 8 + 7  # eight targets per scene
+ids = np.arange(S) * T + (T - 1)  # T targets per scene
 pts, cnt, dts = bench.generate(ids, F, N, T, workers=1)
 sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
 bp = sb.alloc(S * N * 64); bn = sb.alloc(S * 4); bd = sb.alloc(S * 8)
