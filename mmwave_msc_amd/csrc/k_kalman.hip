@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
         const int j = j0 + g;
         const bool live = j < T;
         TrackRec *rec = trk + (live ? order[j] : 0);
-        stage_record(rec, Wj, c, live);
+        stage_record(rec, Wj, c);
         wave_sync();
         const double dtm = Wj[rLife] + dt;
         const double h = 0.5 * (dtm * dtm);

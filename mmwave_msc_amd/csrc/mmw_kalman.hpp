@@ -16,20 +16,25 @@ constexpr int rX = 0, rP = 9, rCen = 90, rSpr = 108, rGd = 114, rNest = 150, rLi
 static_assert(offsetof(TrackRec, P) == rP * 8 && offsetof(TrackRec, centroid) == rCen * 8 && offsetof(TrackRec, spread) == rSpr * 8 &&
               offsetof(TrackRec, gd) == rGd * 8 && offsetof(TrackRec, n_est) == rNest * 8 && offsetof(TrackRec, lifetime) == rLife * 8 &&
               offsetof(TrackRec, point_num) == rInts * 8, "TrackRec prefix layout");
+constexpr int kRecStage = 160;  // words actually copied: ten per lane of a 16-lane group (see stage_record)
+static_assert(kRecStage >= kRecRaw && kRecStage * 8 <= (int)sizeof(TrackRec), "staged prefix");
 
 // per-track LDS scratch (doubles)
-constexpr int pA = kRecRaw, pXn = pA + 81, pS = pXn + 9, kPredScratch = pS + 2;
-constexpr int uA = kRecRaw, uK = uA + 81, uSI = uK + 54, uC1 = uSI /* C1 replaces S^-1 once K is formed */, uY = uSI + 54, uRc = uY + 6,
+constexpr int pA = kRecStage, pXn = pA + 81, pS = pXn + 9, kPredScratch = pS + 2;
+constexpr int uA = kRecStage, uK = uA + 81, uSI = uK + 54, uC1 = uSI /* C1 replaces S^-1 once K is formed */, uY = uSI + 54, uRc = uY + 6,
               kUpdScratch = uRc + 36;
 
-__device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int c, bool live)
+// All 64 lanes load and store unconditionally (the caller points idle groups at a valid record; nothing of
+// theirs is stored later): ten loads, ten LDS stores, no branches.  The copy is 160 words, i.e. it runs a little
+// into the record's ring bookkeeping -- inside the 187-word record, never read from the copy.
+__device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int c)
 {
     const double *src = reinterpret_cast<const double *>(rec);
     double t[10];
 #pragma unroll
-    for (int u = 0; u < 10; u++) { const int k = c + 16 * u; t[u] = (live && k < kRecRaw) ? src[k] : 0.0; }
+    for (int u = 0; u < 10; u++) t[u] = src[c + 16 * u];
 #pragma unroll
-    for (int u = 0; u < 10; u++) { const int k = c + 16 * u; if (live && k < kRecRaw) R[k] = t[u]; }
+    for (int u = 0; u < 10; u++) R[c + 16 * u] = t[u];
 }
 
 // _update_all for tracks 4q.., 4(q+nq).. of scene s by ONE wave (four 16-lane groups); `lds` = this wave's
@@ -53,7 +58,7 @@ __device__ __forceinline__ void update_tracks_wave(const DevCfg &cfg, const DevS
         const int j = j0 + g;
         const bool live = j < T;
         TrackRec *rec = trk + (live ? order[j] : 0);
-        stage_record(rec, Wj, c, live);
+        stage_record(rec, Wj, c);
         wave_sync();
         const double *Pw = Wj + rP;
         // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
