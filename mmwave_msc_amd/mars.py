@@ -119,6 +119,18 @@ class MarsCNN(nn.Module):
         z = np.load(path)
         return cls.from_keras_weights({k: z[k] for k in z.files})
 
+    @classmethod
+    def from_h5(cls, path: str) -> "MarsCNN":
+        """`keras.models.load_model(P_MODEL_PATH)` (offline_main.py:33) for the weights: reads the Keras `.h5` the
+        reference's train.py:252 writes, without keras or h5py (h5weights.py)."""
+        from .h5weights import load_keras_h5
+        return cls.from_keras_weights(load_keras_h5(path))
+
+    @classmethod
+    def load(cls, path: str) -> "MarsCNN":
+        """By extension: `.h5` / `.hdf5` (Keras) or `.npz` (train.py of this package)."""
+        return cls.from_h5(path) if path.lower().endswith((".h5", ".hdf5")) else cls.from_npz(path)
+
     def _hip_convs(self, x: torch.Tensor) -> torch.Tensor:
         """Conv3D+ReLU twice in one HIP kernel (mmw_mars_conv3d) -> (B, 6144) in (d,h,w,c) order."""
         from . import _lib

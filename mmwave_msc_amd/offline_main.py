@@ -21,9 +21,13 @@ SLEEPTIME = 0.1  # radar frame period, config_cases/our_config_8.5m.cfg "frameCf
 def offline_main(experiment_path: str, model=None, on_frame: Optional[Callable] = None,
                  max_frames: Optional[int] = None, max_pts: int = 512, device: int = 0) -> TrackBuffer:
     """Replays a logged experiment.  `on_frame(trackbuffer, detObj, frame_no)` replaces
-    `visual.update(trackbuffer, detObj)`.  Returns the TrackBuffer for inspection."""
+    `visual.update(trackbuffer, detObj)`.  `model`: anything with `.predict`, or the path of a Keras `.h5` /
+    `.npz` weight file (offline_main.py:33 `load_model(const.P_MODEL_PATH)`).  Returns the TrackBuffer."""
     if not os.path.exists(experiment_path):
         raise ValueError(f"No experiment file found in the path: {experiment_path}")
+    if isinstance(model, (str, os.PathLike)):
+        from .mars import MarsCNN
+        model = MarsCNN.load(os.fspath(model)).to(f"cuda:{device}")
     sensor_data = OfflineManager(experiment_path)
     trackbuffer = TrackBuffer(max_pts=max_pts, device=device)
     batch = BatchedData()
@@ -55,5 +59,6 @@ def offline_main(experiment_path: str, model=None, on_frame: Optional[Callable] 
 if __name__ == "__main__":
     import sys
 
-    tb = offline_main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(const.P_LOG_PATH, "mmWave", "A21"))
+    tb = offline_main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(const.P_LOG_PATH, "mmWave", "A21"),
+                      model=const.P_MODEL_PATH if os.path.exists(const.P_MODEL_PATH) else None)
     print("tracks at end:", len(tb.effective_tracks))
