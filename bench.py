@@ -150,7 +150,11 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
     sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks), S, N, device=local_rank)
-    sb.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one real stream for torch and the context: uploads, the CNN of the posture leg and the mmw_* calls on device
+    # tensors are then ordered by the stream itself (torch's default stream would read as "context's own stream")
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    sb.follow_torch_stream(side)
     d_pts = torch.empty((F, S, N, 8), dtype=torch.float64, device=dev)
     for f in range(F):
         d_pts[f] = torch.from_numpy(pts[f]).to(dev).double()

@@ -125,7 +125,12 @@ int mmw_destroy(mmw_ctx *ctx);
 const char *mmw_last_error(const mmw_ctx *ctx);
 /* Fresh TrackBuffer/BatchedData for every scene. */
 int mmw_reset(mmw_ctx *ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = context's own. */
+/* Run on a caller-owned hipStream_t; NULL = the context's own (non-blocking) stream.
+ * Note for callers that share device buffers with another runtime: calls on DEVICE pointers are ordered with that
+ * runtime's work only if both use the same stream.  torch reports the legacy default stream as
+ * torch.cuda.current_stream().cuda_stream == 0, which is NULL here, i.e. NOT torch's stream: pass MMW_STREAM_LEGACY
+ * (HIP's hipStreamLegacy handle) for it, or -- better -- a torch.cuda.Stream() both sides use. */
+#define MMW_STREAM_LEGACY ((void *)1)
 int mmw_set_stream(mmw_ctx *ctx, void *hip_stream);
 int mmw_synchronize(mmw_ctx *ctx);                                   /* sync */
 int mmw_get_dims(const mmw_ctx *ctx, int32_t *n_scenes, int32_t *max_pts, int32_t *track_cap, int32_t *ring, int32_t *ring_rows);

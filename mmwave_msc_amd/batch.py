@@ -96,7 +96,18 @@ class SceneBatch:
         return DevBuf(self, nbytes)
 
     def set_stream(self, stream_ptr):
+        """Raw hipStream_t (0 / None = the context's own non-blocking stream; 1 = HIP's legacy default stream)."""
         self._chk(self.L.mmw_set_stream(self.h, stream_ptr))
+
+    def follow_torch_stream(self, stream=None):
+        """Run this context's kernels on a torch stream (default: torch's current one), so that torch ops and the
+        `*_dev` calls that share device tensors with them are ordered without host synchronisation.  torch reports
+        the legacy default stream as pointer 0, which `mmw_set_stream` reads as "the context's own stream" -- the
+        legacy handle (include/mmw.h: MMW_STREAM_LEGACY) is passed for it."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        ptr = int(s.cuda_stream)
+        self.set_stream(ptr if ptr else 1)
 
     def synchronize(self):
         self._chk(self.L.mmw_synchronize(self.h))

@@ -1,6 +1,6 @@
 // k_misc.hip -- the streaming kernels either side of the tracker:
 //   k_normalize   Utils.normalize_data (Utils.py:294-434)        HBM-bound, ordered compaction
-//   k_feat_scan   row offsets of the per-track feature tensors   (scene, track) order
+//   k_feat_count / k_feat_scan   row offsets of the per-track feature tensors   (scene, track) order
 //   k_features    relative_coordinates + format_single_frame     (Utils.py:437-520), one wave per 64-row frame
 //   k_set_kp      track.keypoints = model output                 (Tracking.py:733-734)
 //   k_export      flatten effective_tracks for read-back
@@ -76,15 +76,23 @@ __device__ inline int eligible_tracks(const DevCfg &cfg, const DevState &st, int
     return c;
 }
 
-// single workgroup: exclusive scan of eligible-track counts over scenes
-__global__ __launch_bounds__(1024) void k_feat_scan(DevCfg cfg, DevState st, int32_t *__restrict__ row_off /*[S+1]*/)
+// eligible tracks per scene, one thread per scene over the whole chip (the records are scattered: as a loop inside
+// the single scan workgroup below this was 170 of the scan's 185 us)
+__global__ __launch_bounds__(256) void k_feat_count(DevCfg cfg, DevState st, int32_t *__restrict__ row_off /*[S+1]*/)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < cfg.n_scenes) row_off[s] = eligible_tracks(cfg, st, s);
+}
+
+// single workgroup: in-place exclusive scan of the counts; row_off[S] = total
+__global__ __launch_bounds__(1024) void k_feat_scan(DevCfg cfg, int32_t *__restrict__ row_off /*[S+1]*/)
 {
     __shared__ int part[1024];
     const int tid = threadIdx.x, S = cfg.n_scenes;
     const int per = (S + 1023) / 1024;
     const int s0 = tid * per, s1 = min(S, s0 + per);
     int sum = 0;
-    for (int s = s0; s < s1; s++) sum += eligible_tracks(cfg, st, s);
+    for (int s = s0; s < s1; s++) sum += row_off[s];
     part[tid] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(1024) void k_feat_scan(DevCfg cfg, DevState st, int
         __syncthreads();
     }
     int run = part[tid] - sum;
-    for (int s = s0; s < s1; s++) { row_off[s] = run; run += eligible_tracks(cfg, st, s); }
+    for (int s = s0; s < s1; s++) { const int c = row_off[s]; row_off[s] = run; run += c; }
     if (tid == 1023) row_off[S] = part[1023];
 }
 
@@ -272,7 +280,8 @@ void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw
 }
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cfg, s, row_off);
+    hipLaunchKernelGGL(k_feat_count, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, row_off);
+    hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cfg, row_off);
 }
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st)
 {

@@ -13,7 +13,7 @@ S, N, T, F = int(os.environ.get("S", 4096)), 512, 8, 12
 pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=16)
 dev = torch.device("cuda:0")
 sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
-sb.set_stream(torch.cuda.current_stream().cuda_stream)
+side = torch.cuda.Stream(); torch.cuda.set_stream(side); sb.follow_torch_stream(side)  # one stream for torch and the context
 for f in range(F):
     sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
 ntr = int(sb.num_tracks().sum())

@@ -127,3 +127,43 @@ def test_estimate_posture_end_to_end():
         for i, j in enumerate(owner):
             assert np.abs(tracks[j].keypoints - ref[i]).max() <= KP_TOL
     tb.close()
+
+
+def test_device_pointer_posture_path_is_ordered_with_torch():
+    """features_dev -> torch CNN -> set_keypoints_dev with NO host synchronisation in between, torch on its default
+    stream: the context must run on that very stream (SceneBatch.follow_torch_stream; include/mmw.h
+    MMW_STREAM_LEGACY), otherwise set_keypoints reads the CNN's output buffer before the CNN has written it.  Two
+    models back to back into the same (re-used) output allocation: the keypoints must be the second model's."""
+    import torch
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.synth import make_batch
+    S, N, F = 64, 256, 6
+    pts, cnt, dts = make_batch(range(S), F, N, 3)
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=4), S, N)
+    for f in range(F):
+        sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    dev = torch.device("cuda:0")
+    sb.follow_torch_stream()  # torch's current stream: the legacy default one here
+    cap = S * sb.track_cap
+    d_feat = torch.empty((cap, sb.ring, 8, 8, 5), dtype=torch.float32, device=dev)
+    d_owner = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    models = [MarsCNN.from_keras_weights(random_keras_weights(seed, sb.ring)).to(dev) for seed in (1, 2)]
+    nrow = 0
+    for m in models:
+        nrow = sb.features_dev(d_feat.data_ptr(), d_owner.data_ptr(), cap)
+        with torch.no_grad():
+            kp = m(d_feat[:nrow])
+        sb.set_keypoints_dev(kp.data_ptr(), d_owner.data_ptr(), nrow)
+        del kp  # the caching allocator hands the same block to the next model's output
+    assert nrow > 0
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = models[1](d_feat[:nrow]).cpu().numpy()
+    owner = d_owner[:nrow].cpu().numpy()
+    table = sb.tracks()
+    for i, (s, j) in enumerate(owner):
+        got = table[s][j]["keypoints"]
+        assert np.array_equal(np.asarray(got, dtype=np.float32), want[i]), (s, j)
+    sb.close()
