@@ -38,7 +38,9 @@ def tensor_to_summaries(t: torch.Tensor, slots: int) -> np.ndarray:
 def all_gather_tables(local: torch.Tensor, counts=None) -> torch.Tensor:
     """All-gather the per-rank summary tensors ([rows_r, SUMMARY_WORDS] int32) into the global
     table ordered by rank (= by global scene id).  Ranks may own different row counts:
-    shorter shards are padded for the collective and trimmed afterwards."""
+    shorter shards are padded for the collective and trimmed afterwards.
+    `local` must be complete on torch's current stream: when `SceneBatch.track_table_dev` filled it, the context has
+    to run on that stream (`SceneBatch.follow_torch_stream`) or be synchronised first."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
