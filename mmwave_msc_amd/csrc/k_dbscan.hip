@@ -261,8 +261,27 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             const double R2 = 2.0 * (eps / wmin) * (1.0 + 1e-9);
             const int bparts = ALL8 ? (NT / U > 0 ? NT / U : 1) : 1;
             bool dense = false;
-            for (int t = tid; t < (ALL8 ? U * bparts : U); t += NT) {
-                const int part = ALL8 ? t / U : 0, p = ALL8 ? t - part * U : t;
+            if (!ALL8) {
+                // the larger clouds: one dense point settles the question ("a core point is possible"), and a cloud
+                // that holds a cluster has one within a few dozen candidates -- 64 at a time, then a look at the
+                // flag the other threads may have raised
+                for (int p = tid; p < U && !dense; p += NT) {
+                    const double px = L.X[p], py = L.Y[p], pz = L.Z[p];
+                    int c = 0;
+                    for (int q0 = 0; q0 < U && !dense; q0 += 64) {
+                        const int q1 = q0 + 64 < U ? q0 + 64 : U;
+#pragma unroll 4
+                        for (int q = q0; q < q1; q++) {
+                            const double dx = px - L.X[q], dy = py - L.Y[q], dz = pz - L.Z[q];
+                            c += ((dx * dx + dy * dy) + zw * (dz * dz) <= R2) ? 1 : 0;
+                        }
+                        if (c >= min_samples) { dense = true; L.misc[3] = 1; }
+                        else if (L.misc[3] != 0) dense = true;
+                    }
+                }
+            } else
+            for (int t = tid; t < U * bparts; t += NT) {
+                const int part = t / U, p = t - part * U;
                 const double px = L.X[p], py = L.Y[p], pz = L.Z[p];
                 int c = 0;
 #pragma unroll 4
@@ -270,7 +289,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                     const double dx = px - L.X[q], dy = py - L.Y[q], dz = pz - L.Z[q];
                     c += ((dx * dx + dy * dy) + zw * (dz * dz) <= R2) ? 1 : 0;
                 }
-                if (ALL8 && bparts > 1) atomicAdd(&L.front[p], c);  // slices of one point add up in LDS
+                if (bparts > 1) atomicAdd(&L.front[p], c);  // slices of one point add up in LDS
                 else if (c >= min_samples) dense = true;
             }
             if (ALL8 && bparts > 1) {
