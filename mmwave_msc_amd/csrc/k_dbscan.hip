@@ -89,6 +89,8 @@ __host__ __device__ inline int db_levels(int U)
 // ALL8 build: private copies of the per-node min/max keys (picked by lane & 7), merged after the atomics -- all
 // lanes of a wave hitting the same sixteen LDS words serialise 64-fold
 constexpr int kMmCopies = 8;
+// (the 512-thread build of k_dbscan_big takes four: with eight its carve-up would cost a workgroup per CU)
+__host__ __device__ inline int db_mm_copies(int UM) { return UM > 256 ? 4 : kMmCopies; }
 constexpr int kFrontChunk = 32;
 
 template <bool WRITE>
@@ -117,7 +119,7 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(nsum, double, nodes * 3)
     CARVE(ncen, double, nodes * 3)
     CARVE(nrad, unsigned long long, nodes + 1)
-    CARVE(mm, unsigned long long, half * 16 * (all8 ? kMmCopies : 1))
+    CARVE(mm, unsigned long long, half * 16 * (all8 ? db_mm_copies(UM) : 1))
     CARVE(sdim, int, half)
     CARVE(lbase, int, half)
     CARVE(blk, int, (NB + 1) > 64 ? (NB + 1) : 64)
@@ -261,7 +263,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             const double R2 = 2.0 * (eps / wmin) * (1.0 + 1e-9);
             const int bparts = ALL8 ? (NT / U > 0 ? NT / U : 1) : 1;
             bool dense = false;
-            if (!ALL8) {
+            if (!ALL8 || bparts == 1) {
                 // the larger clouds: one dense point settles the question ("a core point is possible"), and a cloud
                 // that holds a cluster has one within a few dozen candidates -- 64 at a time, then a look at the
                 // flag the other threads may have raised
@@ -323,6 +325,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         // Thread-per-point build: min/max by fire-and-forget LDS atomics, the median split by ONE bitonic sort
         // of the whole level, stable partition by ballots in lane (= point index) order.
         const int wave = tid >> 6;
+        constexpr int MC = NT > 256 ? 4 : kMmCopies;  // == db_mm_copies(UMc): NT = 256 serves UMc <= 256, NT = 512 the larger class
         unsigned long long *xh = reinterpret_cast<unsigned long long *>(L.key);  // cross-wave exchange of the sort
         unsigned *xl = reinterpret_cast<unsigned *>(L.front);                     // (key[] / front[] are free here)
         unsigned char *leftflag = L.core;                                          // (free until the queries)
@@ -330,12 +333,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         if (tid < U) posarr[tid] = tid;
         for (int level = 0; level + 1 < n_levels; level++) {
             const int first = (1 << level) - 1, nn = 1 << level;
-            for (int e = tid; e < kMmCopies * nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;
+            for (int e = tid; e < MC * nn * 16; e += NT) L.mm[e] = (e & 1) ? 0ULL : ~0ULL;
             __syncthreads();
             const bool act = tid < U;
             const int node = act ? node_of(L, mypos, level) : -1;
             if (act) {  // find_node_split_dim over all 8 features (_binary_tree.pxi.tp:598-645)
-                unsigned long long *m = &L.mm[((lane & (kMmCopies - 1)) * nn + (node - first)) * 16];
+                unsigned long long *m = &L.mm[((lane & (MC - 1)) * nn + (node - first)) * 16];
                 atomicMin(&m[0], sortable(f0)); atomicMax(&m[1], sortable(f0));
                 atomicMin(&m[2], sortable(f1)); atomicMax(&m[3], sortable(f1));
                 atomicMin(&m[4], sortable(f2)); atomicMax(&m[5], sortable(f2));
@@ -347,12 +350,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             }
             __syncthreads();
             if (tid < nn * 16) {  // merge the private copies into copy 0
-                unsigned long long v[kMmCopies];
+                unsigned long long v[MC];
 #pragma unroll
-                for (int q = 0; q < kMmCopies; q++) v[q] = L.mm[q * nn * 16 + tid];
+                for (int q = 0; q < MC; q++) v[q] = L.mm[q * nn * 16 + tid];
                 unsigned long long r = v[0];
 #pragma unroll
-                for (int q = 1; q < kMmCopies; q++) r = (tid & 1) ? (v[q] > r ? v[q] : r) : (v[q] < r ? v[q] : r);
+                for (int q = 1; q < MC; q++) r = (tid & 1) ? (v[q] > r ? v[q] : r) : (v[q] < r ? v[q] : r);
                 L.mm[tid] = r;
             }
             __syncthreads();
@@ -1033,11 +1036,15 @@ __global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState
     const int cls = first ? 1 : 2, UMc = first ? UMc1 : UMc2, CL = first ? CL1 : CL2;
     const int b0 = first ? blockIdx.x : blockIdx.x - g1, nb = first ? g1 : (int)gridDim.x - g1;
     DbLds L;
-    db_lds_layout<true>(UMc, CL, false, lds_raw, &L);
     const int count = st.db_count[parity * 4 + cls];
     for (int w = b0; w < count; w += nb) {
         const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
-        spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
+        // a cloud that fits one point per thread takes the thread-per-point build of the small class (registers
+        // hold the 8 columns, one bitonic sort per level): 3-4x less tree-build time than the strided build
+        const bool tpp = st.hdr[s].db_u <= kBigThreads;  // uniform
+        db_lds_layout<true>(UMc, CL, tpp, lds_raw, &L);
+        if (tpp) spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
+        else spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
         __syncthreads();  // LDS is reused by the next scene
     }
 }
@@ -1076,7 +1083,10 @@ int dbscan_class_cl(int cls, int UM, int t_cap, int min_samples)
 }
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples)
 {
-    return db_lds_layout<false>(dbscan_class_um(cls, UM), dbscan_class_cl(cls, UM, t_cap, min_samples), cls == 0, nullptr, nullptr);
+    const int um = dbscan_class_um(cls, UM), cl = dbscan_class_cl(cls, UM, t_cap, min_samples);
+    const size_t strided = db_lds_layout<false>(um, cl, false, nullptr, nullptr), tpp = db_lds_layout<false>(um, cl, true, nullptr, nullptr);
+    if (cls == 0) return tpp;
+    return strided > tpp ? strided : tpp;  // k_dbscan_big carves either way per cloud
 }
 size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false, nullptr, nullptr); }
 
