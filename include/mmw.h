@@ -125,6 +125,9 @@ int mmw_destroy(mmw_ctx *ctx);
 const char *mmw_last_error(const mmw_ctx *ctx);
 /* Fresh TrackBuffer/BatchedData for every scene. */
 int mmw_reset(mmw_ctx *ctx);
+/* BatchedData.pop_frame() (Tracking.py:66-71; its caller is preprocessing.py:264): drop the oldest frame of the global
+ * ring of every scene whose flag is non-zero (host array of n_scenes words; NULL = every scene). */
+int mmw_pop_frame(mmw_ctx *ctx, const int32_t *scene_flags);
 /* Run on a caller-owned hipStream_t; NULL = the context's own (non-blocking) stream.
  * Note for callers that share device buffers with another runtime: calls on DEVICE pointers are ordered with that
  * runtime's work only if both use the same stream.  torch reports the legacy default stream as

@@ -23,7 +23,7 @@ E_ARG, E_SINGULAR, E_DIVZERO, E_CAPACITY, E_HIP, E_NODEVICE = -1, -2, -3, -4, -5
 K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE, K_PREDICT, K_POST = range(7)
 
 EXPORTS = [
-    "mmw_config_default", "mmw_create", "mmw_destroy", "mmw_last_error", "mmw_reset", "mmw_set_stream",
+    "mmw_config_default", "mmw_create", "mmw_destroy", "mmw_last_error", "mmw_reset", "mmw_pop_frame", "mmw_set_stream",
     "mmw_synchronize", "mmw_get_dims", "mmw_dev_alloc", "mmw_dev_free", "mmw_memcpy_h2d", "mmw_memcpy_d2h",
     "mmw_normalize", "mmw_step", "mmw_step_host", "mmw_dbscan", "mmw_features", "mmw_set_keypoints", "mmw_check",
     "mmw_get_num_tracks", "mmw_get_tracks", "mmw_get_batch_ring", "mmw_get_track_ring_frame",
@@ -127,6 +127,7 @@ def load():
         "mmw_last_error": (C.c_char_p, [vp]),
         "mmw_reset": (C.c_int, [vp]),
         "mmw_set_stream": (C.c_int, [vp, vp]),
+        "mmw_pop_frame": (C.c_int, [vp, vp]),
         "mmw_synchronize": (C.c_int, [vp]),
         "mmw_get_dims": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p]),
         "mmw_dev_alloc": (C.c_int, [vp, C.c_size_t, vpp]),

@@ -112,6 +112,15 @@ class SceneBatch:
     def synchronize(self):
         self._chk(self.L.mmw_synchronize(self.h))
 
+    def pop_frame(self, scenes=None):
+        """BatchedData.pop_frame() on the global ring of the given scenes (default: all)."""
+        if scenes is None:
+            self._chk(self.L.mmw_pop_frame(self.h, None))
+            return
+        flags = np.zeros(self.S, dtype=np.int32)
+        flags[np.asarray(scenes, dtype=np.int64)] = 1
+        self._chk(self.L.mmw_pop_frame(self.h, flags.ctypes.data))
+
     def reset(self):
         self._chk(self.L.mmw_reset(self.h))
 

@@ -3,6 +3,7 @@
 //   k_feat_count / k_feat_scan   row offsets of the per-track feature tensors   (scene, track) order
 //   k_features    relative_coordinates + format_single_frame     (Utils.py:437-520), one wave per 64-row frame
 //   k_set_kp      track.keypoints = model output                 (Tracking.py:733-734)
+//   k_pop_frame   BatchedData.pop_frame on the global ring         (Tracking.py:66-71)
 //   k_export      flatten effective_tracks for read-back
 //   k_table       fixed-size track summaries for the RCCL all-gather
 #include "mmw_device.hpp"
@@ -307,6 +308,26 @@ void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, 
     const int tot = cfg.n_scenes * slots;
     hipLaunchKernelGGL(k_table, dim3((tot + 127) / 128), dim3(128), 0, st, cfg, s, out, slots, base);
 }
+// BatchedData.pop_frame() (Tracking.py:66-71) on the global ring of the scenes whose flag is set: the oldest frame
+// goes, its physical slot moves behind the live ones (the same rotation add_frame does when the ring is full).
+__global__ void k_pop_frame(DevCfg cfg, DevState st, const int32_t *__restrict__ flags)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cfg.n_scenes || (flags && !flags[s])) return;
+    SceneHdr *hdr = st.hdr + s;
+    const int len = hdr->g_len;
+    if (len <= 0) return;
+    const int first = hdr->g_slot[0];
+    for (int k = 1; k < len; k++) { hdr->g_slot[k - 1] = hdr->g_slot[k]; hdr->g_n[k - 1] = hdr->g_n[k]; }
+    hdr->g_slot[len - 1] = first;
+    hdr->g_n[len - 1] = 0;
+    hdr->g_len = len - 1;
+}
+void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pop_frame, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, flags);
+}
+
 void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st)
 {
     hipLaunchKernelGGL(k_reset, dim3((cfg.n_scenes + 255) / 256 > 0 ? (cfg.n_scenes + 255) / 256 : 1), dim3(256), 0, st, cfg, s);

@@ -34,6 +34,7 @@ void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const 
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
 void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st);
+void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
                       hipStream_t stream);
 }  // namespace mmw
@@ -277,6 +278,21 @@ int mmw_reset(mmw_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     launch_reset(c->dc, c->st, c->stream);
     HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_pop_frame(mmw_ctx *c, const int32_t *scene_flags)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int32_t *d_flags = nullptr;
+    if (scene_flags) {  // (staged in the feature-offset scratch: S + 1 words, not live between calls)
+        HIPCHK(c, hipMemcpyAsync(c->d_row_off, scene_flags, sizeof(int32_t) * c->dc.n_scenes, hipMemcpyHostToDevice, c->stream));
+        d_flags = c->d_row_off;
+    }
+    launch_pop_frame(c->dc, c->st, d_flags, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (scene_flags) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's array may go away
     return MMW_OK;
 }
 

@@ -55,6 +55,12 @@ class BatchedData:
             return np.array([])  # state after clear() (Tracking.py:57-58)
         return np.concatenate(fr, axis=0)
 
+    def pop_frame(self):
+        """Remove the oldest frame (Tracking.py:66-71; called by the dataset pre-processing between shards)."""
+        if self._owner is not None and self._owner._sb is not None:
+            self._owner._sb.pop_frame([0])
+            self._owner._tracks_cache = None
+
 
 class _TrackRing:
     def __init__(self, tb, index, rec):

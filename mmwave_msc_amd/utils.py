@@ -218,7 +218,9 @@ def format_single_frame_mode(track_cloud: np.ndarray, mean, std_dev, batch_size,
     if not fuse:
         return limited.reshape((batch_size, 8, 8, 5))
     rows = limited[np.any(limited != 0, axis=1)][:64]
-    frame = np.zeros((64, 5))
+    # dtype as the reference's concatenate gives it: a full frame keeps the input's, a padded one is joined with
+    # float64 zeros (the dataset formatter feeds float32 blocks)
+    frame = np.zeros((64, 5), dtype=rows.dtype if rows.shape[0] == 64 else np.result_type(rows.dtype, np.float64))
     frame[: rows.shape[0]] = rows
     return frame[np.argsort(frame[:, 0])].reshape((8, 8, 5))
 

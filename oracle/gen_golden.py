@@ -353,6 +353,143 @@ def gen_uart():
     print(f"  uart: {len(chunks)} chunks, ok = {[int(out[f'ok{i}']) for i in range(len(chunks))]}")
 
 
+def gen_popframe():
+    """BatchedData.pop_frame() (Tracking.py:66-71; the dataset pre-processing calls it between log shards) in the
+    middle of a tracked sequence: the global ring after every frame, the association and the track count."""
+    f, n, k = 14, 60, 2
+    pts, cnt, dt = make_scene(4711, f, n, k)
+    pops = (2, 3, 6, 7, 11)   # before these frames are tracked (frames 6+7: twice in a row; an empty ring is a no-op)
+    ref = RefScene({})
+    ring_n = np.zeros((f, 4), np.int32)
+    ring_len = np.zeros(f, np.int32)
+    after_pop = np.full((f, 4), -1, np.int32)
+    assoc = np.full((f, n), -2, np.int16)
+    n_tracks = np.zeros(f, np.int32)
+    rings = []
+    for i in range(f):
+        if i in pops:
+            ref.batch.pop_frame()
+            br = ref.batch_ring()
+            after_pop[i, : len(br)] = br
+        a, _ = ref.track(pts[i, : cnt[i]].astype(np.float64), float(dt[i]))
+        assoc[i, : cnt[i]] = a
+        br = ref.batch_ring()
+        ring_len[i] = len(br)
+        ring_n[i, : len(br)] = br
+        n_tracks[i] = ref.n_tracks
+        eff = ref.batch.effective_data
+        rings.append(np.asarray(eff, dtype=np.float64).reshape(-1, 8) if len(eff) else np.zeros((0, 8)))
+    ref.close()
+    rows = np.zeros((f, 3 * n, 8))
+    for i, r in enumerate(rings):
+        rows[i, : len(r)] = r
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "popframe.npz"), pts=pts, cnt=cnt, dt=dt, pops=np.array(pops), assoc=assoc,
+                        n_tracks=n_tracks, ring_len=ring_len, ring_n=ring_n, after_pop=after_pop, ring_rows=rows, meta=_meta())
+    print(f"  popframe: ring lengths {ring_len.tolist()}, tracks {n_tracks.tolist()}")
+
+
+def _reference_functions(path, names, namespace):
+    """Compile the named top-level functions / constants of a reference script that cannot be imported (it runs
+    its pipeline at import time) and return them bound to `namespace`.  Nothing of the source is kept."""
+    import ast
+    with open(path, "r") as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    keep = [n for n in tree.body
+            if (isinstance(n, ast.FunctionDef) and n.name in names)
+            or (isinstance(n, ast.Assign) and all(isinstance(t, ast.Name) and t.id in names for t in n.targets))]
+    mod = ast.Module(body=keep, type_ignores=[])
+    exec(compile(mod, path, "exec"), namespace)
+    return namespace
+
+
+def gen_preprocess():
+    """The dataset pre-processing (src/preprocessing.py:27-145,148-275,298-384) on a synthetic experiment: the
+    mmWave log of the offline golden plus a synthetic Kinect log.  preprocessing.py runs its whole pipeline when it is
+    imported (and wants wakepy + the recorded data), so its functions are compiled one by one from the file and run
+    against the REAL constants / Utils / Tracking with the paths pointed at a temporary tree."""
+    import csv as _csv
+    import shutil as _shutil
+    import pandas as _pd
+    const, utils, tracking = load_reference()
+    z = np.load(os.path.join(GOLDEN_DIR, "offline.npz"))
+    rng = np.random.default_rng(4242)
+    saved = {k: getattr(const, k) for k in ("P_LOG_PATH", "P_PREPROCESS_PATH", "P_FORMATTED_PATH")}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        try:
+            const.P_LOG_PATH, const.P_PREPROCESS_PATH, const.P_FORMATTED_PATH = d + "/log", d + "/pre", d + "/fmt"
+            mm = f"{const.P_LOG_PATH}{const.P_MMWAVE_DIR}A1"
+            os.makedirs(mm)
+            os.makedirs(f"{const.P_LOG_PATH}{const.P_KINECT_DIR}")
+            os.makedirs(f"{const.P_PREPROCESS_PATH}{const.P_KINECT_DIR}")
+            os.makedirs(f"{const.P_PREPROCESS_PATH}{const.P_MMWAVE_DIR}")
+            os.makedirs(d + "/centroids_final")
+            for k in (1, 2):
+                with open(os.path.join(mm, f"{k}.csv"), "w") as fh:
+                    fh.write(str(z[f"csv{k}"]))
+            # Kinect log: time stamp, frame number, 19 joints x (x, z, y), one trailing field.  Most mmWave frames get
+            # a row within +-15 ms, every seventh none closer than 30 ms; a few rows match nothing.
+            stamps = {}
+            for k in (1, 2):
+                for line in str(z[f"csv{k}"]).splitlines():
+                    f = line.split(",")
+                    stamps.setdefault(int(f[0]), int(f[6]))
+            rows = []
+            kf = 1000
+            for fr, t in sorted(stamps.items()):
+                off = int(rng.integers(-15, 16)) if fr % 7 else 30 + int(rng.integers(0, 10))
+                base = np.array([0.1, 2.5, 0.9]) + rng.normal(0, 0.02, 3)
+                joints = base + rng.normal(0, 0.25, (19, 3))
+                rows.append([t + off, kf] + [repr(float(v)) for v in joints.reshape(-1)] + [0])
+                kf += 1
+                if fr % 11 == 0:
+                    rows.append([t + 47, kf] + [repr(float(v)) for v in (joints + 0.01).reshape(-1)] + [0]); kf += 1
+            kin_txt = "".join(",".join(str(v) for v in r) + "\n" for r in rows)
+            with open(f"{const.P_LOG_PATH}{const.P_KINECT_DIR}A1.csv", "w") as fh:
+                fh.write(kin_txt)
+            names = {"pair", "filter_kinect_frames", "translate_kinect", "relative_kinect", "static_kinect", "preprocess_dataset",
+                     "extract_parts", "format_mmwave_to_npy", "format_kinect_to_npy", "KINECT_Z", "KINECT_X", "RELATIVE_ENABLED"}
+            ns = {"np": np, "pd": _pd, "os": os, "csv": _csv, "shutil": _shutil, "const": const, "tqdm": (lambda it: it),
+                  "normalize_data": utils.normalize_data, "OfflineManager": utils.OfflineManager,
+                  "format_single_frame_mode": utils.format_single_frame_mode, "relative_coordinates": utils.relative_coordinates,
+                  "format_batched_frames": utils.format_batched_frames, "TrackBuffer": tracking.TrackBuffer,
+                  "BatchedData": tracking.BatchedData, "print": (lambda *a, **k: None)}
+            ref = _reference_functions(os.path.join(os.path.dirname(const.__file__), "preprocessing.py"), names, ns)
+            os.chdir(d)
+            pairs = ref["pair"]("A1")
+            ref["preprocess_dataset"]()
+            pre_dir = f"{const.P_PREPROCESS_PATH}{const.P_MMWAVE_DIR}/A1"
+            pre_files = sorted(os.listdir(pre_dir), key=lambda x: int(os.path.splitext(x)[0]))
+            pre_txt = [open(os.path.join(pre_dir, f)).read() for f in pre_files]
+            kin_out = open(f"{const.P_PREPROCESS_PATH}{const.P_KINECT_DIR}A1.csv", newline="").read()
+            cen = np.load(d + "/centroids_final/A1_centroid.npy")
+            # split_sets would move the experiment under a mode directory; do that by hand, then format
+            os.makedirs(f"{const.P_PREPROCESS_PATH}{const.P_MMWAVE_DIR}training")
+            _shutil.copytree(pre_dir, f"{const.P_PREPROCESS_PATH}{const.P_MMWAVE_DIR}training/A1")
+            os.makedirs(f"{const.P_PREPROCESS_PATH}{const.P_KINECT_DIR}training")
+            _shutil.copy(f"{const.P_PREPROCESS_PATH}{const.P_KINECT_DIR}A1.csv", f"{const.P_PREPROCESS_PATH}{const.P_KINECT_DIR}training/A1.csv")
+            os.makedirs(f"{const.P_FORMATTED_PATH}{const.P_MMWAVE_DIR}0")
+            os.makedirs(f"{const.P_FORMATTED_PATH}{const.P_KINECT_DIR}0")
+            ref["format_mmwave_to_npy"]("training", 0)
+            ref["format_kinect_to_npy"]("training", 0)
+            fm = np.load(f"{const.P_FORMATTED_PATH}{const.P_MMWAVE_DIR}0/training_mmWave.npy")
+            fk = np.load(f"{const.P_FORMATTED_PATH}{const.P_KINECT_DIR}0/training_labels.npy")
+            # row transforms on their own
+            probe = next(_csv.reader(kin_txt.splitlines()))
+            tr = ref["translate_kinect"](list(probe))
+            st = ref["static_kinect"](list(tr))
+            rel = ref["relative_kinect"](list(tr), [0.25, 2.0])
+        finally:
+            os.chdir(cwd)
+            for k, v in saved.items():
+                setattr(const, k, v)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "preprocess.npz"), kinect_in=kin_txt, pairs=np.array(pairs, dtype=np.int64),
+                        pre_files=np.array(pre_files), pre_txt=np.array(pre_txt), kinect_out=kin_out, centroids=cen,
+                        fmt_mmwave=fm, fmt_labels=fk, probe=np.array(probe), probe_translated=np.array(tr),
+                        probe_static=np.array(st), probe_relative=np.array(rel), meta=_meta())
+    print(f"  preprocess: {len(pairs)} pairs, {len(cen)} valid frames, files {pre_files}, mmWave {fm.shape}, labels {fk.shape}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -375,6 +512,10 @@ def main():
         gen_formatters()
     if not args.only or args.only == "uart":
         gen_uart()
+    if not args.only or args.only == "preprocess":
+        gen_preprocess()
+    if not args.only or args.only == "popframe":
+        gen_popframe()
     return 0
 
 

@@ -167,3 +167,30 @@ def test_device_pointer_posture_path_is_ordered_with_torch():
         got = table[s][j]["keypoints"]
         assert np.array_equal(np.asarray(got, dtype=np.float32), want[i]), (s, j)
     sb.close()
+
+
+def test_batcheddata_pop_frame_matches_reference_recording():
+    """BatchedData.pop_frame() (Tracking.py:66-71) between tracked frames -- empty ring, one frame, a full ring,
+    twice in a row: ring sizes and contents, association and track count as the reference recorded them."""
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "popframe.npz"))
+    pops = set(int(p) for p in g["pops"])
+    tb, batch = TrackBuffer(max_pts=64), BatchedData()
+    for f in range(len(g["cnt"])):
+        c = int(g["cnt"][f])
+        if f in pops:
+            batch.pop_frame()
+            if tb._sb is not None:
+                want = [int(v) for v in g["after_pop"][f] if v >= 0]
+                assert [len(fr) for fr in batch.buffer] == want, f
+        tb.dt = float(g["dt"][f])
+        tb.track(g["pts"][f, :c].astype(np.float64), batch)
+        assert np.array_equal(np.asarray(tb.last_assoc, dtype=np.int16), g["assoc"][f, :c]), f
+        assert len(tb.effective_tracks) == int(g["n_tracks"][f]), f
+        sizes = [len(fr) for fr in batch.buffer]
+        assert sizes == [int(v) for v in g["ring_n"][f, : int(g["ring_len"][f])]], f
+        eff = batch.effective_data
+        n = sum(sizes)
+        got = np.asarray(eff, dtype=np.float64).reshape(-1, 8) if n else np.zeros((0, 8))
+        assert np.array_equal(got, g["ring_rows"][f, :n]), f
+    tb.close()
