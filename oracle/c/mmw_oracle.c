@@ -645,6 +645,17 @@ int orc_dbscan(const orc_config *cfg, const double *pts, int n, double eps, int 
     return label_num;
 }
 
+/* BatchedData.pop_frame Tracking.py:66-71 (called by the dataset pre-processing, preprocessing.py:264) */
+void orc_pop_frame(orc_scene *s)
+{
+    if (s->g_len <= 0) return;
+    double *first = s->g_frame[0];
+    for (int k = 1; k < s->g_len; k++) { s->g_frame[k - 1] = s->g_frame[k]; s->g_n[k - 1] = s->g_n[k]; }
+    s->g_frame[s->g_len - 1] = first;
+    s->g_n[s->g_len - 1] = 0;
+    s->g_len--;
+}
+
 /* ------------------------------------------------------------------ */
 /* BatchedData.add_frame on the global ring Tracking.py:43-51 */
 static void global_ring_push(orc_scene *s, const double *rows, int n)

@@ -110,6 +110,8 @@ def lib():
     L.orc_num_tracks.argtypes = [vp]
     L.orc_get_tracks.argtypes = [vp, C.c_void_p, C.c_int]
     L.orc_get_batch_ring.argtypes = [vp, i32p]
+    L.orc_pop_frame.argtypes = [vp]
+    L.orc_pop_frame.restype = None
     L.orc_get_track_ring_frame.argtypes = [vp, C.c_int, C.c_int, f64p, C.c_int]
     L.orc_features.argtypes = [vp, f32p, i32p]
     L.orc_set_keypoints.argtypes = [vp, f32p, i32p, C.c_int]
@@ -213,6 +215,10 @@ class OracleScene:
         out = np.zeros(max(n, 1), dtype=TRACK_DTYPE)
         self.L.orc_get_tracks(self.h, out.ctypes.data_as(C.c_void_p), n)
         return out[:n]
+
+    def pop_frame(self):
+        """BatchedData.pop_frame() (Tracking.py:66-71)."""
+        self.L.orc_pop_frame(self.h)
 
     def batch_ring(self):
         a = np.zeros(RING_MAX, dtype=np.int32)

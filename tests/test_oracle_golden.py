@@ -79,3 +79,20 @@ def test_log_and_pairwise_sum_helpers():
         got = L.orc_np_pairwise_sum(np.ascontiguousarray(a).ctypes.data_as(co.C.POINTER(co.C.c_double)), n)
         want = float(np.add.reduce(a)) if n else 0.0
         assert got == want, (n, got, want)
+
+
+def test_pop_frame_matches_reference_recording():
+    """BatchedData.pop_frame() (Tracking.py:66-71) in the C restatement: ring sizes, association, track count."""
+    from oracle import c_oracle as co
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "popframe.npz"))
+    pops = set(int(p) for p in g["pops"])
+    sc = co.OracleScene(co.default_config(), 64)
+    for f in range(len(g["cnt"])):
+        c = int(g["cnt"][f])
+        if f in pops:
+            sc.pop_frame()
+            assert sc.batch_ring().tolist() == [int(v) for v in g["after_pop"][f] if v >= 0], f
+        a, _ = sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
+        assert np.array_equal(a.astype(np.int16), g["assoc"][f, :c]), f
+        assert sc.n_tracks == int(g["n_tracks"][f]), f
+        assert sc.batch_ring().tolist() == [int(v) for v in g["ring_n"][f, : int(g["ring_len"][f])]], f
