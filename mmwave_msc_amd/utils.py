@@ -243,10 +243,12 @@ def calc_fade_square(track):
     """Centre and size of the square the smart window fades behind a person (Visualizer.py:14-29): the head
     keypoint (x index 3, y index 41, z index 22 of the 57-vector) relative to the track position, projected onto
     the screen; the size shrinks with range.  `track` is anything with `.state.x` and `.keypoints`."""
-    x, kp = track.state.x, track.keypoints
-    centre = calc_projection_points(float(x[0]) + float(kp[3]), float(x[1]) + float(kp[41]), float(kp[22]))
+    x = np.asarray(track.state.x, dtype=np.float64).reshape(-1)      # (dim_x, 1) column in the reference
+    kp = np.asarray(track.keypoints, dtype=np.float64).reshape(-1)
+    x0, x1 = float(x[0]), float(x[1])
+    centre = calc_projection_points(x0 + float(kp[3]), x1 + float(kp[41]), float(kp[22]))
     size = max(const.V_SCREEN_FADE_SIZE_MIN,
-               min(const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_SIZE_MAX - (float(x[1]) + float(kp[12])) * const.V_SCREEN_FADE_WEIGHT))
+               min(const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_SIZE_MAX - (x1 + float(kp[12])) * const.V_SCREEN_FADE_WEIGHT))
     return centre, size
 
 

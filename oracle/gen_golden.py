@@ -270,8 +270,33 @@ def gen_formatters():
     pp[2] = [const.M_X, 2.0, const.M_Z]
     out["proj_in"] = pp
     out["proj_out"] = np.array([utils.calc_projection_points(*row) for row in pp])
+    # calc_fade_square (Visualizer.py:14-29).  Visualizer.py needs Qt to import; the function is compiled on its
+    # own and run against the real constants / calc_projection_points on tracks shaped like the reference's
+    # (state.x a (9, 1) column, keypoints a float32 57-vector)
+    import types
+    fade = _reference_functions(os.path.join(os.path.dirname(const.__file__), "Visualizer.py"), {"calc_fade_square"},
+                                {"const": const, "calc_projection_points": utils.calc_projection_points, "ClusterTrack": object})
+    fx = rng.uniform(-2, 6, size=(24, 9))
+    fx[0, 1] = 40.0   # far: the size clamps at the minimum
+    fx[1, 1] = -3.0   # behind the screen plane: clamps at the maximum
+    fk = rng.normal(0, 0.5, size=(24, 57)).astype(np.float32)
+    res = []
+    for t in range(24):
+        tr = types.SimpleNamespace(state=types.SimpleNamespace(x=fx[t].reshape(9, 1)), keypoints=fk[t])
+        (cx, cz), sz = fade["calc_fade_square"](tr)
+        res.append([float(np.asarray(cx).reshape(-1)[0]), float(np.asarray(cz).reshape(-1)[0]), float(np.asarray(sz).reshape(-1)[0])])
+    out["fade_x"], out["fade_kp"], out["fade_out"] = fx, fk, np.array(res)
+    # the same with the keypoints widened first: no float32 scalar takes part in the arithmetic, so the values do
+    # not depend on numpy's promotion rules (2.x keeps `float32 - python float` in float32, 1.26 -- the reference's
+    # pinned version -- does not)
+    res = []
+    for t in range(24):
+        tr = types.SimpleNamespace(state=types.SimpleNamespace(x=fx[t].reshape(9, 1)), keypoints=fk[t].astype(np.float64))
+        (cx, cz), sz = fade["calc_fade_square"](tr)
+        res.append([float(np.asarray(cx).reshape(-1)[0]), float(np.asarray(cz).reshape(-1)[0]), float(np.asarray(sz).reshape(-1)[0])])
+    out["fade_out64"] = np.array(res)
     np.savez_compressed(os.path.join(GOLDEN_DIR, "formatters.npz"), meta=_meta(), **out)
-    print("  formatters: 4 cases")
+    print("  formatters: 4 cases + projection + fade squares")
 
 
 def _uart_packet(frame, objs, qfmt=9, tlv_type=1, num_det=None):

@@ -111,7 +111,7 @@ def test_dataset_formatters_match_reference_goldens():
 
 def test_projection_and_fade_square():
     """calc_projection_points against values recorded from the reference (Utils.py:180-219); calc_fade_square
-    (Visualizer.py:14-29, not importable here: Qt) against its formula, scalar and table forms agreeing."""
+    (Visualizer.py:14-29) against values recorded from the reference's function, scalar and table forms agreeing."""
     import os
     import types
     import numpy as np
@@ -122,6 +122,18 @@ def test_projection_and_fade_square():
         assert np.array_equal(np.array(calc_projection_points(*row)), want), row
     xs, zs = calc_projection_points(g["proj_in"][:, 0], g["proj_in"][:, 1], g["proj_in"][:, 2])
     assert np.array_equal(np.stack([xs, zs], axis=1), g["proj_out"])
+    # calc_fade_square as the reference computes it (recorded by compiling the function out of Visualizer.py)
+    # (fp64 throughout, like the reference under its pinned numpy 1.26: bit-equal to the recording made with widened
+    #  keypoints; numpy 2.x keeps one subtraction of the float32 keypoint in float32 -> 1e-6 on that recording)
+    fx, fk, want, want32 = g["fade_x"], g["fade_kp"], g["fade_out64"], g["fade_out"]
+    px, pz, size = fade_squares(fx, fk)
+    assert np.array_equal(np.stack([px, pz, size], axis=1), want)
+    assert np.abs(np.stack([px, pz, size], axis=1) - want32).max() <= 1e-6
+    for t in range(len(fx)):
+        tr = types.SimpleNamespace(state=types.SimpleNamespace(x=fx[t].reshape(9, 1)), keypoints=fk[t])
+        (cx, cz), sz = calc_fade_square(tr)
+        assert [cx, cz, sz] == want[t].tolist(), t
+    assert want[0, 2] == const.V_SCREEN_FADE_SIZE_MIN and want[1, 2] == const.V_SCREEN_FADE_SIZE_MAX
     rng = np.random.default_rng(5)
     sx = rng.uniform(-2, 6, size=(12, 9))
     kp = rng.normal(0, 0.5, size=(12, 57))
