@@ -1019,9 +1019,14 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     const int wave = threadIdx.x >> 6;
     const int unit = ((int)blockIdx.x - G0) * 4 + wave;
     if (unit >= cfg.n_scenes * nq) return;
+    double *scratch = reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch;
+    if (cfg.t_cap <= 63) {  // four real tracks per wave, from the lists k_track built this frame
+        update_tracks_dense<DX>(cfg, st, unit, cfg.n_scenes * nq, parity, scratch);
+        return;
+    }
     const int us = unit / nq, q = unit - us * nq;
     const int s = st.perm[(size_t)parity * cfg.n_scenes + us];  // this step's schedule (the worker above writes the next one)
-    update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch);
+    update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, scratch);
 }
 
 // Work lists 1 and 2 (clouds of more than 256 points: the start-up frames of a scene) in one launch: blocks

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
+    if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
     if (n <= 0 || n > NP) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
@@ -695,6 +696,10 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         const int U = L.misc[13];
         hdr->n_tracks = T;
         hdr->n_upd = T;
+        if (T > 0) {  // this scene's tracks join the update list of their count (k_post lays _update_all out over tracks)
+            const int bin = parity * (cfg.t_cap + 1) + T;
+            st.upd_list[(size_t)bin * cfg.n_scenes + atomicAdd(&st.upd_count[bin], 1)] = s;
+        }
         const bool need = U > 0 && T < cfg.tr_max_tracks;
         hdr->need_db = need ? 1 : 0;
         L.misc[2] = need ? U : 0;

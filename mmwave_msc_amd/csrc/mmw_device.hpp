@@ -89,6 +89,8 @@ struct DevState {
     int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
     int32_t *perm;                 // [2][S] by step parity: scene handled by unit b of k_predict / k_track / k_post, heaviest scenes (most tracks) first; k_post builds the next step's
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
+    int32_t *upd_count;            // [2][t_cap+1] by step parity: scenes that hold t tracks to update this frame (k_track -> k_post)
+    int32_t *upd_list;             // [2][t_cap+1][S] ... and which ones: _update_all is laid out over the TRACKS, four per wave
 };
 
 // Counters are spread over kStatSlots copies (one 256-byte line each, picked by scene index): thousands of

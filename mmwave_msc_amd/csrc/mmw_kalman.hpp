@@ -37,9 +37,164 @@ __device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int
     for (int u = 0; u < 10; u++) R[c + 16 * u] = t[u];
 }
 
-// _update_all for tracks 4q.., 4(q+nq).. of scene s by ONE wave (four 16-lane groups); `lds` = this wave's
-// 4 * kUpdScratch doubles.  Reads hdr->n_upd: the tracks that survived _maintain_tracks in k_track -- this
-// frame's new tracks (spawn_scene, running in worker blocks of the same launch) are not updated.
+// One Kalman update (update_state, Tracking.py:387-398; _get_Rc 299-312; filterpy's Joseph-form update) per 16-lane
+// group: `rec` = the group's track record (idle groups: any valid record, `live` false -- they compute and store
+// nothing that matters), `Wj` = the group's kUpdScratch doubles.  All 64 lanes of the wave must call.
+template <int DX>
+__device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, double *Wj, int lane, int c, int &err)
+{
+    stage_record(rec, Wj, c);
+    wave_sync();
+    const double *Pw = Wj + rP;
+    // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
+    {
+        const bool valid = live && c < 6;
+        double v[6], det;
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;
+        if (valid) {
+            const double N = (double)reinterpret_cast<const int32_t *>(Wj + rInts)[0], nest = Wj[rNest];
+            const double den = (nest - 1) * N;
+            if (den == 0.0) err |= ERR_DIVZERO;
+            const double coef = (nest - N) / den;
+            const double hh = Wj[rSpr + c] / 2;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * Wj[rGd + i * 6 + c];
+                Wj[uRc + i * 6 + c] = rc;
+                v[i] = Pw[i * 9 + c] + rc;  // S = H P H^T + R
+            }
+            Wj[uY + c] = Wj[rCen + c] - Wj[rX + c];  // y = z - H x
+        }
+        const bool ok = lu6_inverse_cols(v, lane, det);
+        if (live) {
+            if (!ok) err |= ERR_SINGULAR;
+            if (c >= 6 && c < 12) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) Wj[uSI + r * 6 + c - 6] = v[r];
+            }
+        }
+    }
+    wave_sync();
+    if (live) {
+        for (int k = c; k < DX * 6; k += 16) {  // K = P H^T S^-1
+            const int i = k / 6, cc = k - i * 6;
+            double a = Pw[i * 9] * Wj[uSI + cc];
+#pragma unroll
+            for (int m = 1; m < 6; m++) a += Pw[i * 9 + m] * Wj[uSI + m * 6 + cc];
+            Wj[uK + k] = a;
+        }
+    }
+    wave_sync();
+    if (live) {
+        const double *Kw = Wj + uK, *yw = Wj + uY, *Rcw = Wj + uRc;
+        for (int k = c; k < 81; k += 16) {  // A = (I - K H) P
+            const int i = k / 9, cc = k - i * 9;
+            if (i < DX && cc < DX) {
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < DX; m++) {
+                    const double d = (i == m) ? 1.0 : 0.0;
+                    const double ikh = m < 6 ? d - Kw[i * 6 + m] : d;
+                    a = (m == 0) ? ikh * Pw[cc] : a + ikh * Pw[m * 9 + cc];
+                }
+                Wj[uA + k] = a;
+            }
+        }
+        if (c < DX) {  // x = x + K y
+            double a = Kw[c * 6] * yw[0];
+#pragma unroll
+            for (int m = 1; m < 6; m++) a += Kw[c * 6 + m] * yw[m];
+            double xnew = Wj[rX + c] + a;
+            if (c == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
+                const double var = Wj[rCen] - xnew;
+                if (!(var == 0.0) && Wj[rLife] == 0.0) xnew += var * 0.4;
+            }
+            rec->x[c] = xnew;
+        }
+        double c1[4];  // C1 = K R, into the S^-1 area: every lane forms its entries first, then they are stored
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = c + 16 * u;
+            c1[u] = 0.0;
+            if (k < DX * 6) {
+                const int i = k / 6, cc = k - i * 6;
+                double a = Kw[i * 6] * Rcw[cc];
+#pragma unroll
+                for (int m = 1; m < 6; m++) a += Kw[i * 6 + m] * Rcw[m * 6 + cc];
+                c1[u] = a;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int k = c + 16 * u; if (k < DX * 6) Wj[uC1 + k] = c1[u]; }
+    }
+    wave_sync();
+    if (live) {
+        const double *Aw = Wj + uA, *Kw = Wj + uK, *C1w = Wj + uC1;
+        for (int k = c; k < 81; k += 16) {  // P = A (I-KH)^T + C1 K^T
+            const int i = k / 9, cc = k - i * 9;
+            if (i < DX && cc < DX) {
+                double b = 0.0;
+#pragma unroll
+                for (int m = 0; m < DX; m++) {
+                    const double d = (cc == m) ? 1.0 : 0.0;
+                    const double ikh = m < 6 ? d - Kw[cc * 6 + m] : d;
+                    b = (m == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + m] * ikh;
+                }
+                double c2 = C1w[i * 6] * Kw[cc * 6];
+#pragma unroll
+                for (int m = 1; m < 6; m++) c2 += C1w[i * 6 + m] * Kw[cc * 6 + m];
+                rec->P[k] = b + c2;
+            }
+        }
+    }
+    wave_sync();
+}
+
+// _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of the list
+// "scenes by track count, most tracks first" that k_track built this frame (st.upd_list / st.upd_count; every scene
+// in it was tracked this frame and holds hdr->n_upd = its bin's count) -- entry k is track k % t of the (k / t)-th
+// scene of its bin.  Four real tracks per wave whatever the scenes hold (per-scene waves ran at 75 % of their lanes
+// with 1..8 tracks per scene).  This frame's new tracks (spawn_scene, in worker blocks of the same launch) are not in
+// the lists: they are not updated (Tracking.py:598-603 runs before _add_tracks).  `lds` = this wave's 4 * kUpdScratch
+// doubles.  Needs t_cap <= 63 (one lane per bin).
+template <int DX>
+__device__ __forceinline__ void update_tracks_dense(const DevCfg &cfg, const DevState &st, int unit0, int n_units, int parity, double *lds)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int nb = cfg.t_cap;                       // bins t = t_cap .. 1, lane b <-> t = t_cap - b
+    const int t_of_lane = nb - lane;
+    const int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
+    int incl = (lane < nb) ? t_of_lane * cnt[t_of_lane] : 0;  // tracks in this bin
+    const int mine = incl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int total = __shfl(incl, 63);
+    const int excl = incl - mine;
+    // (the grid is sized for tr_max_tracks per scene; a scene may hold more right after a frame of many new clusters)
+    for (int unit = unit0; unit * 4 < total; unit += n_units) {
+    int my_s = 0, my_j = 0;
+    bool live = false;
+#pragma unroll
+    for (int gg = 0; gg < 4; gg++) {
+        const int k = unit * 4 + gg;            // uniform
+        const unsigned long long hit = __ballot(lane < nb && incl > k);
+        if (k < total && hit) {
+            const int b = __ffsll((long long)hit) - 1;  // first bin whose inclusive count exceeds k
+            const int base = __shfl(excl, b), t = nb - b;
+            const int rel = k - base, r = rel / t, j = rel - r * t;
+            const int sc = st.upd_list[((size_t)parity * (cfg.t_cap + 1) + t) * cfg.n_scenes + r];
+            if (g == gg) { my_s = sc; my_j = j; live = true; }
+        }
+    }
+    TrackRec *rec = st.trk + (size_t)my_s * cfg.t_cap + (live ? st.order[(size_t)my_s * cfg.t_cap + my_j] : 0);
+    int err = 0;
+    update_one_track<DX>(rec, live, lds + g * kUpdScratch, lane, c, err);
+    if (err && live) atomicOr(&st.hdr[my_s].err, err);
+    }
+}
+
+// The per-scene layout (kept for contexts with t_cap > 63): tracks 4q.., 4(q+nq).. of scene s by ONE wave.
 template <int DX>
 __device__ __forceinline__ void update_tracks_wave(const DevCfg &cfg, const DevState &st, const int32_t *__restrict__ n_pts, int s, int q,
                                                    int nq, double *lds)
@@ -57,113 +212,7 @@ __device__ __forceinline__ void update_tracks_wave(const DevCfg &cfg, const DevS
     for (int j0 = q * 4; j0 < T; j0 += nq * 4) {
         const int j = j0 + g;
         const bool live = j < T;
-        TrackRec *rec = trk + (live ? order[j] : 0);
-        stage_record(rec, Wj, c);
-        wave_sync();
-        const double *Pw = Wj + rP;
-        // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
-        {
-            const bool valid = live && c < 6;
-            double v[6], det;
-#pragma unroll
-            for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;
-            if (valid) {
-                const double N = (double)reinterpret_cast<const int32_t *>(Wj + rInts)[0], nest = Wj[rNest];
-                const double den = (nest - 1) * N;
-                if (den == 0.0) err |= ERR_DIVZERO;
-                const double coef = (nest - N) / den;
-                const double hh = Wj[rSpr + c] / 2;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * Wj[rGd + i * 6 + c];
-                    Wj[uRc + i * 6 + c] = rc;
-                    v[i] = Pw[i * 9 + c] + rc;  // S = H P H^T + R
-                }
-                Wj[uY + c] = Wj[rCen + c] - Wj[rX + c];  // y = z - H x
-            }
-            const bool ok = lu6_inverse_cols(v, lane, det);
-            if (live) {
-                if (!ok) err |= ERR_SINGULAR;
-                if (c >= 6 && c < 12) {
-#pragma unroll
-                    for (int r = 0; r < 6; r++) Wj[uSI + r * 6 + c - 6] = v[r];
-                }
-            }
-        }
-        wave_sync();
-        if (live) {
-            for (int k = c; k < DX * 6; k += 16) {  // K = P H^T S^-1
-                const int i = k / 6, cc = k - i * 6;
-                double a = Pw[i * 9] * Wj[uSI + cc];
-#pragma unroll
-                for (int m = 1; m < 6; m++) a += Pw[i * 9 + m] * Wj[uSI + m * 6 + cc];
-                Wj[uK + k] = a;
-            }
-        }
-        wave_sync();
-        if (live) {
-            const double *Kw = Wj + uK, *yw = Wj + uY, *Rcw = Wj + uRc;
-            for (int k = c; k < 81; k += 16) {  // A = (I - K H) P
-                const int i = k / 9, cc = k - i * 9;
-                if (i < DX && cc < DX) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int m = 0; m < DX; m++) {
-                        const double d = (i == m) ? 1.0 : 0.0;
-                        const double ikh = m < 6 ? d - Kw[i * 6 + m] : d;
-                        a = (m == 0) ? ikh * Pw[cc] : a + ikh * Pw[m * 9 + cc];
-                    }
-                    Wj[uA + k] = a;
-                }
-            }
-            if (c < DX) {  // x = x + K y
-                double a = Kw[c * 6] * yw[0];
-#pragma unroll
-                for (int m = 1; m < 6; m++) a += Kw[c * 6 + m] * yw[m];
-                double xnew = Wj[rX + c] + a;
-                if (c == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
-                    const double var = Wj[rCen] - xnew;
-                    if (!(var == 0.0) && Wj[rLife] == 0.0) xnew += var * 0.4;
-                }
-                rec->x[c] = xnew;
-            }
-            double c1[4];  // C1 = K R, into the S^-1 area: every lane forms its entries first, then they are stored
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int k = c + 16 * u;
-                c1[u] = 0.0;
-                if (k < DX * 6) {
-                    const int i = k / 6, cc = k - i * 6;
-                    double a = Kw[i * 6] * Rcw[cc];
-#pragma unroll
-                    for (int m = 1; m < 6; m++) a += Kw[i * 6 + m] * Rcw[m * 6 + cc];
-                    c1[u] = a;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int k = c + 16 * u; if (k < DX * 6) Wj[uC1 + k] = c1[u]; }
-        }
-        wave_sync();
-        if (live) {
-            const double *Aw = Wj + uA, *Kw = Wj + uK, *C1w = Wj + uC1;
-            for (int k = c; k < 81; k += 16) {  // P = A (I-KH)^T + C1 K^T
-                const int i = k / 9, cc = k - i * 9;
-                if (i < DX && cc < DX) {
-                    double b = 0.0;
-#pragma unroll
-                    for (int m = 0; m < DX; m++) {
-                        const double d = (cc == m) ? 1.0 : 0.0;
-                        const double ikh = m < 6 ? d - Kw[cc * 6 + m] : d;
-                        b = (m == 0) ? Aw[i * 9] * ikh : b + Aw[i * 9 + m] * ikh;
-                    }
-                    double c2 = C1w[i * 6] * Kw[cc * 6];
-#pragma unroll
-                    for (int m = 1; m < 6; m++) c2 += C1w[i * 6 + m] * Kw[cc * 6 + m];
-                    rec->P[k] = b + c2;
-                }
-            }
-        }
-        wave_sync();
+        update_one_track<DX>(trk + (live ? order[j] : 0), live, Wj, lane, c, err);
     }
     if (err) atomicOr(&st.hdr[s].err, err);
 }
