@@ -818,7 +818,7 @@ __device__ __forceinline__ void finish_scene_stats(const DevState &st, int s, in
 
 template <int NT, bool ALL8>
 __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &st, const DbLds &L, int s, int UMc, int CL, int UM_out,
-                                            bool screened, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+                                            bool screened, int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     SceneHdr *hdr = st.hdr + s;
@@ -846,6 +846,11 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
         hdr->g_len = 0;
         for (int k = 0; k < MMW_RING_MAX; k++) hdr->g_n[k] = 0;
         hdr->n_tracks = T0 + nspawn;
+        if (nspawn > 0) {  // the next k_predict takes the new tracks T0.. from here (the older ones from the update lists)
+            const int pos = atomicAdd(&st.spc_count[parity], 1);
+            st.spc_list[((size_t)parity * cfg.n_scenes + pos) * 2] = s;
+            st.spc_list[((size_t)parity * cfg.n_scenes + pos) * 2 + 1] = T0;
+        }
         L.misc[4] = hdr->next_uid;
         hdr->next_uid += nspawn;
         if (err) atomicOr(&hdr->err, err);
@@ -972,6 +977,14 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             // The key is n_upd, which nothing in this launch writes: n_tracks may be raised by a spawning worker
             // between the two passes, and a scene counted in one bin but scattered into another would break the
             // permutation.
+            // ... and the number of tracks in this frame's update lists, for the next k_predict: its idle waves leave
+            // on one word (bin 0 of the counts is otherwise unused; 4096 workgroups adding to it in k_track cost 12 us)
+            if (threadIdx.x == 255) {
+                int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
+                int tot = 0;
+                for (int t = 1; t <= cfg.t_cap; t++) tot += t * cnt[t];
+                cnt[0] = tot;
+            }
             int *hist = reinterpret_cast<int *>(lds_raw);  // [t_cap + 2]
             const int nb = cfg.t_cap + 1;
             for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
@@ -1011,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
                 cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
             else
-                spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, labels_out, db_n_out);
+                spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
             __syncthreads();  // LDS is reused by the next scene
         }
         return;
@@ -1048,8 +1061,8 @@ __global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState
         // hold the 8 columns, one bitonic sort per level): 3-4x less tree-build time than the strided build
         const bool tpp = st.hdr[s].db_u <= kBigThreads;  // uniform
         db_lds_layout<true>(UMc, CL, tpp, lds_raw, &L);
-        if (tpp) spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
-        else spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, labels_out, db_n_out);
+        if (tpp) spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+        else spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
         __syncthreads();  // LDS is reused by the next scene
     }
 }

@@ -20,17 +20,204 @@
 
 namespace mmw {
 
-// One wave = four tracks of one scene (16-lane groups).  Wave q of a scene's `nq` waves takes tracks
-// 4q.., 4(q+nq).., so scenes with more than 4*nq tracks just loop.  DX = dim_x (6 or 9): a template so
-// that every dot product below is fully unrolled with constant LDS offsets.
+// _predict_all for ONE track per 16-lane group (predict_state, Tracking.py:372-385: filterpy predict with the motion
+// model of constants.py:195-215) + the gate matrix of _calc_dist_fun (Tracking.py:549-560) into gate_buf[s][j].
+// Idle groups (`live` false) point at any valid record and store nothing.  All 64 lanes of the wave must call.
+template <int DX>
+__device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
+                                                  double *Wj, int lane, int c, int &err)
+{
+    stage_record(rec, Wj, c);
+    wave_sync();
+    const double dtm = Wj[rLife] + dt;
+    const double h = 0.5 * (dtm * dtm);
+    if (live) {
+        for (int k = c; k < 81; k += 16) {
+            // A = F P.  F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense
+            // dot product reduces to these terms (the others are exact zeros).
+            const int i = k / 9, cc = k - i * 9;
+            if (i < DX && cc < DX) {
+                double a = Wj[rP + k];
+                if (i + 3 < DX) a += dtm * Wj[rP + (i + 3) * 9 + cc];
+                if (i + 6 < DX) a += h * Wj[rP + (i + 6) * 9 + cc];
+                Wj[pA + k] = a;
+            }
+        }
+        if (c < DX) {
+            double xn = Wj[rX + c];
+            if (c + 3 < DX) xn += dtm * Wj[rX + c + 3];
+            if (c + 6 < DX) xn += h * Wj[rX + c + 6];
+            Wj[pXn + c] = xn;
+        }
+    }
+    wave_sync();
+    if (live) {
+        const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
+        for (int k = c; k < 81; k += 16) {
+            const int i = k / 9, cc = k - i * 9;
+            if (i < DX && cc < DX) {
+                double b = Wj[pA + k];  // B = A F^T
+                if (cc + 3 < DX) b += Wj[pA + i * 9 + cc + 3] * dtm;
+                if (cc + 6 < DX) b += Wj[pA + i * 9 + cc + 6] * h;
+                double qn = 0.0;
+                if (i / 3 == cc / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
+                    const int qi = i % 3, qc = cc % 3, sdeg = qi + qc;
+                    const double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
+                                      : sdeg == 3 ? dtm : 1.0;
+                    qn = base * cfg.kf_q_std;
+                }
+                const double pn = b + qn;
+                rec->P[k] = pn;
+                Wj[rP + k] = pn;
+            }
+        }
+        if (c < DX) { const double xn = Wj[pXn + c]; rec->x[c] = xn; Wj[rX + c] = xn; }
+    }
+    wave_sync();
+    // gate matrix: lane c < 6 of the group holds column c of C = P[:6,:6] + diag((spread/2)^2) + group_disp_est
+    {
+        const bool valid = live && c < 6;
+        double v[6], det;
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;  // idle groups: identity
+        if (valid) {
+            const double hh = Wj[rSpr + c] / 2;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] = (Wj[rP + i * 9 + c] + ((i == c) ? hh * hh : 0.0)) + Wj[rGd + i * 6 + c];
+        }
+        const bool ok = lu6_inverse_cols(v, lane, det);
+        if (live) {
+            if (!ok) err |= ERR_SINGULAR;
+            double *G = st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec;  // by effective_tracks position
+            if (c >= 6 && c < 12) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
+            }
+            if (c == 0) G[36] = dlog(fabs(det));
+            if (c < 6) G[37 + c] = Wj[rX + c];
+        }
+    }
+    wave_sync();
+}
+
+// Which (scene, track) a 16-lane group of wave `unit` takes when the work is laid out over the lists "scenes by track
+// count, most tracks first" (st.upd_list / st.upd_count of `parity`): entry k = 4 * unit + group is track k % t of
+// the (k / t)-th scene of its bin.  Returns false for a group past the end.  Needs t_cap <= 63 (one lane per bin).
+struct DenseBins {
+    int incl, excl, total;
+};
+__device__ __forceinline__ DenseBins dense_bins(const DevCfg &cfg, const DevState &st, int parity, int lane)
+{
+    const int nb = cfg.t_cap, t_of_lane = nb - lane;
+    const int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
+    DenseBins B;
+    B.incl = (lane < nb) ? t_of_lane * cnt[t_of_lane] : 0;
+    const int mine = B.incl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(B.incl, o); if (lane >= o) B.incl += v; }
+    B.total = __shfl(B.incl, 63);
+    B.excl = B.incl - mine;
+    return B;
+}
+__device__ __forceinline__ bool dense_pick(const DevCfg &cfg, const DevState &st, int parity, const DenseBins &B, int unit, int lane, int g,
+                                           int &my_s, int &my_j)
+{
+    const int nb = cfg.t_cap;
+    bool live = false;
+    my_s = 0; my_j = 0;
+#pragma unroll
+    for (int gg = 0; gg < 4; gg++) {
+        const int k = unit * 4 + gg;  // uniform
+        const unsigned long long hit = __ballot(lane < nb && B.incl > k);
+        if (k < B.total && hit) {
+            const int b = __ffsll((long long)hit) - 1;  // first bin whose inclusive count exceeds k
+            const int base = __shfl(B.excl, b), t = nb - b;
+            const int rel = k - base, r = rel / t, j = rel - r * t;
+            const int sc = st.upd_list[((size_t)parity * (cfg.t_cap + 1) + t) * cfg.n_scenes + r];
+            if (g == gg) { my_s = sc; my_j = j; live = true; }
+        }
+    }
+    return live;
+}
+
+// k_predict, 64-thread workgroups = one wave = four tracks.  The tracks of the context come from three places:
+//   * units [0, n_dense): the scenes tracked in the PREVIOUS frame, by their update lists (tracks 0 .. n_upd-1),
+//     four real tracks per wave whatever the scenes hold;
+//   * the last kSpecialUnits units: the scenes that spawned tracks in the previous frame (st.spc_list: their new tracks
+//     n_upd .. n_tracks-1) and the scenes whose previous frame was empty (hdr->skipped: all their tracks), one per wave;
+//   * contexts with t_cap > 63: the per-scene layout, wave q of a scene's nq takes tracks 4q.., 4(q+nq)..
+// An empty frame (n_pts <= 0) predicts nothing (offline_main.py:56: such frames never reach track()).
+constexpr int kSpecialUnits = 64;
 template <int DX>
 __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts,
                                                 const double *__restrict__ dt_all, int nq, int parity)
 {
     __shared__ double lds[4 * kPredScratch];
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    double *Wj = lds + g * kPredScratch;
+    int err = 0;
+    if (cfg.t_cap <= 63) {
+        const int prev = parity ^ 1, n_dense = cfg.n_scenes * nq;
+        if ((int)blockIdx.x < n_dense) {
+            if ((int)blockIdx.x * 4 >= st.upd_count[(size_t)prev * (cfg.t_cap + 1)]) return;  // (bin 0 = the total)
+            const DenseBins B = dense_bins(cfg, st, prev, lane);
+            for (int unit = blockIdx.x; unit * 4 < B.total; unit += n_dense) {
+                int s, j;
+                bool live = dense_pick(cfg, st, prev, B, unit, lane, g, s, j);
+                const int n = n_pts[s];
+                live = live && n > 0 && n <= cfg.max_pts;
+                if (!__any(live)) continue;
+                TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? st.order[(size_t)s * cfg.t_cap + j] : 0);
+                int e1 = 0;
+                predict_one_track<DX>(cfg, st, rec, live, s, j, dt_all[s], Wj, lane, c, e1);
+                if (e1 && live) atomicOr(&st.hdr[s].err, e1);
+            }
+            return;
+        }
+        const int count = st.spc_count[prev];
+        for (int i = (int)blockIdx.x - n_dense; i < count; i += kSpecialUnits) {
+            const int s = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2], first = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2 + 1];
+            const int n = n_pts[s];
+            if (n <= 0 || n > cfg.max_pts) continue;
+            const int T = st.hdr[s].n_tracks;
+            const int32_t *order = st.order + (size_t)s * cfg.t_cap;
+            TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+            for (int j0 = first; j0 < T; j0 += 4) {
+                const int j = j0 + g;
+                const bool live = j < T;
+                predict_one_track<DX>(cfg, st, trk + (live ? order[j] : 0), live, s, j, dt_all[s], Wj, lane, c, err);
+            }
+            if (err) { atomicOr(&st.hdr[s].err, err); err = 0; }
+        }
+        // scenes whose last frame was empty (no update list holds them): all their tracks.  64 scenes per look (one
+        // per lane), the rare hits one after the other
+        for (int s0 = ((int)blockIdx.x - n_dense) * 64; s0 < cfg.n_scenes; s0 += kSpecialUnits * 64) {
+            const int sl = s0 + lane;
+            bool mine = false;
+            if (sl < cfg.n_scenes) {
+                const int n = n_pts[sl];
+                mine = st.hdr[sl].skipped != 0 && st.hdr[sl].n_tracks > 0 && n > 0 && n <= cfg.max_pts;
+            }
+            unsigned long long todo = __ballot(mine);
+            while (todo) {
+                const int s = s0 + __ffsll((long long)todo) - 1;
+                todo &= todo - 1ULL;
+                const int T = st.hdr[s].n_tracks;
+                const int32_t *order = st.order + (size_t)s * cfg.t_cap;
+                TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+                for (int j0 = 0; j0 < T; j0 += 4) {
+                    const int j = j0 + g;
+                    const bool live = j < T;
+                    predict_one_track<DX>(cfg, st, trk + (live ? order[j] : 0), live, s, j, dt_all[s], Wj, lane, c, err);
+                }
+                if (err) { atomicOr(&st.hdr[s].err, err); err = 0; }
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= cfg.n_scenes * nq) return;
     const int us = blockIdx.x / nq, q = blockIdx.x - us * nq;
     const int s = st.perm[(size_t)parity * cfg.n_scenes + us];  // heaviest scenes first (see k_track)
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const int n = n_pts[s];
     if (n <= 0 || n > cfg.max_pts) return;  // offline_main.py:56: empty frames never reach track()
     const SceneHdr *hdr = st.hdr + s;
@@ -39,83 +226,10 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
     const double dt = dt_all[s];
     const int32_t *order = st.order + (size_t)s * cfg.t_cap;
     TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
-    double *Wj = lds + g * kPredScratch;
-    int err = 0;
     for (int j0 = q * 4; j0 < T; j0 += nq * 4) {
         const int j = j0 + g;
         const bool live = j < T;
-        TrackRec *rec = trk + (live ? order[j] : 0);
-        stage_record(rec, Wj, c);
-        wave_sync();
-        const double dtm = Wj[rLife] + dt;
-        const double h = 0.5 * (dtm * dtm);
-        if (live) {
-            for (int k = c; k < 81; k += 16) {
-                // A = F P.  F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense
-                // dot product reduces to these terms (the others are exact zeros).
-                const int i = k / 9, cc = k - i * 9;
-                if (i < DX && cc < DX) {
-                    double a = Wj[rP + k];
-                    if (i + 3 < DX) a += dtm * Wj[rP + (i + 3) * 9 + cc];
-                    if (i + 6 < DX) a += h * Wj[rP + (i + 6) * 9 + cc];
-                    Wj[pA + k] = a;
-                }
-            }
-            if (c < DX) {
-                double xn = Wj[rX + c];
-                if (c + 3 < DX) xn += dtm * Wj[rX + c + 3];
-                if (c + 6 < DX) xn += h * Wj[rX + c + 6];
-                Wj[pXn + c] = xn;
-            }
-        }
-        wave_sync();
-        if (live) {
-            const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
-            for (int k = c; k < 81; k += 16) {
-                const int i = k / 9, cc = k - i * 9;
-                if (i < DX && cc < DX) {
-                    double b = Wj[pA + k];  // B = A F^T
-                    if (cc + 3 < DX) b += Wj[pA + i * 9 + cc + 3] * dtm;
-                    if (cc + 6 < DX) b += Wj[pA + i * 9 + cc + 6] * h;
-                    double qn = 0.0;
-                    if (i / 3 == cc / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
-                        const int qi = i % 3, qc = cc % 3, sdeg = qi + qc;
-                        const double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
-                                          : sdeg == 3 ? dtm : 1.0;
-                        qn = base * cfg.kf_q_std;
-                    }
-                    const double pn = b + qn;
-                    rec->P[k] = pn;
-                    Wj[rP + k] = pn;
-                }
-            }
-            if (c < DX) { const double xn = Wj[pXn + c]; rec->x[c] = xn; Wj[rX + c] = xn; }
-        }
-        wave_sync();
-        // gate matrix: lane c < 6 of the group holds column c of C = P[:6,:6] + diag((spread/2)^2) + group_disp_est
-        {
-            const bool valid = live && c < 6;
-            double v[6], det;
-#pragma unroll
-            for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;  // idle groups: identity
-            if (valid) {
-                const double hh = Wj[rSpr + c] / 2;
-#pragma unroll
-                for (int i = 0; i < 6; i++) v[i] = (Wj[rP + i * 9 + c] + ((i == c) ? hh * hh : 0.0)) + Wj[rGd + i * 6 + c];
-            }
-            const bool ok = lu6_inverse_cols(v, lane, det);
-            if (live) {
-                if (!ok) err |= ERR_SINGULAR;
-                double *G = st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec;  // by effective_tracks position
-                if (c >= 6 && c < 12) {
-#pragma unroll
-                    for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
-                }
-                if (c == 0) G[36] = dlog(fabs(det));
-                if (c < 6) G[37 + c] = Wj[rX + c];
-            }
-        }
-        wave_sync();
+        predict_one_track<DX>(cfg, st, trk + (live ? order[j] : 0), live, s, j, dt, Wj, lane, c, err);
     }
     if (err) atomicOr(&st.hdr[s].err, err);
 }
@@ -129,8 +243,9 @@ static int waves_per_scene(const DevCfg &cfg)
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream)
 {
     const int nq = waves_per_scene(cfg);
-    if (cfg.dx == 9) mmw_launch(k_predict<9>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
-    else mmw_launch(k_predict<6>, dim3(cfg.n_scenes * nq), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
+    const int grid = cfg.n_scenes * nq + (cfg.t_cap <= 63 ? kSpecialUnits : 0);
+    if (cfg.dx == 9) mmw_launch(k_predict<9>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
+    else mmw_launch(k_predict<6>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
 }
 
 }  // namespace mmw

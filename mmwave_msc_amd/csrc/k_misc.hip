@@ -268,10 +268,12 @@ __global__ void k_reset(DevCfg cfg, DevState st)
         h->db_u = 0;
         h->next_uid = 0;
         h->n_upd = 0;
+        h->skipped = 0;
         st.perm[g] = g;
         st.perm[cfg.n_scenes + g] = g;
     }
     for (int e = g; e < 2 * (cfg.t_cap + 1); e += gridDim.x * blockDim.x) st.upd_count[e] = 0;
+    if (g < 2) st.spc_count[g] = 0;
     const size_t tot = (size_t)cfg.n_scenes * cfg.t_cap;
     for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);
 }

@@ -227,9 +227,11 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
+    if (s == 0 && tid == kThreads - 1) st.spc_count[parity ^ 1] = 0;
     if (n <= 0 || n > NP) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
+            hdr->skipped = 1;  // not in this frame's update lists: the next k_predict finds its tracks by this flag
             if (n < 0 || n > NP) atomicOr(&hdr->err, ERR_BADCOUNT);  // a count the context was not sized for
         }
         return;
@@ -690,16 +692,18 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     STAMP(7);  // maintenance
 
     // (_update_all, Tracking.py:598-603, is batched over all tracks in the next launch: k_post)
+    int upd_pos = -1;
     STAMP(8);  // update
     // ---- DBSCAN trigger (Tracking.py:693-697) ----
     if (tid == 0) {
         const int U = L.misc[13];
         hdr->n_tracks = T;
         hdr->n_upd = T;
-        if (T > 0) {  // this scene's tracks join the update list of their count (k_post lays _update_all out over tracks)
-            const int bin = parity * (cfg.t_cap + 1) + T;
-            st.upd_list[(size_t)bin * cfg.n_scenes + atomicAdd(&st.upd_count[bin], 1)] = s;
-        }
+        hdr->skipped = 0;
+        // this scene's tracks join the update list of their count (k_post lays _update_all out over tracks): the
+        // slot is requested here and written at the very end of the kernel -- the atomic's round trip (a microsecond
+        // under 4096 workgroups) must not sit in front of the screen below
+        if (T > 0) upd_pos = atomicAdd(&st.upd_count[parity * (cfg.t_cap + 1) + T], 1);
         const bool need = U > 0 && T < cfg.tr_max_tracks;
         hdr->need_db = need ? 1 : 0;
         L.misc[2] = need ? U : 0;
@@ -753,6 +757,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         atomicAdd(&sl[5], (unsigned long long)Tin);
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);
     }
+    if (tid == 0 && upd_pos >= 0) st.upd_list[((size_t)parity * (cfg.t_cap + 1) + T) * cfg.n_scenes + upd_pos] = s;
 }
 
 template <int PPT>

@@ -236,6 +236,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.perm, 2 * S * sizeof(int32_t));
     ALLOC(c->st.upd_count, 2 * (size_t)(cap + 1) * sizeof(int32_t));
     ALLOC(c->st.upd_list, 2 * (size_t)(cap + 1) * S * sizeof(int32_t));
+    ALLOC(c->st.spc_count, 2 * sizeof(int32_t));
+    ALLOC(c->st.spc_list, 4 * S * sizeof(int32_t));
 #undef ALLOC
     c->st.default_posture = c->d_posture;
     c->st.stats = c->d_stats;
@@ -245,6 +247,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         hipMemset(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.upd_count, 0, 2 * (size_t)(cap + 1) * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(c->st.spc_count, 0, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     c->stream = c->own_stream;
@@ -267,7 +270,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->own_stream) hipStreamDestroy(c->own_stream);

@@ -51,7 +51,7 @@ struct SceneHdr {
     int32_t db_u;
     int32_t next_uid;              // TrackBuffer.next_track_id (Tracking.py:509,588)
     int32_t n_upd;                 // tracks after _maintain_tracks of this frame = what _update_all covers (k_track -> k_post)
-    int32_t pad;
+    int32_t skipped;               // the last frame was empty for this scene (k_track returned at once): its tracks are in no update list
 };
 static_assert(sizeof(SceneHdr) == 64, "SceneHdr");
 
@@ -91,6 +91,8 @@ struct DevState {
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
     int32_t *upd_count;            // [2][t_cap+1] by step parity: scenes that hold t tracks to update this frame (k_track -> k_post)
     int32_t *upd_list;             // [2][t_cap+1][S] ... and which ones: _update_all is laid out over the TRACKS, four per wave
+    int32_t *spc_count;            // [2] by step parity: scenes the next k_predict cannot take from the update lists ...
+    int32_t *spc_list;             // [2][S][2] ... (scene, first new track): scenes that spawned tracks this frame
 };
 
 // Counters are spread over kStatSlots copies (one 256-byte line each, picked by scene index): thousands of
