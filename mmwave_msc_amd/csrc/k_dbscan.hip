@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     const int unit = ((int)blockIdx.x - G0) * 4 + wave;
     if (unit >= cfg.n_scenes * nq) return;
     double *scratch = reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch;
-    if (cfg.t_cap <= 63) {  // four real tracks per wave, from the lists k_track built this frame
+    if (tracks_dense(cfg, nq)) {  // four real tracks per wave, from the lists k_track built this frame
         update_tracks_dense<DX>(cfg, st, unit, cfg.n_scenes * nq, parity, scratch);
         return;
     }

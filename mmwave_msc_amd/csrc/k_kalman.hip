@@ -145,7 +145,7 @@ __device__ __forceinline__ bool dense_pick(const DevCfg &cfg, const DevState &st
 //     four real tracks per wave whatever the scenes hold;
 //   * the last kSpecialUnits units: the scenes that spawned tracks in the previous frame (st.spc_list: their new tracks
 //     n_upd .. n_tracks-1) and the scenes whose previous frame was empty (hdr->skipped: all their tracks), one per wave;
-//   * contexts with t_cap > 63: the per-scene layout, wave q of a scene's nq takes tracks 4q.., 4(q+nq)..
+//   * contexts with t_cap > 63 or too few tracks to fill the chip (tracks_dense, mmw_kalman.hpp): the per-scene layout, wave q of a scene's nq takes tracks 4q.., 4(q+nq)..
 // An empty frame (n_pts <= 0) predicts nothing (offline_main.py:56: such frames never reach track()).
 constexpr int kSpecialUnits = 64;
 template <int DX>
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
     const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     double *Wj = lds + g * kPredScratch;
     int err = 0;
-    if (cfg.t_cap <= 63) {
+    if (tracks_dense(cfg, nq)) {
         const int prev = parity ^ 1, n_dense = cfg.n_scenes * nq;
         if ((int)blockIdx.x < n_dense) {
             if ((int)blockIdx.x * 4 >= st.upd_count[(size_t)prev * (cfg.t_cap + 1)]) return;  // (bin 0 = the total)
@@ -243,7 +243,7 @@ static int waves_per_scene(const DevCfg &cfg)
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream)
 {
     const int nq = waves_per_scene(cfg);
-    const int grid = cfg.n_scenes * nq + (cfg.t_cap <= 63 ? kSpecialUnits : 0);
+    const int grid = cfg.n_scenes * nq + (tracks_dense(cfg, nq) ? kSpecialUnits : 0);
     if (cfg.dx == 9) mmw_launch(k_predict<9>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
     else mmw_launch(k_predict<6>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
 }

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -207,6 +208,11 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (cap > MMW_TRACK_CAP_LIMIT) cap = MMW_TRACK_CAP_LIMIT;
     if (cap < 1) cap = 1;
     d.t_cap = cap; d.max_pts = max_pts; d.n_scenes = n_scenes;
+    {
+        const char *e = getenv("MMW_DENSE_MIN_UNITS");  // test hook: layout of the Kalman kernels, see tracks_dense()
+        d.dense_min_units = e ? atoi(e) : 1024;
+        d.pad0 = 0;
+    }
     d.db_z_weight = cfg->db_z_weight; d.db_range_weight = cfg->db_range_weight; d.db_eps = cfg->db_eps;
     d.tr_lifetime_dynamic = cfg->tr_lifetime_dynamic; d.tr_lifetime_static = cfg->tr_lifetime_static;
     d.tr_vel_thres = cfg->tr_vel_thres; d.tr_gate = cfg->tr_gate; d.kf_q_std = cfg->kf_q_std; d.kf_p_init = cfg->kf_p_init;

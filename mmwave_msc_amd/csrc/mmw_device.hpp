@@ -31,6 +31,8 @@ struct DevCfg {
     int32_t t_cap;
     int32_t max_pts;
     int32_t n_scenes;
+    int32_t dense_min_units;  // Kalman kernels laid out over tracks when the context has more 4-track waves than this (mmw_kalman.hpp)
+    int32_t pad0;
     double db_z_weight, db_range_weight, db_eps;
     double tr_lifetime_dynamic, tr_lifetime_static, tr_vel_thres, tr_gate;
     double kf_q_std, kf_p_init, kf_group_disp_est_init, kf_a_n, kf_est_pointnum;

@@ -151,6 +151,12 @@ __device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, doubl
     wave_sync();
 }
 
+// When the track-wise layout is used: it needs one lane per bin (t_cap <= 63), and it only pays when there are more
+// waves than the chip runs at once -- a small context (256 scenes x 4 tracks) is bound by the latency of one wave, and
+// the lists put two more dependent loads in front of it (k_predict 8.3 -> 9.2 us there).  The threshold is 1024 waves;
+// MMW_DENSE_MIN_UNITS in the environment of mmw_create overrides it (the parity tests run both layouts on small contexts).
+__host__ __device__ inline bool tracks_dense(const DevCfg &cfg, int nq) { return cfg.t_cap <= 63 && cfg.n_scenes * nq > cfg.dense_min_units; }
+
 // _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of the list
 // "scenes by track count, most tracks first" that k_track built this frame (st.upd_list / st.upd_count; every scene
 // in it was tracked this frame and holds hdr->n_upd = its bin's count) -- entry k is track k % t of the (k / t)-th

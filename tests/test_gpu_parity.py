@@ -15,6 +15,13 @@ from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["per_scene", "track_wise"], autouse=True)
+def kalman_layout(request, monkeypatch):
+    """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense): by default the
+    track-wise one is only chosen for contexts with more than 1024 four-track waves."""
+    monkeypatch.setenv("MMW_DENSE_MIN_UNITS", "1000000000" if request.param == "per_scene" else "0")
+
+
 def _mk(n_scenes, max_pts, **kw):
     from mmwave_msc_amd import _lib
     from mmwave_msc_amd.batch import SceneBatch
