@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: scene-frames/s of `TrackBuffer.track` (DBSCAN + gating /
-association + Kalman) over S concurrent synthetic scenes per GPU.
+association + Kalman) over S concurrent synthetic scenes.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
 
-A "step" = one radar frame for every scene of the rank (one `mmw_step`).  Inputs for
+N > 1 needs no launcher: when WORLD_SIZE is unset the script starts one child process per GPU
+itself (before anything in this process touches the GPU) and prints rank 0's line; under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` the ranks it is
+given are used as they are.
+
+A "step" = one radar frame for every scene of the job (one `mmw_step` per rank).  Inputs for
 all W+K frames are resident in HBM before the timed region.  One JSON line on rank 0.
 
-Workload (config.workload): BASELINE.json configs[2] at one GPU -- 4096 scenes x 512
-points, TR_MAX_TRACKS = 8 -- with scene s holding 1 + (s mod 8) walking targets, so that
-7/8 of the scenes keep calling apply_DBscan every frame (a scene whose track list is
-full never clusters again; see DESIGN.md §5 for why the population is mixed).
-Weak scaling: every rank owns `--scenes` scenes; no data-path collective; one RCCL
+Workload: BASELINE.json configs[2] -- 4096 scenes x 512 points, TR_MAX_TRACKS = 8 -- with scene
+s holding 1 + (s mod 8) walking targets, so that 7/8 of the scenes keep calling apply_DBscan
+every frame (a scene whose track list is full never clusters again).
+Scaling: "strong" (default for N > 1) shards the 4096 scenes of configs[2]/[4] over the ranks;
+"weak" gives every rank `--scenes` scenes.  No data-path collective either way; one RCCL
 all-gather of the track table closes the timed region when N > 1.
+
+Beside `value` (tracker only, configs[1]/[2]) the line carries `e2e`: the same scenes stepped
+through track -> features -> MARS CNN -> keypoints EVERY frame (configs[3]/[4], Tracking.py:
+705-734 after every track()), with its own scene-frames/s, the CNN's MFMA roofline and the
+feature kernel's HBM rate; `e2e_parity`: configs[3] (256 scenes x 256 points x 4 tracks) end to
+end against the oracle (ints bit-equal, keypoints <= 1e-4); `cold_start`: frames 0..3 of fresh
+scenes, where every scene clusters its whole ring (the BallTree DBSCAN kernels' own number).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +40,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from mmwave_msc_amd.shard import shard_range  # noqa: E402  (no torch, no GPU)
 from mmwave_msc_amd.synth import make_scene  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+MFMA_FP32_PEAK_TF = 157.3   # dense fp32 matrix-core peak (MI355X_MICROARCH.md)
+VALU_FP64_PEAK_TF = 78.6    # fp64 vector peak with FMA (the tracker is built with -ffp-contract=off: half of it is reachable)
+CNN_FLOP = {3: 25187328.0, 1: 2837504.0}   # per sample: define_CNN_3D / define_CNN
 
 
 def _gen_one(args):
@@ -52,37 +69,43 @@ def generate(scene_ids, frames, n_pts, tracks, workers):
     return np.ascontiguousarray(pts), np.ascontiguousarray(cnt), np.ascontiguousarray(dts)
 
 
-def cpu_legs(pts, cnt, dts, tracks, cores, py_scenes, py_frames, c_scenes):
-    """CPU baselines on a bounded sample of the SAME workload, before the GPU is touched.
-    Returns (cpu_baseline dict, native dict, oracle final states for the parity check)."""
+def cpu_legs(pts, cnt, dts, tracks, cores, W, py_scenes_per_core, py_frames, c_scenes):
+    """CPU baselines on a bounded sample of the SAME workload and the SAME frame window as the GPU (frames
+    W.. of every sampled scene; frames 0..W-1 advance the state untimed), before the GPU is touched.
+    Returns (dict of the two legs, oracle final states for the parity check)."""
     from oracle import c_oracle as co
-    from oracle.py_tracker import run_batch_multiprocess
+    from oracle.py_tracker import run_window_multiprocess
 
     F, S = pts.shape[0], pts.shape[1]
     out = {}
-    # (i) reference-faithful Python restatement, scenes sharded over processes
-    procs = max(1, min(cores, py_scenes))
-    ns = min(S, py_scenes)
-    nf = min(F, py_frames)
-    el, _ = run_batch_multiprocess({"TR_MAX_TRACKS": tracks}, pts[:nf, :ns], cnt[:nf, :ns], dts[:nf, :ns], procs)
+    # (i) reference-shaped Python restatement: one process per host core, BLAS threads pinned to 1, pool up and
+    #     warm-up frames done before the clock starts (a barrier separates the two phases in every worker)
+    procs = max(1, min(cores, S))
+    ns = min(S, procs * max(1, py_scenes_per_core))
+    nf = max(1, min(F - W, py_frames))
+    el, _ = run_window_multiprocess({"TR_MAX_TRACKS": tracks}, pts[:W + nf, :ns], cnt[:W + nf, :ns], dts[:W + nf, :ns], procs, W)
     out["cpu_baseline"] = {
         "value": round(ns * nf / el, 2), "unit": "scene-frames/s", "cores": procs, "kind": "port",
-        "sample": f"oracle/py_tracker.py (numpy + per-point inv/det + sklearn DBSCAN with the Python metric, as the "
-                  f"reference): first {ns} scenes x first {nf} frames of this workload, {procs} processes, {el:.1f} s wall",
+        "sample": f"oracle/py_tracker.py (numpy + per-point inv/det + sklearn DBSCAN with the Python metric, as the reference): "
+                  f"scenes 0..{ns - 1} of this workload, frames {W}..{W + nf - 1} timed after frames 0..{W - 1} untimed "
+                  f"(the GPU's window starts at frame {W} too), {procs} processes x 1 BLAS thread, pool started before the clock, {el:.1f} s wall",
     }
-    # (ii) plain-C oracle, OpenMP over scenes, all frames (also yields the parity reference)
+    # (ii) plain-C oracle, OpenMP over scenes, same window (also yields the parity reference over all F frames)
     cfg = co.default_config(tr_max_tracks=tracks)
     nc = min(S, c_scenes)
     ob = co.OracleBatch(cfg, nc, pts.shape[2])
     threads = max(1, min(cores, co.max_threads(), nc))
     sub_pts = np.ascontiguousarray(pts[:, :nc])
     sub_cnt, sub_dt = np.ascontiguousarray(cnt[:, :nc]), np.ascontiguousarray(dts[:, :nc])
+    if W > 0:
+        co.batch_run_f32(ob, sub_pts[:W], sub_cnt[:W], sub_dt[:W], threads)
     t0 = time.perf_counter()
-    co.batch_run_f32(ob, sub_pts, sub_cnt, sub_dt, threads)
+    co.batch_run_f32(ob, sub_pts[W:], sub_cnt[W:], sub_dt[W:], threads)
     elc = time.perf_counter() - t0
     out["cpu_baseline_native"] = {
-        "value": round(nc * F / elc, 1), "unit": "scene-frames/s", "cores": threads, "kind": "port",
-        "sample": f"oracle/c (plain C, OpenMP, each thread runs whole scenes): first {nc} scenes x all {F} frames, {threads} threads, {elc:.2f} s wall",
+        "value": round(nc * (F - W) / elc, 1), "unit": "scene-frames/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/c (plain C, OpenMP, each thread runs whole scenes): scenes 0..{nc - 1}, frames {W}..{F - 1} timed after "
+                  f"frames 0..{W - 1} untimed, {threads} threads, {elc:.2f} s wall",
     }
     finals = [sc.tracks() for sc in ob.scenes]
     return out, finals
@@ -95,6 +118,84 @@ OTHER_KERNELS = (5, 1, 6)  # _lib.K_PREDICT, K_DBSCAN, K_POST
 # writes P and x
 PREDICT_BYTES_PER_TRACK = 1232 + 720 + 352
 UPDATE_BYTES_PER_TRACK = 1232 + 720
+# fp64 operations per unit of work, counted from the kernels' arithmetic: one gate evaluation =
+# 6 subtractions + 36 mul + 30 add (y'C^-1 y, dense) + 6 mul + 5 add (outer dot) + 1 add (log det) ...
+FLOP_PER_GATE = 84.0
+# k_predict per track: x' = F x and F P F' + Q over F's non-zero terms (~900), C = P[:6,:6] + diag + gd (72),
+# pivoted 6x6 LU + inverse + log det (~580); update half of k_post: K = P H' S^-1 (648), S^-1 (~580), x += K y (114),
+# Joseph form (I-KH) P (I-KH)' (2916) + K R K' (1620)
+FLOP_PER_TRACK_PREDICT = 1550.0
+FLOP_PER_TRACK_UPDATE = 5900.0
+# per point of a frame: 6 column-sum adds + 12 min/max compares + centred 21-entry dispersion products (6 sub, 21 mul, 21 add)
+FLOP_PER_POINT_STATS = 66.0
+
+
+def workload_label(S_total, N, T, world, scaling, S_rank):
+    tag = ""
+    if (S_total, N, T) == (4096, 512, 8):
+        tag = "; BASELINE.json configs[2]"
+    elif (S_total, N, T) == (256, 256, 4):
+        tag = "; BASELINE.json configs[1]"
+    return (f"{S_total} scenes x {N} pts x TR_MAX_TRACKS={T}, DBSCAN+gating+KF (TrackBuffer.track), "
+            f"targets per scene = 1 + (scene_id mod {T}){tag}")
+
+
+def self_launch(args, argv):
+    """One child per GPU, started before this process has touched the GPU; rank 0's stdout is passed through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for raw in procs[0].stdout:
+            line = raw.decode(errors="replace")
+            # the JSON line is the contract; library chatter that lands on rank 0's stdout goes to stderr
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(rank, world, lo, hi, S_total, scaling, slots):
+    """The N > 1 plumbing without a GPU: process group (gloo), this rank's shard, the all-gather of a track table whose
+    rows carry their global scene id, and the rank-0 line."""
+    import torch
+    import torch.distributed as dist
+
+    from mmwave_msc_amd._lib import SUMMARY_DTYPE
+    from mmwave_msc_amd.dist import all_gather_tables, summaries_to_tensor, tensor_to_summaries
+
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    tab = np.zeros((hi - lo, slots), dtype=SUMMARY_DTYPE)
+    tab["scene"] = np.arange(lo, hi)[:, None]
+    tab["slot"] = np.arange(slots)[None, :]
+    glob = tensor_to_summaries(all_gather_tables(summaries_to_tensor(tab)), slots)
+    ok = glob.shape[0] == S_total and bool(np.array_equal(glob["scene"][:, 0], np.arange(S_total)))
+    if world > 1:
+        t = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(t.item() == 1.0)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "scaling": scaling,
+                          "scenes_total": S_total, "scenes_rank0": hi - lo, "gathered_table_rows": int(glob.shape[0]), "gather_ok": ok}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -102,38 +203,66 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scenes", type=int, default=4096, help="scenes per GPU")
+    ap.add_argument("--scenes", type=int, default=4096, help="scenes of the job (strong) / per GPU (weak)")
     ap.add_argument("--pts", type=int, default=512)
     ap.add_argument("--tracks", type=int, default=8, help="TR_MAX_TRACKS")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=None,
+                    help="strong (default): --scenes is the whole job, sharded over the GPUs (BASELINE configs[2]/[4]); "
+                         "weak: every GPU owns --scenes scenes")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
-    ap.add_argument("--py-scenes", type=int, default=64)
+    ap.add_argument("--py-scenes-per-core", type=int, default=2)
     ap.add_argument("--py-frames", type=int, default=20)
     ap.add_argument("--c-scenes", type=int, default=1024)
-    ap.add_argument("--no-posture", action="store_true", help="skip the (untimed-for-value) feature-map + CNN leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (tracker + features + CNN every frame) leg")
+    ap.add_argument("--no-e2e-parity", action="store_true", help="skip the configs[3] end-to-end parity leg")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / shard / gather plumbing only, on the CPU with gloo (tests/test_dist_gloo.py): no GPU work, no metric")
     ap.add_argument("--gen-workers", type=int, default=-1,
                     help="processes for scene generation (-1 = auto; use 1 under rocprofv3: its preloaded tool initialises "
                          "the GPU before main(), and forking after that hangs)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    S, N, K, W = args.scenes, args.pts, args.steps, args.warmup
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    scaling = args.scaling or "strong"
+    N, K, W = args.pts, args.steps, args.warmup
+    if scaling == "strong":
+        S_total = args.scenes
+        lo, hi = shard_range(S_total, rank, world)
+    else:
+        S_total = args.scenes * world
+        lo, hi = rank * args.scenes, (rank + 1) * args.scenes
+    S = hi - lo
+    if S < 1:
+        raise SystemExit(f"rank {rank}: no scenes to own ({S_total} scenes over {world} ranks)")
     F = K + W
     cores = os.cpu_count() or 1
+    single = world == 1 and rank == 0
+
+    if args.dry_run:
+        return dry_run(rank, world, lo, hi, S_total, scaling, args.tracks)
 
     # ---- host-side generation and CPU legs: nothing below touches the GPU yet ----
     t_gen = time.perf_counter()
-    ids = np.arange(rank * S, rank * S + S)
+    ids = np.arange(lo, hi)
     workers = args.gen_workers if args.gen_workers > 0 else max(1, min(32, cores // max(world, 1)))
     pts, cnt, dts = generate(ids, F, N, args.tracks, workers=workers)
     t_gen = time.perf_counter() - t_gen
     cpu, finals = {}, None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu, finals = cpu_legs(pts, cnt, dts, args.tracks, cores, args.py_scenes, args.py_frames, args.c_scenes)
+    if single and not args.no_cpu:
+        cpu, finals = cpu_legs(pts, cnt, dts, args.tracks, cores, W, args.py_scenes_per_core, args.py_frames, args.c_scenes)
+    e2e_ref = None
+    if single and not args.no_e2e_parity:
+        from bench_e2e import oracle_reference  # CPU side of the configs[3] leg (oracle), before the GPU is initialised
+        e2e_ref = oracle_reference(workers)
 
     # ---- GPU ----
     import torch
@@ -148,7 +277,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
     sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks), S, N, device=local_rank)
     # one real stream for torch and the context: uploads, the CNN of the posture leg and the mmw_* calls on device
     # tensors are then ordered by the stream itself (torch's default stream would read as "context's own stream")
@@ -174,6 +307,48 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    # ---- cold start: frames 0..3 of fresh scenes (every scene clusters its whole ring: the BallTree kernels) ----
+    cold = None
+    if not args.no_cold and F >= 4:
+        sb.profile_reset()
+        sb.stats_reset()
+        sb.profile(True)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for f in range(4):
+            step(f)
+        torch.cuda.synchronize()
+        tc = time.perf_counter() - tc
+        sb.profile(False)
+        st = sb.stats()
+        pk = {k: sb.profile_get(k) for k in (_lib.K_DBSCAN, _lib.K_POST, _lib.K_TRACK, _lib.K_PREDICT)}
+        db_ms = pk[_lib.K_DBSCAN][0]
+        cold = {"frames": 4, "ms_total": round(tc * 1e3, 3), "ms_per_frame": [],
+                "k_dbscan_big_ms": round(db_ms, 3), "k_post_ms": round(pk[_lib.K_POST][0], 3), "k_track_ms": round(pk[_lib.K_TRACK][0], 3),
+                "dbscan_calls": int(st[3]), "mean_U": round(float(st[4]) / max(float(st[3]), 1), 1), "clusters_found": int(st[7]),
+                "dbscan_alg_bytes": int(st[1]),
+                "roofline_dbscan": {"kernel": "k_dbscan_big", "bound": "hbm", "achieved": round(float(st[1]) / max(db_ms, 1e-9) / 1e6, 2),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(float(st[1]) / max(db_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 6),
+                                    "note": "BallTree DBSCAN is a latency chain per cloud (build levels, queries, label propagation), "
+                                            "not a stream: algorithmic bytes (68 B per clustered point + spawned records) over kernel time"}}
+        sb.reset()
+        torch.cuda.synchronize()
+        # per-frame wall times of a second cold pass (each frame synchronised: includes launch latency)
+        for f in range(4):
+            t1 = time.perf_counter()
+            step(f)
+            torch.cuda.synchronize()
+            cold["ms_per_frame"].append(round((time.perf_counter() - t1) * 1e3, 3))
+        sb.reset()
+        torch.cuda.synchronize()
+
     for f in range(W):
         step(f)
     torch.cuda.synchronize()
@@ -194,54 +369,17 @@ def main():
             sb.profile(False)
         step(f)
     sb.profile(True)
-    sb.track_table_dev(d_table.data_ptr(), slots, scene_base=rank * S)
+    sb.track_table_dev(d_table.data_ptr(), slots, scene_base=lo)
     gathered = all_gather_tables(d_table)
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
     sb.profile(False)
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = max_over_ranks(el)
     sb.check()
     stats = sb.stats()
     prof = {k: sb.profile_get(k) for k in (_lib.K_TRACK, _lib.K_DBSCAN, _lib.K_TABLE, _lib.K_PREDICT, _lib.K_POST)}
-
-    # ---- secondary: the posture leg on the final state (features kernel -> MARS CNN -> keypoints).
-    #      Not part of `value`; reported so configs[3]/[4] (end-to-end) have a measured number. ----
-    posture = None
-    if not args.no_posture:
-        try:
-            from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
-            cap = S * min(sb.track_cap, 2 * args.tracks)
-            d_feat = torch.empty((cap, sb.ring, 8, 8, 5), dtype=torch.float32, device=dev)
-            d_owner = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-            model = MarsCNN.from_keras_weights(random_keras_weights(0, sb.ring)).to(dev)
-
-            def posture_iter():
-                nrow = sb.features_dev(d_feat.data_ptr(), d_owner.data_ptr(), cap)
-                with torch.no_grad():
-                    kp = model(d_feat[:nrow])
-                sb.set_keypoints_dev(kp.data_ptr(), d_owner.data_ptr(), nrow)
-                return nrow
-
-            for _ in range(2):
-                nrow = posture_iter()
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                nrow = posture_iter()
-            torch.cuda.synchronize()
-            tp = (time.perf_counter() - tp) / reps
-            flop = 25187328.0 if sb.ring == 3 else 2837504.0
-            posture = {"tracks": int(nrow), "ms_per_iter": round(tp * 1e3, 3), "samples_per_s": round(nrow / tp, 1),
-                       "cnn_tflops_fp32": round(nrow * flop / tp / 1e12, 2), "mfma_fp32_peak_tflops": 157.3,
-                       "note": "features kernel + torch-ROCm CNN (fp32, random Keras-layout weights) + keypoint scatter on the final state; "
-                               "with this leg every frame the step would take ms_per_step + ms_per_iter"}
-        except Exception as exc:  # never lose the headline line over the secondary leg
-            posture = {"error": repr(exc)[:200]}
+    gathered_rows = int(gathered.shape[0])
 
     parity = None
     if finals is not None:
@@ -257,14 +395,31 @@ def main():
                 ok &= bool(np.array_equal(got[name], want[name]))
         parity = {"scenes_checked": len(finals), "frames": F, "bit_equal_vs_oracle": bool(ok)}
 
+    # ---- end to end: the same scenes again from frame 0, estimate_posture after every track() ----
+    e2e = None
+    if not args.no_e2e:
+        try:
+            from bench_e2e import e2e_leg
+            e2e = e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, side)
+        except Exception as exc:  # never lose the headline line over the second leg
+            e2e = {"error": repr(exc)[:300]}
+    e2e_par = None
+    if e2e_ref is not None:
+        try:
+            from bench_e2e import e2e_parity_leg
+            e2e_par = e2e_parity_leg(e2e_ref, local_rank)
+        except Exception as exc:
+            e2e_par = {"error": repr(exc)[:300]}
+
     if rank == 0:
-        total_sf = S * world * K
+        total_sf = S_total * K
         # per-kernel device time from the sampled HIP-event pairs (one step in PROF_EVERY); algorithmic bytes
         # from the device counters, which cover all K steps
         n_samp = max(prof[_lib.K_TRACK][1], 1)
         step_ms = {k: prof[k][0] / max(prof[k][1], 1)
                    for k in (_lib.K_PREDICT, _lib.K_TRACK, _lib.K_DBSCAN, _lib.K_POST)}
         tracks_in = float(stats[5])  # sum over scene-frames of the tracks entering track()
+        gate_evals = float(stats[6])
         step_bytes = {
             _lib.K_PREDICT: tracks_in * PREDICT_BYTES_PER_TRACK / K,
             _lib.K_TRACK: float(stats[0]) / K,
@@ -274,7 +429,7 @@ def main():
         dom = max(step_ms, key=step_ms.get)
         dom_ms, dom_bytes = step_ms[dom], step_bytes[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             try:
@@ -284,22 +439,35 @@ def main():
                 # FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, bytes per launch, from a
                 # separate rocprofv3 --pmc run of this workload (profiles/README.md)
                 traffic = ent.get("hbm_bytes_per_launch_fetch_x2") if isinstance(ent, dict) else ent
+                if traffic is not None:
+                    traffic_src = f"profiles/traffic.json[{key}] ({tj.get('source', 'separate rocprofv3 --pmc passes')}); not measured in this run"
             except Exception:
                 traffic = None
+        # B_trk = 64N + 4N + 4U + 2*T*1200 + 64*U_new per scene-frame, with the run's own means
+        sf = max(float(stats[2]), 1.0)
+        mean_T = tracks_in / sf
+        mean_U = float(stats[4]) / max(float(stats[3]), 1.0)
+        db_frac = float(stats[3]) / sf      # apply_DBscan calls per scene-frame
+        u_new = mean_U / sb.ring            # unassigned rows appended per frame ~ a ring-th of the clustered cloud
+        b_trk = 64.0 * N + 4.0 * N + 4.0 * mean_U * db_frac + 2.0 * mean_T * 1200.0 + 64.0 * u_new
+        # fp64 operations of the step's tracker arithmetic, counted from the device work counters
+        flop_track = gate_evals / K * FLOP_PER_GATE + (S * N) * FLOP_PER_POINT_STATS
+        flop_step = flop_track + tracks_in / K * (FLOP_PER_TRACK_PREDICT + FLOP_PER_TRACK_UPDATE)
         line = {
             "metric": "scene_frames_per_sec", "value": round(total_sf / el, 1), "unit": "scene-frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"{S} scenes/GPU x {N} pts x TR_MAX_TRACKS={args.tracks}, DBSCAN+gating+KF (TrackBuffer.track), "
-                            f"targets per scene = 1 + (scene_id mod {args.tracks}); BASELINE.json configs[2]",
-                "scenes_per_gpu": S, "points_per_frame": N, "max_tracks": args.tracks, "frames_resident": F,
-                "parallelism": f"scenes sharded over {world} GPU(s), weak; all-gather of track table once per run",
+                "workload": workload_label(S_total, N, args.tracks, world, scaling, S),
+                "scenes_total": S_total, "scenes_per_gpu": S, "points_per_frame": N, "max_tracks": args.tracks, "frames_resident": F,
+                "parallelism": f"scenes sharded over {world} GPU(s), {scaling} scaling, no data-path collective; "
+                               f"all-gather of the track table once per run",
+                "n_ranks_seen": n_ranks_seen, "gathered_table_rows": gathered_rows,
             },
             "roofline": {
                 "kernel": _lib.load().mmw_kernel_name(dom).decode(), "bound": "hbm",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(dom_bytes, 1),
                 "avg_launch_ms": round(dom_ms, 5), "launches_timed": n_samp,
             },
@@ -307,21 +475,37 @@ def main():
             "roofline_whole_step": {"bound": "hbm", "achieved": round(sum(step_bytes.values()) / (el / K) / 1e9, 2), "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(sum(step_bytes.values()) / (el / K) / 1e9 / HBM_PEAK_GBS, 6),
                                     "algorithmic_bytes_per_step": round(sum(step_bytes.values()), 1)},
+            # the same step priced with SURVEY.md §8(d)'s own byte formula (one read + one write of a 1200-byte record
+            # per track, no per-track ring rows): the kernels move more than that (4 launches re-read the records)
+            "roofline_survey_bytes": {"bound": "hbm", "bytes_per_scene_frame": round(b_trk, 1),
+                                      "achieved": round(b_trk * S / (el / K) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(b_trk * S / (el / K) / 1e9 / HBM_PEAK_GBS, 6)},
+            # the other roof SURVEY.md §8(d) names: fp64 vector arithmetic of k_track / of the whole step
+            "roofline_valu": {"bound": "valu_fp64", "kernel": "k_track", "flop_per_launch": round(flop_track, 1),
+                              "achieved": round(flop_track / (step_ms[_lib.K_TRACK] * 1e-3) / 1e12, 3) if step_ms[_lib.K_TRACK] > 0 else None,
+                              "peak": VALU_FP64_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": round(flop_track / (step_ms[_lib.K_TRACK] * 1e-3) / 1e12 / VALU_FP64_PEAK_TF, 6) if step_ms[_lib.K_TRACK] > 0 else None,
+                              "whole_step_tflops": round(flop_step / (el / K) / 1e12, 3),
+                              "note": "peak counts FMA as 2; the tracker is compiled with -ffp-contract=off (fixed operation order), so half the peak is reachable"},
             "kernels": {
                 name: {"avg_ms": round(step_ms[k], 5), "alg_bytes_per_launch": round(step_bytes[k], 1)}
                 for k, name in ((_lib.K_PREDICT, "k_predict"), (_lib.K_TRACK, "k_track"),
                                 (_lib.K_DBSCAN, "k_dbscan_big"), (_lib.K_POST, "k_post"))
             },
-            "work": {"dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(float(stats[4]) / max(float(stats[3]), 1), 1),
-                     "gate_evals_per_step": round(float(stats[6]) / K, 1), "tracks_per_scene": round(tracks_in / max(float(stats[2]), 1), 2),
+            "work": {"dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(mean_U, 1),
+                     "gate_evals_per_step": round(gate_evals / K, 1), "tracks_per_scene": round(mean_T, 2),
                      "clusters_found_per_step": round(float(stats[7]) / K, 2)},
             "host": {"cores": cores, "gen_s": round(t_gen, 1)},
         }
         line.update(cpu)
         if parity is not None:
             line["parity"] = parity
-        if posture is not None:
-            line["posture_leg"] = posture
+        if cold is not None:
+            line["cold_start"] = cold
+        if e2e is not None:
+            line["e2e"] = e2e
+        if e2e_par is not None:
+            line["e2e_parity"] = e2e_par
         if "cpu_baseline" in cpu:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / cpu["cpu_baseline"]["value"], 1)
             line["speedup_vs_cpu_native"] = round(line["value"] / cpu["cpu_baseline_native"]["value"], 1)
@@ -329,8 +513,7 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     sb.close()
-    _ = gathered
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

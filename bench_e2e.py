@@ -1,0 +1,195 @@
+"""End-to-end legs of bench.py (BASELINE.json configs[3]/[4]): `TrackBuffer.track` followed by
+`TrackBuffer.estimate_posture` EVERY frame (reference offline_main.py:57-60, Tracking.py:705-734),
+batched over the scenes of a context and pipelined by `mmwave_msc_amd.posture.PosturePipeline`.
+
+* `e2e_leg`          -- the bench workload again from frame 0 with the CNN in the loop: scene-frames/s,
+                        MFMA roofline of the CNN, HBM rate of the feature kernel.
+* `oracle_reference` -- CPU side of the configs[3] parity leg (256 scenes x 256 points x 4 tracks): the C oracle's
+                        tracker + feature map every frame and the fp64 numpy CNN (oracle/, test infrastructure: used
+                        here only as the checker).
+* `e2e_parity_leg`   -- the GPU side of it and the comparison: integers / fp64 state bit-equal, keypoints <= 1e-4.
+"""
+import time
+
+import numpy as np
+
+MFMA_FP32_PEAK_TF = 157.3
+HBM_PEAK_GBS = 8000.0
+CNN_FLOP = {3: 25187328.0, 1: 2837504.0}
+KP_TOL = 1e-4            # max|d| <= 1e-4 (m) and rel 1e-4 on the 57 outputs
+E2E_PAR = dict(S=256, N=256, T=4, F=10, seed0=9000)
+MARK = 12345.0
+
+
+def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
+    import torch
+
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.posture import PosturePipeline
+
+    cap = S * min(sb.track_cap, 2 * sb.cfg.tr_max_tracks)
+    model = MarsCNN.from_keras_weights(random_keras_weights(0, sb.ring)).to(dev)
+    out = {}
+    for mode in ("overlap", "serial"):
+        pipe = PosturePipeline(sb, model, cap, tracker_stream=stream_a, overlap=(mode == "overlap"), time_cnn=True)
+        sb.reset()
+        sb.profile(False)
+        for f in range(W):
+            step(f)
+            pipe.after_step()
+        pipe.drain()
+        sb.check()
+        sb.stats_reset()
+        sb.profile_reset()
+        pipe.reset_counters()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(W, F):
+            # the feature kernel's own HIP-event pair on a sample of the frames (a pair idles the stream ~10 us)
+            sb.profile(True, kernels=(_lib.K_FEATURES,)) if (f - W) % 4 == 0 else sb.profile(False)
+            step(f)
+            pipe.after_step()
+        pipe.drain()
+        torch.cuda.synchronize()
+        barrier()
+        el = max_over_ranks(time.perf_counter() - t0)
+        sb.profile(False)
+        sb.check()
+        K = F - W
+        rows = pipe.rows_total
+        ext = sb.stats_ext()
+        f_ms, f_cnt = sb.profile_get(_lib.K_FEATURES)
+        feat_bytes_per_launch = float(ext[30]) / max(K, 1)
+        f_avg = f_ms / max(f_cnt, 1)
+        cnn_ms = pipe.cnn_ms()
+        flop = CNN_FLOP[3 if sb.ring == 3 else 1]
+        res = {
+            "value": round(S * world * K / el, 1), "unit": "scene-frames/s", "ms_per_step": round(el / K * 1e3, 4),
+            "samples_per_step": round(rows / max(K, 1), 1), "samples_per_s": round(rows / el, 1),
+            "cnn_ms_per_step": round(cnn_ms, 4) if cnn_ms is not None else None,
+            "roofline_cnn": {"bound": "mfma", "dtype": "f32", "achieved": round(rows * flop / el / 1e12, 2), "peak": MFMA_FP32_PEAK_TF,
+                             "unit": "TFLOP/s", "frac": round(rows * flop / el / 1e12 / MFMA_FP32_PEAK_TF, 6),
+                             "flop_per_sample": flop,
+                             "cnn_only_tflops": round(rows / max(K, 1) * flop / (cnn_ms * 1e-3) / 1e12, 2) if cnn_ms else None},
+            "roofline_features": {"kernel": "k_features", "bound": "hbm", "achieved": round(feat_bytes_per_launch / max(f_avg, 1e-9) / 1e6, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(feat_bytes_per_launch / max(f_avg, 1e-9) / 1e6 / HBM_PEAK_GBS, 6),
+                                  "algorithmic_bytes_per_launch": round(feat_bytes_per_launch, 1), "avg_launch_ms": round(f_avg, 5),
+                                  "launches_timed": int(f_cnt)},
+        }
+        out[mode] = res
+    best = out["overlap"]
+    best = dict(best)
+    best["mode"] = ("track(f+1) on the tracker stream beside CNN(f) on a second stream; keypoints scattered by track creation ordinal "
+                    "(mmwave_msc_amd/posture.py)")
+    best["serial_one_stream"] = {k: out["serial"][k] for k in ("value", "ms_per_step", "cnn_ms_per_step")}
+    best["config"] = (f"{S * world} scenes, track -> features -> MARS CNN (fp32, random Keras-layout weights) -> keypoints every frame; "
+                      f"BASELINE.json configs[4] shape at {world} GPU(s)")
+    best["steps"] = F - W
+    return best
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def oracle_reference(workers=1):
+    """configs[3] on the CPU oracle: per frame track -> features -> (CNN deferred) -> set_keypoints.  The CNN is a pure
+    function of the feature tensor, so the oracle stores every tensor it would have fed to `model.predict`, tags the
+    track with the tensor's index instead of real keypoints, and evaluates the fp64 CNN once at the end for the
+    tensor each surviving track was tagged with last: identical to running it every frame, at a fraction of the cost."""
+    from mmwave_msc_amd.mars import random_keras_weights
+    from mmwave_msc_amd.synth import make_batch  # noqa: F401
+    from oracle import c_oracle as co
+    from oracle.mars_np import mars_forward_np
+    import bench
+
+    p = E2E_PAR
+    S, N, T, F = p["S"], p["N"], p["T"], p["F"]
+    ids = np.arange(p["seed0"], p["seed0"] + S)
+    pts, cnt, dts = bench.generate(ids, F, N, T, workers)
+    cfg = co.default_config(tr_max_tracks=T)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    store = []
+    t0 = time.perf_counter()
+    for f in range(F):
+        for s, sc in enumerate(scenes):
+            c = int(cnt[f, s])
+            if c == 0:
+                continue
+            sc.track(pts[f, s, :c].astype(np.float64), float(dts[f, s]))
+            feat, owner = sc.features()
+            if len(owner):
+                tag = np.zeros((len(owner), 57), dtype=np.float32)
+                tag[:, 0] = np.arange(len(store), len(store) + len(owner), dtype=np.float32)
+                tag[:, 1] = MARK
+                store.extend(feat)
+                sc.set_keypoints(tag, owner)
+    assert len(store) < (1 << 24)
+    finals = [sc.tracks() for sc in scenes]
+    w = random_keras_weights(0, 3)
+    need = sorted({int(r["keypoints"][0]) for fin in finals for r in fin if r["keypoints"][1] == MARK})
+    kp_of = {}
+    for i in range(0, len(need), 256):
+        idx = need[i:i + 256]
+        kp = mars_forward_np(w, np.stack([store[j] for j in idx]).astype(np.float64))
+        kp_of.update(zip(idx, kp))
+    default = np.array(list(cfg.default_posture), dtype=np.float64)
+    want_kp = [np.stack([kp_of[int(r["keypoints"][0])] if r["keypoints"][1] == MARK else default for r in fin])
+               if len(fin) else np.zeros((0, 57)) for fin in finals]
+    return {"pts": pts, "cnt": cnt, "dts": dts, "finals": finals, "want_kp": want_kp, "weights": w,
+            "oracle_s": round(time.perf_counter() - t0, 1), "samples_cnn": len(need)}
+
+
+def e2e_parity_leg(ref, device):
+    import torch
+
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.mars import MarsCNN
+    from mmwave_msc_amd.posture import PosturePipeline
+
+    p = E2E_PAR
+    S, N, T, F = p["S"], p["N"], p["T"], p["F"]
+    dev = torch.device("cuda", device)
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N, device=device)
+    model = MarsCNN.from_keras_weights(ref["weights"]).to(dev)
+    pipe = PosturePipeline(sb, model, S * min(sb.track_cap, 2 * T))
+    with torch.cuda.stream(pipe.A):
+        d_pts = torch.from_numpy(ref["pts"]).to(dev).double()
+        d_cnt = torch.from_numpy(ref["cnt"]).to(dev)
+        d_dt = torch.from_numpy(ref["dts"]).to(dev)
+    pipe.A.synchronize()
+
+    def run():
+        sb.reset()
+        for f in range(F):
+            sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+            pipe.after_step()
+        pipe.drain()
+
+    run()            # first pass: also warms hipBLASLt / the allocator
+    sb.check()
+    t0 = time.perf_counter()
+    run()
+    el = time.perf_counter() - t0
+    sb.check()
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    ints_ok, max_err, n_kp = True, 0.0, 0
+    for s, want in enumerate(ref["finals"]):
+        got = trk[s, : ntr[s]]
+        ints_ok &= len(want) == int(ntr[s])
+        if not ints_ok:
+            break
+        for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "lifetime", "point_num", "is_static", "ring_n"):
+            ints_ok &= bool(np.array_equal(got[name], want[name]))
+        if len(want):
+            wk = ref["want_kp"][s]
+            err = np.abs(got["keypoints"].astype(np.float64) - wk) / np.maximum(1.0, np.abs(wk))
+            max_err = max(max_err, float(err.max()))
+            n_kp += len(want)
+    sb.close()
+    return {"config": f"{S} scenes x {N} pts x TR_MAX_TRACKS={T}, {F} frames, track+features+CNN+keypoints every frame; BASELINE.json configs[3]",
+            "tracker_state_bit_equal_vs_oracle": bool(ints_ok), "tracks_checked": int(n_kp),
+            "keypoint_max_err": float(f"{max_err:.3e}"), "keypoint_tol": KP_TOL, "keypoints_ok": bool(ints_ok and max_err <= KP_TOL),
+            "cnn_oracle": "oracle/mars_np.py (fp64 numpy restatement of train.py:71-106; parity unpinned: no Keras / MARS.h5 in the image)",
+            "ms_per_step": round(el / F * 1e3, 4), "scene_frames_per_sec": round(S * F / el, 1), "oracle_s": ref["oracle_s"]}

@@ -176,6 +176,14 @@ int mmw_dbscan(mmw_ctx *ctx, const double *pts, const int32_t *n, int32_t max_n,
  *   owner[cap_rows][2] int32 (dev) = (scene, track index)
  *   *n_rows (host) = rows written (sync).  MMW_E_CAPACITY if cap_rows is too small. */
 int mmw_features(mmw_ctx *ctx, float *feat, int32_t *owner, int32_t cap_rows, int32_t *n_rows);
+/* The same without the host wait, for a caller that pipelines frames (the CNN of frame f on one stream while the
+ * tracker of frame f+1 runs on the context's): the rows are written behind the preceding mmw_step on the context's
+ * stream, the eligible-track total follows them into pinned host memory, and mmw_features_wait(ticket) waits for THAT
+ * copy only (not for the stream).  ticket in [0,4): up to four calls may be outstanding (ticket 3 is the one
+ * mmw_features itself uses).  uid[cap_rows] (dev, may be NULL) receives each row's track creation ordinal
+ * (mmw_track_record.uid) for mmw_set_keypoints_uid. */
+int mmw_features_async(mmw_ctx *ctx, float *feat, int32_t *owner, int32_t *uid, int32_t cap_rows, int32_t ticket);
+int mmw_features_wait(mmw_ctx *ctx, int32_t ticket, int32_t *n_rows);   /* waits for that ticket's total only */
 /* Utils.relative_coordinates + Utils.format_single_frame (Utils.py:437-520) on caller
  * frames: frames[B][ring][64][8] fp64 (only rows [:64] matter, Utils.py:505-510),
  * counts[B][ring] valid rows (<= 0 rows: frame stays zero, Utils.py:493), ref[B][2] = (x, y)
@@ -183,6 +191,11 @@ int mmw_features(mmw_ctx *ctx, float *feat, int32_t *owner, int32_t cap_rows, in
 int mmw_format_frames(mmw_ctx *ctx, const double *frames, const int32_t *counts, const double *ref, float *feat, int32_t n_items);
 /* track.keypoints = frame_keypoints[i] (Tracking.py:733-734): kp[n_rows][57] fp32 dev. */
 int mmw_set_keypoints(mmw_ctx *ctx, const float *kp, const int32_t *owner, int32_t n_rows);
+
+/* The same assignment when later frames have been tracked since mmw_features_async took the rows (list positions are
+ * stale then): row i goes to the track of scene owner[i][0] whose creation ordinal is uid[i]; rows of tracks that
+ * have expired meanwhile are dropped, as `track.keypoints = ...` on an object no list refers to any more would be. */
+int mmw_set_keypoints_uid(mmw_ctx *ctx, const float *kp, const int32_t *owner, const int32_t *uid, int32_t n_rows);
 
 /* Read-back (sync; host pointers).  Also surfaces per-scene errors recorded by
  * the kernels (returns the first one and sets the message). */
@@ -242,8 +255,9 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
  * [6] gate evaluations (points x tracks)  [7] clusters found.  Definitions: DESIGN.md §4. */
 int mmw_stats_get(mmw_ctx *ctx, uint64_t *out /*[8]*/);
 int mmw_stats_reset(mmw_ctx *ctx);
-/* [0..7] as mmw_stats_get; [8..31] per-phase cycle sums, non-zero only in the diagnostic build
- * (make -C mmwave_msc_amd/csrc STAMPS=1), see scripts/phase_stamps.py. */
+/* [0..7] as mmw_stats_get; [8..29] per-phase cycle sums, non-zero only in the diagnostic build
+ * (make -C mmwave_msc_amd/csrc STAMPS=1), see scripts/phase_stamps.py; [30] k_features algorithmic bytes (ring rows
+ * read + fp32 tensors written)  [31] feature tensors written. */
 int mmw_stats_get_ext(mmw_ctx *ctx, uint64_t *out /*[32]*/);
 /* on = 0: off; 1: every kernel id; otherwise a mask, bit (k + 1) selects kernel id k.  Does not synchronise. */
 int mmw_profile_enable(mmw_ctx *ctx, int32_t on);

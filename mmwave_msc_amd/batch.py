@@ -186,6 +186,20 @@ class SceneBatch:
         self._chk(self.L.mmw_features(self.h, feat_ptr, owner_ptr, int(cap_rows), C.byref(nrows)))
         return nrows.value
 
+    def features_async(self, feat_ptr, owner_ptr, uid_ptr, cap_rows: int, ticket: int = 0):
+        """mmw_features without the host wait (pipelined callers): rows behind the last step on the context's stream."""
+        self._chk(self.L.mmw_features_async(self.h, feat_ptr, owner_ptr, uid_ptr, int(cap_rows), int(ticket)))
+
+    def features_wait(self, ticket: int = 0) -> int:
+        """Rows of the `features_async` call with this ticket (waits for its total only, not for the stream)."""
+        nrows = C.c_int32(0)
+        self._chk(self.L.mmw_features_wait(self.h, int(ticket), C.byref(nrows)))
+        return nrows.value
+
+    def set_keypoints_uid_dev(self, kp_ptr, owner_ptr, uid_ptr, n_rows: int):
+        """Keypoint scatter matched by track creation ordinal (rows taken one or more frames ago)."""
+        self._chk(self.L.mmw_set_keypoints_uid(self.h, kp_ptr, owner_ptr, uid_ptr, int(n_rows)))
+
     def features_host(self, cap_rows=None):
         """Returns (feat[B,ring,8,8,5] float32 (or [B,8,8,5] when ring == 1), owner[B,2])."""
         cap = int(cap_rows if cap_rows is not None else self.S * self.track_cap)
@@ -255,6 +269,12 @@ class SceneBatch:
     def stats(self) -> np.ndarray:
         out = np.zeros(8, dtype=np.uint64)
         self._chk(self.L.mmw_stats_get(self.h, out.ctypes.data))
+        return out
+
+    def stats_ext(self) -> np.ndarray:
+        """[0..7] as `stats`; [30] k_features algorithmic bytes, [31] feature tensors written (include/mmw.h)."""
+        out = np.zeros(32, dtype=np.uint64)
+        self._chk(self.L.mmw_stats_get_ext(self.h, out.ctypes.data))
         return out
 
     def stats_reset(self):

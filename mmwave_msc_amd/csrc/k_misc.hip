@@ -134,7 +134,8 @@ __device__ inline void sort_rows_store(int lane, double v0, double v1, double v2
 
 // One wave per (eligible track, ring frame): lane r owns row r of the 64-row frame.
 __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const int32_t *__restrict__ row_off,
-                                                  float *__restrict__ feat, int32_t *__restrict__ owner, int cap_rows)
+                                                  float *__restrict__ feat, int32_t *__restrict__ owner, int32_t *__restrict__ uid,
+                                                  int cap_rows)
 {
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const SceneHdr *hdr = st.hdr + s;
@@ -142,14 +143,21 @@ __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const
     const TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
     const int T = hdr->n_tracks, ring = cfg.ring;
     int row = row_off[s];
+    unsigned long long rd_bytes = 0, rows_done = 0;
     for (int j = 0; j < T; j++) {
         const int slot = order[j];
         const TrackRec *rec = trk + slot;
         int total = 0;
         for (int k = 0; k < rec->ring_len; k++) total += rec->ring_n[k];
         if (!(total > cfg.model_min_input)) continue;
-        if (row >= cap_rows) return;
-        if (tid == 0) { owner[row * 2] = s; owner[row * 2 + 1] = j; }
+        if (row >= cap_rows) break;
+        for (int k = 0; k < rec->ring_len; k++) rd_bytes += 64ULL * min(rec->ring_n[k], 64);
+        rows_done++;
+        if (tid == 0) {
+            owner[row * 2] = s;
+            owner[row * 2 + 1] = j;
+            if (uid) uid[row] = rec->uid;
+        }
         const double cx = rec->centroid[0], cy = rec->centroid[1];
         for (int k = wave; k < ring; k += 4) {
             float *dst = feat + (((size_t)row * ring + k) * 64) * 5;
@@ -168,6 +176,11 @@ __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const
             sort_rows_store(lane, v0, v1, v2, v3, v4, dst);
         }
         row++;
+    }
+    if (tid == 0 && st.stats && rows_done) {  // algorithmic bytes: ring rows read (<= 64 per frame, 64 B each), fp32 tensor written
+        unsigned long long *sl = stats_slot(st, s);
+        atomicAdd(&sl[kStatFeatBytes], rd_bytes + rows_done * (unsigned long long)(ring * 64 * 5 * 4));
+        atomicAdd(&sl[kStatFeatRows], rows_done);
     }
 }
 
@@ -204,6 +217,32 @@ __global__ void k_set_kp(DevCfg cfg, DevState st, const float *__restrict__ kp, 
     if (j < 0 || j >= hdr->n_tracks) return;
     TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + st.order[(size_t)s * cfg.t_cap + j];
     rec->kp[e] = kp[(size_t)row * MMW_NKP + e];
+}
+
+// The same assignment one or more frames LATER (the CNN of frame f runs beside the tracker of frame f+1): the track
+// list may have been re-ordered or shortened by _maintain_tracks since the features were taken, so a row is matched
+// by the track's creation ordinal instead of its list position; a track that has expired meanwhile drops its row.
+__global__ void k_set_kp_uid(DevCfg cfg, DevState st, const float *__restrict__ kp, const int32_t *__restrict__ owner,
+                             const int32_t *__restrict__ uid, int n_rows)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = g / 64, e = g % 64;
+    if (row >= n_rows) return;
+    const int s = owner[row * 2], u = uid[row];
+    if (s < 0 || s >= cfg.n_scenes) return;
+    const int T = min(st.hdr[s].n_tracks, cfg.t_cap);
+    const int32_t *order = st.order + (size_t)s * cfg.t_cap;
+    TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+    // list positions only move towards the front (ballot compaction), so start at the recorded one
+    int hit = -1;
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        const int j = j0 + e;
+        const bool m = j < T && trk[order[j]].uid == u;
+        const unsigned long long b = __ballot(m);
+        if (b) { hit = order[j0 + __ffsll((long long)b) - 1]; break; }
+    }
+    if (hit < 0 || e >= MMW_NKP) return;
+    trk[hit].kp[e] = kp[(size_t)row * MMW_NKP + e];
 }
 
 // ---------------------------------------------------------------------------
@@ -287,9 +326,10 @@ void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hi
     hipLaunchKernelGGL(k_feat_count, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, row_off);
     hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cfg, row_off);
 }
-void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st)
+void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
+                     hipStream_t st)
 {
-    hipLaunchKernelGGL(k_features, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, s, row_off, feat, owner, cap);
+    hipLaunchKernelGGL(k_features, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, s, row_off, feat, owner, uid, cap);
 }
 void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t *counts, const double *ref, float *feat, int B, hipStream_t st)
 {
@@ -300,6 +340,12 @@ void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const 
 {
     if (n_rows <= 0) return;
     hipLaunchKernelGGL(k_set_kp, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, st, cfg, s, kp, owner, n_rows);
+}
+void launch_set_kp_uid(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, const int32_t *uid, int n_rows,
+                       hipStream_t st)
+{
+    if (n_rows <= 0) return;
+    hipLaunchKernelGGL(k_set_kp_uid, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, st, cfg, s, kp, owner, uid, n_rows);
 }
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st)
 {

@@ -29,7 +29,10 @@ void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int3
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
 void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
-void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int cap, hipStream_t st);
+void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
+                     hipStream_t st);
+void launch_set_kp_uid(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, const int32_t *uid, int n_rows,
+                       hipStream_t st);
 void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t *counts, const double *ref, float *feat, int B, hipStream_t st);
 void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st);
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
@@ -56,6 +59,9 @@ struct mmw_ctx {
     std::string err;
     // internal scratch
     int32_t *d_row_off = nullptr;     // [S+1]
+    int32_t *h_rows = nullptr;        // pinned [kTickets]: eligible-track totals of the outstanding mmw_features_async calls
+    hipEvent_t feat_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t feat_cap[4] = {0, 0, 0, 0};
     float *d_posture = nullptr;
     unsigned long long *d_stats = nullptr;
     int32_t *d_db_list = nullptr, *d_db_count = nullptr;
@@ -71,6 +77,8 @@ struct mmw_ctx {
     double tot_ms[MMW_K_COUNT] = {0};
     int64_t launches[MMW_K_COUNT] = {0};
 };
+
+constexpr int kTickets = 4;
 
 static int fail(mmw_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -256,6 +264,11 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         hipMemset(c->st.spc_count, 0, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
+    if (hipHostMalloc((void **)&c->h_rows, kTickets * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipHostMalloc failed"); }
+    for (int k = 0; k < kTickets; k++) {
+        c->h_rows[k] = 0;
+        if (hipEventCreateWithFlags(&c->feat_ev[k], hipEventDisableTiming) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipEventCreate failed"); }
+    }
     c->stream = c->own_stream;
     size_t lds_b = dbscan_only_lds_bytes(c->UM);
     for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
@@ -279,6 +292,8 @@ int mmw_destroy(mmw_ctx *c)
     void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
+    for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
+    if (c->h_rows) hipHostFree(c->h_rows);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return MMW_OK;
@@ -441,22 +456,39 @@ int mmw_dbscan(mmw_ctx *c, const double *pts, const int32_t *n, int32_t max_n, d
     return MMW_OK;
 }
 
-int mmw_features(mmw_ctx *c, float *feat, int32_t *owner, int32_t cap_rows, int32_t *n_rows)
+int mmw_features_async(mmw_ctx *c, float *feat, int32_t *owner, int32_t *uid, int32_t cap_rows, int32_t ticket)
 {
-    if (!c || !feat || !owner || !n_rows || cap_rows < 0) return fail(c, MMW_E_ARG, "mmw_features: bad argument");
+    if (!c || !feat || !owner || cap_rows < 0 || ticket < 0 || ticket >= kTickets) return fail(c, MMW_E_ARG, "mmw_features_async: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
     launch_feat_scan(c->dc, c->st, c->d_row_off, c->stream);
     prof_begin(c, MMW_K_FEATURES, ep);
-    launch_features(c->dc, c->st, c->d_row_off, feat, owner, cap_rows, c->stream);
+    launch_features(c->dc, c->st, c->d_row_off, feat, owner, uid, cap_rows, c->stream);
     prof_end(c, ep);
     HIPCHK(c, hipGetLastError());
-    int32_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, c->d_row_off + c->dc.n_scenes, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the total travels to pinned host memory behind the kernels; only mmw_features_wait(ticket) waits for it
+    HIPCHK(c, hipMemcpyAsync(c->h_rows + ticket, c->d_row_off + c->dc.n_scenes, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->feat_ev[ticket], c->stream));
+    c->feat_cap[ticket] = cap_rows;
+    return MMW_OK;
+}
+
+int mmw_features_wait(mmw_ctx *c, int32_t ticket, int32_t *n_rows)
+{
+    if (!c || !n_rows || ticket < 0 || ticket >= kTickets) return fail(c, MMW_E_ARG, "mmw_features_wait: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->feat_ev[ticket]));
+    const int32_t total = c->h_rows[ticket], cap_rows = c->feat_cap[ticket];
     *n_rows = total < cap_rows ? total : cap_rows;
     if (total > cap_rows) return fail(c, MMW_E_CAPACITY, "mmw_features: %d eligible tracks but cap_rows=%d", total, cap_rows);
     return MMW_OK;
+}
+
+int mmw_features(mmw_ctx *c, float *feat, int32_t *owner, int32_t cap_rows, int32_t *n_rows)
+{
+    if (!c || !feat || !owner || !n_rows || cap_rows < 0) return fail(c, MMW_E_ARG, "mmw_features: bad argument");
+    const int rc = mmw_features_async(c, feat, owner, nullptr, cap_rows, kTickets - 1);
+    return rc ? rc : mmw_features_wait(c, kTickets - 1, n_rows);
 }
 
 int mmw_format_frames(mmw_ctx *c, const double *frames, const int32_t *counts, const double *ref, float *feat, int32_t n_items)
@@ -473,6 +505,15 @@ int mmw_set_keypoints(mmw_ctx *c, const float *kp, const int32_t *owner, int32_t
     if (!c || (n_rows > 0 && (!kp || !owner)) || n_rows < 0) return fail(c, MMW_E_ARG, "mmw_set_keypoints: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     launch_set_kp(c->dc, c->st, kp, owner, n_rows, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
+int mmw_set_keypoints_uid(mmw_ctx *c, const float *kp, const int32_t *owner, const int32_t *uid, int32_t n_rows)
+{
+    if (!c || (n_rows > 0 && (!kp || !owner || !uid)) || n_rows < 0) return fail(c, MMW_E_ARG, "mmw_set_keypoints_uid: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_set_kp_uid(c->dc, c->st, kp, owner, uid, n_rows, c->stream);
     HIPCHK(c, hipGetLastError());
     return MMW_OK;
 }

@@ -102,6 +102,8 @@ struct DevState {
 // the kernels themselves.
 constexpr int kStatSlots = 256;
 constexpr int kStatWords = 32;
+constexpr int kStatFeatBytes = 30;  // k_features: algorithmic bytes (mmw_stats_get_ext)
+constexpr int kStatFeatRows = 31;   // k_features: feature tensors written
 __device__ inline unsigned long long *stats_slot(const DevState &st, int scene)
 {
     return st.stats ? st.stats + (size_t)(scene & (kStatSlots - 1)) * kStatWords : nullptr;

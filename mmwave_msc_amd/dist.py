@@ -13,15 +13,9 @@ import torch
 import torch.distributed as dist
 
 from ._lib import SUMMARY_DTYPE
+from .shard import shard_range  # noqa: F401  (re-exported)
 
 SUMMARY_WORDS = SUMMARY_DTYPE.itemsize // 4
-
-
-def shard_range(n_total: int, rank: int, world: int):
-    """Contiguous block [lo, hi) of the global scene ids owned by `rank` (sizes differ by <= 1)."""
-    base, rem = divmod(int(n_total), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
 
 
 def summaries_to_tensor(table: np.ndarray, device="cpu") -> torch.Tensor:

@@ -1,0 +1,97 @@
+"""`TrackBuffer.estimate_posture` (reference Tracking.py:705-734) for every scene of a
+`SceneBatch`, every frame, pipelined one frame behind the tracker.
+
+The reference calls `estimate_posture(model)` right after `track()` (offline_main.py:57-60):
+features of the eligible tracks -> `model.predict` -> `track.keypoints`.  Batched over
+thousands of scenes the CNN (matrix cores) takes ~15x the tracker (vector ALUs / LDS), and
+the two do not compete for the same units, so frame f's CNN runs on a second stream while
+frame f+1 is tracked:
+
+    tracker stream A:  step(f) feat(f) | wait cnn(f-1) scatter(f-1) | step(f+1) feat(f+1) | ...
+    CNN stream     B:                  wait feat(f-1)  cnn(f-1)     | wait feat(f) cnn(f) | ...
+
+* `mmw_features_async` leaves the row count in pinned host memory; the host waits for THAT
+  copy only (it completed a frame ago), so the GEMMs get their exact batch size and the GPU
+  never drains.
+* The scatter of frame f-1 runs after frame f was tracked, when list positions may have moved
+  (`_maintain_tracks`), so it matches tracks by creation ordinal (`mmw_set_keypoints_uid`);
+  it runs on the TRACKER stream, so it cannot race a spawn re-using a record.
+* The tracker never reads keypoints, so after `drain()` every live track holds exactly what the
+  frame-by-frame reference loop would have left in it.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import NKP
+
+
+class PosturePipeline:
+    def __init__(self, sb, model, cap_rows: int, tracker_stream=None, cnn_stream=None, overlap: bool = True, time_cnn: bool = False):
+        self.sb, self.model, self.cap = sb, model, int(cap_rows)
+        self.dev = torch.device("cuda", sb.device)
+        self.A = tracker_stream if tracker_stream is not None else torch.cuda.Stream(device=self.dev)
+        self.B = (cnn_stream if cnn_stream is not None else torch.cuda.Stream(device=self.dev)) if overlap else self.A
+        sb.follow_torch_stream(self.A)
+        shape = (self.cap, sb.ring, 8, 8, 5) if sb.ring > 1 else (self.cap, 8, 8, 5)
+        with torch.cuda.stream(self.A):
+            self.feat = [torch.zeros(shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
+            self.owner = [torch.zeros((self.cap, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
+            self.uid = [torch.zeros((self.cap,), dtype=torch.int32, device=self.dev) for _ in range(2)]
+            self.kp = [torch.zeros((self.cap, NKP), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.A.synchronize()
+        self.ev_feat = [torch.cuda.Event() for _ in range(2)]
+        self.ev_cnn = [torch.cuda.Event() for _ in range(2)]
+        self.time_cnn = bool(time_cnn)
+        self._cnn_pairs = []       # (start, stop) timing events around model() on the CNN stream
+        self.f = 0                 # frames submitted
+        self.rows = [0, 0]
+        self.rows_total = 0        # feature tensors pushed through the CNN since construction / reset_counters()
+
+    def reset_counters(self):
+        self.rows_total = 0
+        self._cnn_pairs = []
+
+    def cnn_ms(self):
+        """Mean device time of model() per frame since reset_counters() (None unless time_cnn); synchronises."""
+        if not self._cnn_pairs:
+            return None
+        self.B.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._cnn_pairs) / len(self._cnn_pairs)
+
+    def _finish(self, d: int):
+        """CNN + scatter of the frame whose features sit in buffer d."""
+        n = self.sb.features_wait(ticket=d)
+        self.rows[d] = n
+        self.rows_total += n
+        if n == 0:
+            return
+        with torch.cuda.stream(self.B), torch.no_grad():
+            self.B.wait_event(self.ev_feat[d])
+            if self.time_cnn:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                pair[0].record(self.B)
+            self.kp[d][:n].copy_(self.model(self.feat[d][:n]))
+            if self.time_cnn:
+                pair[1].record(self.B)
+                self._cnn_pairs.append(pair)
+            self.ev_cnn[d].record(self.B)
+        self.A.wait_event(self.ev_cnn[d])
+        self.sb.set_keypoints_uid_dev(self.kp[d].data_ptr(), self.owner[d].data_ptr(), self.uid[d].data_ptr(), n)
+
+    def after_step(self):
+        """Call once after every `sb.step_dev(...)` (issued on the tracker stream)."""
+        d = self.f & 1
+        self.sb.features_async(self.feat[d].data_ptr(), self.owner[d].data_ptr(), self.uid[d].data_ptr(), self.cap, ticket=d)
+        self.ev_feat[d].record(self.A)
+        if self.f > 0:
+            self._finish(d ^ 1)
+        self.f += 1
+
+    def drain(self):
+        """CNN + scatter of the last submitted frame; afterwards the keypoints are those of the reference loop."""
+        if self.f > 0:
+            self._finish((self.f - 1) & 1)
+        self.f = 0
+        self.A.synchronize()
+        self.B.synchronize()

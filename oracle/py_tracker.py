@@ -266,3 +266,59 @@ def run_batch_multiprocess(params_kw, pts, cnt, dts, procs):
             res = pool.map(_worker, jobs)
     el = time.perf_counter() - t0
     return el, [x for r in res for x in r]
+
+
+def _window_proc(idx, q, params_kw, frames, counts, dts, warm, barrier):
+    import time
+    try:  # one BLAS thread per process: the processes ARE the parallelism (numpy is already imported in the parent)
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    scenes = [PyScene(Params(**params_kw)) for _ in range(frames.shape[1])]
+
+    def run(f0, f1):
+        for s, sc in enumerate(scenes):
+            for f in range(f0, f1):
+                c = int(counts[f, s])
+                if c:
+                    sc.track(frames[f, s, :c].astype(np.float64), float(dts[f, s]))
+
+    try:
+        run(0, warm)
+        barrier.wait()
+        t0 = time.perf_counter()
+        run(warm, frames.shape[0])
+        t1 = time.perf_counter()
+        q.put((idx, t0, t1, [sc.n_tracks for sc in scenes]))
+    except BaseException as exc:  # a dead worker must not leave the others at the barrier
+        barrier.abort()
+        q.put((idx, None, None, repr(exc)))
+
+
+def run_window_multiprocess(params_kw, pts, cnt, dts, procs, warm):
+    """The bench's CPU baseline: scenes sharded evenly over `procs` processes (started, and the first `warm`
+    frames of every scene tracked, BEFORE the clock starts; a barrier lines the processes up), then frames
+    warm.. timed.  Wall = last finish - first start on the shared monotonic clock.  pts[F,S,N,8].
+    Returns (wall seconds, final track counts by scene)."""
+    import multiprocessing as mp
+
+    S = pts.shape[1]
+    procs = max(1, min(int(procs), S))
+    shards = [sh for sh in np.array_split(np.arange(S), procs) if len(sh)]
+    ctx = mp.get_context("fork")
+    barrier = ctx.Barrier(len(shards))
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_window_proc, args=(i, q, params_kw, pts[:, sh], cnt[:, sh], dts[:, sh], int(warm), barrier))
+          for i, sh in enumerate(shards)]
+    for p in ps:
+        p.start()
+    res = [q.get() for _ in ps]
+    for p in ps:
+        p.join()
+    bad = [r for r in res if r[1] is None]
+    if bad:
+        raise RuntimeError(f"cpu baseline worker failed: {bad[0][3]}")
+    res.sort(key=lambda r: r[0])
+    wall = max(r[2] for r in res) - min(r[1] for r in res)
+    return wall, [x for r in res for x in r[3]]

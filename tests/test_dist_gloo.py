@@ -66,3 +66,48 @@ def test_all_gather_track_tables_even_shards():
 
 def test_all_gather_track_tables_uneven_shards():
     _run(total=7, slots=3)
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # ONE JSON line on stdout, whatever the libraries print
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_its_ranks_strong_scaling():
+    """`python bench.py --gpus 2` without a launcher: two ranks are spawned before any GPU call, the 4096 scenes of
+    BASELINE configs[2] are sharded over them (strong scaling is the default), the gathered table is the global one."""
+    j = _bench("--gpus", "2", "--dry-run")
+    assert j["n_gpus"] == 2 and j["n_ranks_seen"] == 2 and j["scaling"] == "strong"
+    assert j["scenes_total"] == 4096 and j["scenes_rank0"] == 2048 and j["gathered_table_rows"] == 4096 and j["gather_ok"]
+
+
+def test_bench_weak_scaling_and_uneven_strong_shards():
+    j = _bench("--gpus", "2", "--dry-run", "--scaling", "weak", "--scenes", "6")
+    assert j["scenes_total"] == 12 and j["scenes_rank0"] == 6 and j["gather_ok"]
+    j = _bench("--gpus", "3", "--dry-run", "--scenes", "10")
+    assert j["scenes_total"] == 10 and j["scenes_rank0"] == 4 and j["gathered_table_rows"] == 10 and j["gather_ok"]
+
+
+def test_bench_under_an_external_launcher_uses_the_given_ranks():
+    """The driver's form: torch.distributed.run sets RANK/WORLD_SIZE/MASTER_*; bench.py must not spawn again."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--scenes", "64"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = [json.loads(ln) for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(js) == 1 and js[0]["n_ranks_seen"] == 2 and js[0]["scenes_rank0"] == 32 and js[0]["gather_ok"]

@@ -1,0 +1,198 @@
+"""GPU tests of the end-to-end path (BASELINE.json configs[3]) and of the N > 1 exchange step on real contexts:
+
+* track -> features -> MARS CNN -> keypoints every frame for 256 scenes x 256 points x 4 tracks, pipelined on two
+  streams (mmwave_msc_amd/posture.py), against the C oracle's tracker / feature map and the fp64 numpy CNN;
+* the pipelined loop against the plain, frame-synchronous one (same final keypoints);
+* `mmw_features_async` / `mmw_set_keypoints_uid` after the track list has been re-ordered;
+* two ranks, two contexts: `mmw_track_table` with `scene_base`, gathered, equals the table of one context over all scenes.
+
+CNN oracle = oracle/mars_np.py: parity unpinned against Keras (absent from the image); tolerance 1e-4."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KP_TOL = 1e-4
+
+
+def test_e2e_256_scenes_every_frame_vs_oracle():
+    import bench_e2e
+    ref = bench_e2e.oracle_reference(workers=4)
+    assert ref["samples_cnn"] > 256  # most scenes hold tracks with keypoints from the CNN
+    res = bench_e2e.e2e_parity_leg(ref, 0)
+    assert res["tracker_state_bit_equal_vs_oracle"], res
+    assert res["tracks_checked"] >= ref["samples_cnn"]
+    assert res["keypoint_max_err"] <= KP_TOL, res
+
+
+def _run_loop(sb, pts, cnt, dts, model, pipelined):
+    import torch
+    from mmwave_msc_amd.posture import PosturePipeline
+    dev = torch.device("cuda", 0)
+    F, S = cnt.shape
+    cap = S * sb.track_cap
+    pipe = PosturePipeline(sb, model, cap, overlap=pipelined)
+    with torch.cuda.stream(pipe.A):
+        d_pts = torch.from_numpy(pts).to(dev).double()
+        d_cnt = torch.from_numpy(cnt).to(dev)
+        d_dt = torch.from_numpy(dts).to(dev)
+    pipe.A.synchronize()
+    sb.reset()
+    if pipelined:
+        for f in range(F):
+            sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+            pipe.after_step()
+        pipe.drain()
+    else:  # the reference's order: estimate_posture completes before the next track()
+        for f in range(F):
+            sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+            feat, owner = sb.features_host()
+            if len(owner):
+                sb.set_keypoints_host(model.predict_numpy(feat), owner)
+    sb.check()
+    ntr = sb.num_tracks()
+    return ntr, sb.tracks(cap=max(int(ntr.max()), 1))
+
+
+def test_pipelined_posture_equals_frame_synchronous_loop():
+    """Tracks expire and the list is compacted while a frame's CNN is still in flight (presence gaps of > 3 s)."""
+    import torch
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.synth import make_scene
+    S, N, F = 24, 256, 48
+    ps, cs, ds = [], [], []
+    for s in range(S):
+        presence = np.ones((F, 3), dtype=bool)
+        presence[6 + (s % 5): 6 + (s % 5) + 34, s % 3] = False   # one target vanishes for 3.4 s: its track expires mid-run
+        p, c, d = make_scene(700 + s, F, N, 3, ragged=(s % 2 == 0), presence=presence)
+        ps.append(p); cs.append(c); ds.append(d)
+    pts, cnt, dts = np.stack(ps, 1), np.stack(cs, 1), np.stack(ds, 1)
+    model = MarsCNN.from_keras_weights(random_keras_weights(3, 3)).to("cuda:0")
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=4), S, N, device=0)
+    n1, t1 = _run_loop(sb, pts, cnt, dts, model, pipelined=True)
+    n2, t2 = _run_loop(sb, pts, cnt, dts, model, pipelined=False)
+    assert np.array_equal(n1, n2) and int(n1.sum()) > S
+    uids1 = [set(t1[s, : n1[s]]["uid"]) for s in range(S)]
+    assert any(max(u) >= 3 for u in uids1 if u), "no scene re-spawned a track: the scenario does not exercise list compaction"
+    for s in range(S):
+        a, b = t1[s, : n1[s]], t2[s, : n2[s]]
+        assert np.array_equal(a["uid"], b["uid"]) and np.array_equal(a["x"], b["x"])
+        assert np.allclose(a["keypoints"], b["keypoints"], rtol=0, atol=1e-6), s
+    sb.close()
+    torch.cuda.synchronize()
+
+
+def test_features_async_tickets_and_uid_scatter():
+    import torch
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.synth import make_batch
+    S, N, F = 6, 256, 6
+    pts, cnt, dts = make_batch(range(50, 50 + S), F, N, 3)
+    sb = SceneBatch(_lib.default_config(), S, N, device=0)
+    for f in range(F):
+        sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    feat_h, owner_h = sb.features_host()
+    cap = S * sb.track_cap
+    dev = torch.device("cuda", 0)
+    feat = torch.zeros((cap, 3, 8, 8, 5), dtype=torch.float32, device=dev)
+    owner = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+    uid = torch.full((cap,), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for ticket in (0, 1, 2):
+        sb.features_async(feat.data_ptr(), owner.data_ptr(), uid.data_ptr(), cap, ticket=ticket)
+    rows = [sb.features_wait(t) for t in (2, 0, 1)]
+    assert rows == [len(owner_h)] * 3
+    sb.synchronize()
+    n = rows[0]
+    assert np.array_equal(feat[:n].cpu().numpy(), feat_h) and np.array_equal(owner[:n].cpu().numpy(), owner_h)
+    trk = sb.tracks()
+    want_uid = np.array([trk[s, j]["uid"] for s, j in owner_h])
+    assert np.array_equal(uid[:n].cpu().numpy(), want_uid)
+    # rows in reverse order, one row for a uid that does not exist: matched by (scene, uid), the stranger is dropped
+    kp = torch.arange(n * 57, dtype=torch.float32, device=dev).reshape(n, 57)
+    perm = torch.arange(n - 1, -1, -1, device=dev)
+    kp_p, owner_p, uid_p = kp[perm].contiguous(), owner[:n][perm].contiguous(), uid[:n][perm].contiguous()
+    owner_p[:, 1] = 63  # the list position is not what the uid form looks at
+    uid_bad = uid_p.clone()
+    uid_bad[0] = 999
+    torch.cuda.synchronize()
+    before = sb.tracks()
+    sb.set_keypoints_uid_dev(kp_p.data_ptr(), owner_p.data_ptr(), uid_bad.data_ptr(), n)
+    sb.synchronize()
+    after = sb.tracks()
+    kp_h = kp.cpu().numpy()
+    for i, (s, j) in enumerate(owner_h):
+        if i == n - 1:   # its row carried the unknown uid
+            assert np.array_equal(after[s, j]["keypoints"], before[s, j]["keypoints"])
+        else:
+            assert np.array_equal(after[s, j]["keypoints"], kp_h[i])
+    with pytest.raises(_lib.MmwError):
+        sb.features_async(feat.data_ptr(), owner.data_ptr(), uid.data_ptr(), 1, ticket=0)
+        sb.features_wait(0)   # cap_rows too small -> MMW_E_CAPACITY, as mmw_features
+    sb.close()
+
+
+# ---- N > 1 on real contexts ------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, total, n_pts, frames, slots, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.dist import all_gather_tables, shard_range, summaries_to_tensor, tensor_to_summaries
+    from mmwave_msc_amd.synth import make_batch
+    lo, hi = shard_range(total, rank, world)
+    pts, cnt, dts = make_batch(range(300 + lo, 300 + hi), frames, n_pts, 3)
+    sb = SceneBatch(_lib.default_config(), hi - lo, n_pts, device=0)   # both ranks share the one GPU of the box
+    for f in range(frames):
+        sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    local = sb.track_table_host(slots, scene_base=lo)
+    glob = tensor_to_summaries(all_gather_tables(summaries_to_tensor(local)), slots)
+    sb.close()
+    q.put((rank, glob))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_two_contexts_track_table_gather():
+    import torch.multiprocessing as mp
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.synth import make_batch
+    total, n_pts, frames, slots = 7, 256, 6, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, total, n_pts, frames, slots, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # one context over all scenes = what the gathered table must equal, row for row
+    pts, cnt, dts = make_batch(range(300, 300 + total), frames, n_pts, 3)
+    sb = SceneBatch(_lib.default_config(), total, n_pts, device=0)
+    for f in range(frames):
+        sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    want = sb.track_table_host(slots, scene_base=0)
+    sb.close()
+    assert want.dtype == _lib.SUMMARY_DTYPE and int(want["alive"].sum()) >= total
+    for r in (0, 1):
+        got = res[r]
+        assert got.shape == (total, slots)
+        assert np.array_equal(got["scene"], np.repeat(np.arange(total)[:, None], slots, 1))
+        assert np.array_equal(got["slot"], np.repeat(np.arange(slots)[None, :], total, 0))
+        for name in want.dtype.names:
+            assert np.array_equal(got[name], want[name]), name
