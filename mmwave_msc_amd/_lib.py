@@ -46,6 +46,7 @@ class MmwConfig(C.Structure):
         ("kf_spread_lim", C.c_double * 6), ("kf_a_spr", C.c_double), ("intensity_mu", C.c_double),
         ("intensity_std", C.c_double), ("s_height", C.c_double), ("tilt_cos", C.c_double), ("tilt_sin", C.c_double),
         ("default_posture", C.c_float * NKP),
+        ("kalman_dense_min_units", C.c_int32), ("seek_inner", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

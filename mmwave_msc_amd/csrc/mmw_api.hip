@@ -169,7 +169,7 @@ int mmw_config_default(mmw_config *c)
         0.0786f, -0.0056f, 0.0346f, -0.0007f, 0.0683f, -0.0082f, 0.0312f};
     memset(c, 0, sizeof(*c));
     c->fb_frames_batch = 2; c->db_min_samples = 35; c->tr_max_tracks = 4; c->kf_enable_est = 0;
-    c->model_min_input = 0; c->dim_x = 9; c->ring_rows = 64; c->track_cap = 0;
+    c->model_min_input = 0; c->dim_x = 9; c->ring_rows = 64; c->track_cap = 0; c->kalman_dense_min_units = 0;
     c->db_z_weight = 0.4; c->db_range_weight = 0.03; c->db_eps = 0.3;
     c->tr_lifetime_dynamic = 3; c->tr_lifetime_static = 7; c->tr_vel_thres = 0.12; c->tr_gate = 4.5;
     c->kf_q_std = 1; c->kf_p_init = 0.1; c->kf_group_disp_est_init = 0.1; c->kf_a_n = 0.9; c->kf_est_pointnum = 10;
@@ -199,9 +199,12 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (!c) return fail(nullptr, MMW_E_ARG, "out of host memory");
     c->cfg = *cfg;
     c->device = device;
-    HIPCHK(nullptr, hipSetDevice(device));
     hipDeviceProp_t prop;
-    HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+    {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess) { delete c; return fail(nullptr, MMW_E_HIP, "hipSetDevice / hipGetDeviceProperties(%d) -> %s", device, hipGetErrorString(e)); }
+    }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return fail(nullptr, MMW_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName); }
     DevCfg &d = c->dc;
     memset(&d, 0, sizeof(d));
@@ -216,11 +219,10 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (cap > MMW_TRACK_CAP_LIMIT) cap = MMW_TRACK_CAP_LIMIT;
     if (cap < 1) cap = 1;
     d.t_cap = cap; d.max_pts = max_pts; d.n_scenes = n_scenes;
-    {
-        const char *e = getenv("MMW_DENSE_MIN_UNITS");  // test hook: layout of the Kalman kernels, see tracks_dense()
-        d.dense_min_units = e ? atoi(e) : 1024;
-        d.pad0 = 0;
-    }
+    // layout of the Kalman kernels (mmw_kalman.hpp: tracks_dense): laid out over tracks when the context holds more
+    // four-track waves than this; 0 = the default threshold (one wave per CU x 4), < 0 = always per scene
+    d.dense_min_units = cfg->kalman_dense_min_units == 0 ? 1024 : (cfg->kalman_dense_min_units < 0 ? 0x7fffffff : cfg->kalman_dense_min_units - 1);
+    d.pad0 = 0;
     d.db_z_weight = cfg->db_z_weight; d.db_range_weight = cfg->db_range_weight; d.db_eps = cfg->db_eps;
     d.tr_lifetime_dynamic = cfg->tr_lifetime_dynamic; d.tr_lifetime_static = cfg->tr_lifetime_static;
     d.tr_vel_thres = cfg->tr_vel_thres; d.tr_gate = cfg->tr_gate; d.kf_q_std = cfg->kf_q_std; d.kf_p_init = cfg->kf_p_init;
@@ -326,6 +328,7 @@ int mmw_pop_frame(mmw_ctx *c, const int32_t *scene_flags)
 int mmw_set_stream(mmw_ctx *c, void *s)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     hipStreamSynchronize(c->stream);
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return MMW_OK;
@@ -334,6 +337,7 @@ int mmw_set_stream(mmw_ctx *c, void *s)
 int mmw_synchronize(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
 }
@@ -359,12 +363,14 @@ int mmw_dev_alloc(mmw_ctx *c, size_t bytes, void **dptr)
 int mmw_dev_free(mmw_ctx *c, void *p)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     if (p) HIPCHK(c, hipFree(p));
     return MMW_OK;
 }
 int mmw_memcpy_h2d(mmw_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
@@ -372,6 +378,7 @@ int mmw_memcpy_h2d(mmw_ctx *c, void *dst, const void *src, size_t bytes)
 int mmw_memcpy_d2h(mmw_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
@@ -520,6 +527,7 @@ int mmw_set_keypoints_uid(mmw_ctx *c, const float *kp, const int32_t *owner, con
 
 static int read_headers(mmw_ctx *c, std::vector<SceneHdr> &h)
 {
+    HIPCHK(c, hipSetDevice(c->device));
     h.resize(c->dc.n_scenes);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->st.hdr, h.size() * sizeof(SceneHdr), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -588,6 +596,7 @@ int mmw_get_tracks(mmw_ctx *c, mmw_track_record *out, int32_t cap)
 int mmw_get_track_ring_frame(mmw_ctx *c, int32_t scene, int32_t track, int32_t k, double *out, int32_t *n_rows)
 {
     if (!c || !out || !n_rows || scene < 0 || scene >= c->dc.n_scenes) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     SceneHdr h;
     HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -610,6 +619,7 @@ int mmw_get_track_ring_frame(mmw_ctx *c, int32_t scene, int32_t track, int32_t k
 int mmw_get_batch_ring_frame(mmw_ctx *c, int32_t scene, int32_t k, double *out, int32_t *n_rows)
 {
     if (!c || !out || !n_rows || scene < 0 || scene >= c->dc.n_scenes) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     SceneHdr h;
     HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -646,6 +656,7 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
 // the device keeps kStatSlots partial copies of the counters (mmw_device.hpp); the totals are formed here
 static int read_stats(mmw_ctx *c, uint64_t *out, int words)
 {
+    HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint64_t> h((size_t)kStatSlots * kStatWords);
     HIPCHK(c, hipMemcpyAsync(h.data(), c->d_stats, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -732,6 +743,7 @@ int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[128]*/)
 int mmw_stats_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(uint64_t), c->stream));
     return MMW_OK;
 }
@@ -745,6 +757,7 @@ int mmw_profile_enable(mmw_ctx *c, int32_t on)
 int mmw_profile_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     hipStreamSynchronize(c->stream);
     prof_fold(c);
     for (int k = 0; k < MMW_K_COUNT; k++) { c->tot_ms[k] = 0; c->launches[k] = 0; }
@@ -753,6 +766,7 @@ int mmw_profile_reset(mmw_ctx *c)
 int mmw_profile_get(mmw_ctx *c, int32_t k, double *total_ms, int64_t *launches)
 {
     if (!c || k < 0 || k >= MMW_K_COUNT) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     hipStreamSynchronize(c->stream);
     prof_fold(c);
     if (total_ms) *total_ms = c->tot_ms[k];

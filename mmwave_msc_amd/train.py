@@ -8,7 +8,7 @@ size 128 with a validation set (28-30, 130-138), evaluated on a test split with 
 per-joint MAE/RMSE table in centimetres (140-232), and saved when the test MAE improves (244-254).
 
 This module is that loop on torch: `MarsTrainNet` is the model in training form (Keras semantics: glorot-uniform
-kernels, zero biases, BatchNorm epsilon 1e-3 and momentum 0.95 = torch momentum 0.05, channels-last Flatten
+kernels, zero biases, BatchNorm epsilon 1e-3, momentum 0.95 and biased moving variance, channels-last Flatten
 order), `fit` / `evaluate` / `paper_table` are the loop and its metrics, and `export_keras_weights` writes the
 tensors in Keras layouts -- exactly the `.npz` that `mmwave_msc_amd.mars.MarsCNN.from_npz` (the inference path
 `estimate_posture` uses) loads, so trained weights drop into the tracker without conversion.
@@ -32,6 +32,33 @@ EPOCHS = 150       # train.py:30
 KERAS_ADAM_EPS = 1e-7
 
 
+class KerasBatchNorm(nn.Module):
+    """Keras `BatchNormalization(momentum)` over channel axis 1: training normalises with the batch's mean and BIASED
+    variance and moves `moving_mean` / `moving_variance` towards exactly those (torch's BatchNorm accumulates the
+    unbiased variance instead, so its exported `running_var` would differ from a Keras-trained model's by n/(n-1))."""
+
+    def __init__(self, channels: int, eps: float = BN_EPS, keras_momentum: float = 0.95):
+        super().__init__()
+        self.eps, self.mom = float(eps), float(keras_momentum)
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        if self.training:
+            dims = [d for d in range(x.dim()) if d != 1]
+            mean = x.mean(dim=dims)
+            var = x.var(dim=dims, unbiased=False)
+            with torch.no_grad():
+                self.running_mean.mul_(self.mom).add_(mean.detach(), alpha=1.0 - self.mom)
+                self.running_var.mul_(self.mom).add_(var.detach(), alpha=1.0 - self.mom)
+        else:
+            mean, var = self.running_mean, self.running_var
+        return (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + self.eps) * self.weight.view(shape) + self.bias.view(shape)
+
+
 class MarsTrainNet(nn.Module):
     """define_CNN_3D (frames = 3, input (B,3,8,8,5)) or define_CNN (frames = 1, input (B,8,8,5)), trainable."""
 
@@ -40,14 +67,13 @@ class MarsTrainNet(nn.Module):
         self.frames = int(frames)
         self.three_d = self.frames > 1
         conv = nn.Conv3d if self.three_d else nn.Conv2d
-        bn = nn.BatchNorm3d if self.three_d else nn.BatchNorm2d
         self.conv1 = conv(5, 16, 3, padding=1)
         self.conv2 = conv(16, 32, 3, padding=1)
-        self.bn1 = bn(32, eps=BN_EPS, momentum=0.05)      # Keras momentum 0.95 (train.py:45,83)
+        self.bn1 = KerasBatchNorm(32, BN_EPS, 0.95)          # train.py:45,83
         flat = (self.frames if self.three_d else 1) * 64 * 32
         hidden = 512 * (3 if self.three_d else 1)
         self.dense1 = nn.Linear(flat, hidden)
-        self.bn2 = nn.BatchNorm1d(hidden, eps=BN_EPS, momentum=0.05)
+        self.bn2 = KerasBatchNorm(hidden, BN_EPS, 0.95)
         self.dense2 = nn.Linear(hidden, n_keypoints)
         for m in (self.conv1, self.conv2, self.dense1, self.dense2):  # Keras defaults: glorot_uniform, zeros
             nn.init.xavier_uniform_(m.weight)
@@ -172,25 +198,33 @@ def main(argv=None) -> int:
     ap.add_argument("--out", default="model/MARS.npz")
     ap.add_argument("--epochs", type=int, default=EPOCHS)
     ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
-    ap.add_argument("--runs", type=int, default=1, help="the reference repeats the fit 10 times and keeps the best test MAE")
+    ap.add_argument("--folds", type=int, default=0,
+                    help="the reference trains 10 dataset folds, formatted/mmWave/{i} and formatted/kinect/{i} (train.py:110-124): with "
+                         "--folds K, --features and --labels name the parents of the sub-directories 0..K-1; 0 = the two directories themselves")
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     a = ap.parse_args(argv)
     ld = lambda d, f: np.load(os.path.join(d, f))
-    xtr, xva, xte = ld(a.features, "training_mmWave.npy"), ld(a.features, "validate_mmWave.npy"), ld(a.features, "testing_mmWave.npy")
-    ytr, yva, yte = ld(a.labels, "training_labels.npy"), ld(a.labels, "validate_labels.npy"), ld(a.labels, "testing_labels.npy")
-    frames = xtr.shape[1] if xtr.ndim == 5 else 1
-    best = None
-    for run in range(a.runs):
+    tables = []
+    for fold in range(max(a.folds, 1)):
+        fdir = os.path.join(a.features, str(fold)) if a.folds > 0 else a.features
+        ldir = os.path.join(a.labels, str(fold)) if a.folds > 0 else a.labels
+        xtr, xva, xte = ld(fdir, "training_mmWave.npy"), ld(fdir, "validate_mmWave.npy"), ld(fdir, "testing_mmWave.npy")
+        ytr, yva, yte = ld(ldir, "training_labels.npy"), ld(ldir, "validate_labels.npy"), ld(ldir, "testing_labels.npy")
+        frames = xtr.shape[1] if xtr.ndim == 5 else 1
         net = MarsTrainNet(frames, ytr.shape[1])
-        fit(net, xtr, ytr, xva, yva, a.batch_size, a.epochs, a.device, seed=run, verbose=True)
+        score_min = 10.0   # train.py:128: re-set inside the loop, so EVERY fold whose test MAE is below 10 overwrites the file
+        fit(net, xtr, ytr, xva, yva, a.batch_size, a.epochs, a.device, seed=fold, verbose=True)
         tr, te = evaluate(net, xtr, ytr, a.device), evaluate(net, xte, yte, a.device)
         print("train MAPE = ", tr["mape"])
         print("test MAPE = ", te["mape"])
-        print(paper_table(yte, predict(net, xte, a.device)))
-        if best is None or te["mae"] < best:   # train.py:251-254
+        tables.append(paper_table(yte, predict(net, xte, a.device)))
+        print(tables[-1])
+        if te["mae"] < score_min:   # train.py:251-254
             os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
             save_npz(net, a.out)
-            best = te["mae"]
+            score_min = te["mae"]
+    if len(tables) > 1:   # train.py:257-258: the mean table over the folds
+        print(np.mean(tables, axis=0))
     return 0
 
 

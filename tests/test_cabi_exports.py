@@ -36,7 +36,7 @@ def test_config_struct_matches_header_layout():
     import numpy as np
     assert cfg.tilt_cos == float(np.cos(np.radians(-5))) and cfg.tilt_sin == float(np.sin(np.radians(-5)))
     assert L.mmw_version().startswith(b"mmw-hip")
-    assert C.sizeof(_lib.MmwConfig) == 8 * 4 + 24 * 8 + 57 * 4 + 4  # 8 ints, 24 doubles, 57 floats, tail pad
+    assert C.sizeof(_lib.MmwConfig) == 8 * 4 + 24 * 8 + 57 * 4 + 3 * 4  # 8 ints, 24 doubles, 57 floats, 3 ints
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():

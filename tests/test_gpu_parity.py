@@ -15,16 +15,22 @@ from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_
 pytestmark = pytest.mark.gpu
 
 
+_LAYOUT = {"value": 0}
+
+
 @pytest.fixture(params=["per_scene", "track_wise"], autouse=True)
-def kalman_layout(request, monkeypatch):
+def kalman_layout(request):
     """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense): by default the
-    track-wise one is only chosen for contexts with more than 1024 four-track waves."""
-    monkeypatch.setenv("MMW_DENSE_MIN_UNITS", "1000000000" if request.param == "per_scene" else "0")
+    track-wise one is only chosen for contexts with more than 1024 four-track waves (mmw_config.kalman_dense_min_units)."""
+    _LAYOUT["value"] = -1 if request.param == "per_scene" else 1
+    yield
+    _LAYOUT["value"] = 0
 
 
 def _mk(n_scenes, max_pts, **kw):
     from mmwave_msc_amd import _lib
     from mmwave_msc_amd.batch import SceneBatch
+    kw.setdefault("kalman_dense_min_units", _LAYOUT["value"])
     return SceneBatch(_lib.default_config(**kw), n_scenes, max_pts)
 
 

@@ -54,7 +54,7 @@ def test_fit_reduces_loss_and_reports_history():
 def test_keras_semantics_of_the_model():
     net = T.MarsTrainNet(3)
     assert net.bn1.eps == 1e-3 and net.bn2.eps == 1e-3
-    assert abs(net.bn1.momentum - 0.05) < 1e-12      # Keras momentum 0.95 (train.py:83,88)
+    assert net.bn1.mom == 0.95 and net.bn2.mom == 0.95   # Keras momentum (train.py:83,88)
     assert float(net.conv1.bias.detach().abs().sum()) == 0.0  # zeros initialiser
     lim = np.sqrt(6.0 / (27 * 5 + 27 * 16))          # glorot_uniform bound of conv1
     assert float(net.conv1.weight.detach().abs().max()) <= lim + 1e-6
@@ -89,3 +89,24 @@ def test_cli_round_trip(tmp_path):
     assert T.main(["--features", str(f), "--labels", str(l), "--out", str(out), "--epochs", "1", "--batch-size", "32", "--device", "cpu"]) == 0
     m = MarsCNN.from_npz(str(out))
     assert m.predict(np.zeros((2, 3, 8, 8, 5), np.float32)).shape == (2, 57)
+
+
+def test_batchnorm_moving_statistics_follow_keras():
+    """Keras: moving = moving * momentum + batch * (1 - momentum), with the BIASED batch variance (torch's own BatchNorm
+    accumulates the unbiased one); inference uses gamma * (x - mean) / sqrt(var + 1e-3) + beta."""
+    import torch
+    from mmwave_msc_amd import train as T
+    torch.manual_seed(0)
+    bn = T.KerasBatchNorm(4, 1e-3, 0.95)
+    x1, x2 = torch.randn(6, 4, 3, 2, 2) * 2 + 1, torch.randn(5, 4, 3, 2, 2) - 3
+    bn.train()
+    y1 = bn(x1)
+    m1, v1 = x1.transpose(0, 1).reshape(4, -1).mean(1), x1.transpose(0, 1).reshape(4, -1).var(1, unbiased=False)
+    assert torch.allclose(y1, (x1 - m1.view(1, 4, 1, 1, 1)) / torch.sqrt(v1.view(1, 4, 1, 1, 1) + 1e-3), atol=1e-5)
+    bn(x2)
+    m2, v2 = x2.transpose(0, 1).reshape(4, -1).mean(1), x2.transpose(0, 1).reshape(4, -1).var(1, unbiased=False)
+    assert torch.allclose(bn.running_mean, (0.0 * 0.95 + 0.05 * m1) * 0.95 + 0.05 * m2, atol=1e-6)
+    assert torch.allclose(bn.running_var, (1.0 * 0.95 + 0.05 * v1) * 0.95 + 0.05 * v2, atol=1e-6)
+    bn.eval()
+    z = bn(x1)
+    assert torch.allclose(z, (x1 - bn.running_mean.view(1, 4, 1, 1, 1)) / torch.sqrt(bn.running_var.view(1, 4, 1, 1, 1) + 1e-3), atol=1e-5)
