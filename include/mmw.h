@@ -81,7 +81,15 @@ typedef struct mmw_config {
                                        tracks from n waves on (tests run both layouts) */
     int32_t seek_inner;             /* 0 = Tracking.py:656 stays commented out (the reference as shipped); 1 = run
                                        ClusterTrack.seek_inner_clusters (Tracking.py:409-448) after every associate_pointcloud */
+    int32_t db_points_thres;        /* DB_POINTS_THRES :76   (seek_inner_clusters) */
+    int32_t fb_frames_batch_static; /* FB_FRAMES_BATCH_STATIC :67 */
     int32_t reserved0;
+    double db_spread_thres;         /* DB_SPREAD_THRES :77 */
+    double db_inner_eps;            /* DB_INNER_EPS :78 */
+    double m_x, m_y, m_z;           /* M_X, M_Y, M_Z :31-33  monitoring point (calc_projection_points, Utils.py:180-219) */
+    double v_screen_fade_size_max;  /* V_SCREEN_FADE_SIZE_MAX :48 */
+    double v_screen_fade_size_min;  /* V_SCREEN_FADE_SIZE_MIN :49 */
+    double v_screen_fade_weight;    /* V_SCREEN_FADE_WEIGHT :50 */
 } mmw_config;
 
 /* One entry of TrackBuffer.effective_tracks (Tracking.py:139-230), flattened:
@@ -117,6 +125,11 @@ typedef struct mmw_track_summary {
     float x[9];
     float centroid[6];
     float keypoints[MMW_NKP];
+    /* the output step after the path, fused into the table kernel: Visualizer.calc_fade_square (Visualizer.py:14-29)
+     * = Utils.calc_projection_points (Utils.py:180-219) of the head keypoint (x index 3, y index 41, z index 22)
+     * relative to the track position onto the screen plane y = 0, and the side of the faded square (shrinks with
+     * range, clamped to [V_SCREEN_FADE_SIZE_MIN, V_SCREEN_FADE_SIZE_MAX]).  fp64 arithmetic, rounded once. */
+    float fade_x, fade_z, fade_size;
 } mmw_track_summary;
 
 typedef struct mmw_ctx mmw_ctx;

@@ -46,7 +46,11 @@ class MmwConfig(C.Structure):
         ("kf_spread_lim", C.c_double * 6), ("kf_a_spr", C.c_double), ("intensity_mu", C.c_double),
         ("intensity_std", C.c_double), ("s_height", C.c_double), ("tilt_cos", C.c_double), ("tilt_sin", C.c_double),
         ("default_posture", C.c_float * NKP),
-        ("kalman_dense_min_units", C.c_int32), ("seek_inner", C.c_int32), ("reserved0", C.c_int32),
+        ("kalman_dense_min_units", C.c_int32), ("seek_inner", C.c_int32), ("db_points_thres", C.c_int32),
+        ("fb_frames_batch_static", C.c_int32), ("reserved0", C.c_int32),
+        ("db_spread_thres", C.c_double), ("db_inner_eps", C.c_double),
+        ("m_x", C.c_double), ("m_y", C.c_double), ("m_z", C.c_double),
+        ("v_screen_fade_size_max", C.c_double), ("v_screen_fade_size_min", C.c_double), ("v_screen_fade_weight", C.c_double),
     ]
 
 
@@ -61,7 +65,8 @@ TRACK_DTYPE = np.dtype(
 )
 SUMMARY_DTYPE = np.dtype(
     [("scene", "i4"), ("slot", "i4"), ("alive", "i4"), ("is_static", "i4"), ("point_num", "i4"),
-     ("lifetime", "f4"), ("x", "f4", (9,)), ("centroid", "f4", (6,)), ("keypoints", "f4", (NKP,))],
+     ("lifetime", "f4"), ("x", "f4", (9,)), ("centroid", "f4", (6,)), ("keypoints", "f4", (NKP,)),
+     ("fade_x", "f4"), ("fade_z", "f4"), ("fade_size", "f4")],
     align=True,
 )
 

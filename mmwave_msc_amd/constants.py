@@ -169,6 +169,11 @@ def to_config(**overrides) -> "_lib.MmwConfig":
         intensity_mu=float(g["INTENSITY_MU"]), intensity_std=float(g["INTENSITY_STD"]),
         s_height=float(g["S_HEIGHT"]), s_tilt=float(g["S_TILT"]),
         default_posture=[float(v) for v in np.asarray(g["MODEL_DEFAULT_POSTURE"], dtype=np.float32)],
+        db_points_thres=int(g["DB_POINTS_THRES"]), fb_frames_batch_static=int(g["FB_FRAMES_BATCH_STATIC"]),
+        db_spread_thres=float(g["DB_SPREAD_THRES"]), db_inner_eps=float(g["DB_INNER_EPS"]),
+        m_x=float(g["M_X"]), m_y=float(g["M_Y"]), m_z=float(g["M_Z"]),
+        v_screen_fade_size_max=float(g["V_SCREEN_FADE_SIZE_MAX"]), v_screen_fade_size_min=float(g["V_SCREEN_FADE_SIZE_MIN"]),
+        v_screen_fade_weight=float(g["V_SCREEN_FADE_WEIGHT"]),
     )
     kw.update(overrides)
     return _lib.default_config(**kw)

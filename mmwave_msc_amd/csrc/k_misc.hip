@@ -292,6 +292,20 @@ __global__ void k_table(DevCfg cfg, DevState st, mmw_track_summary *__restrict__
     for (int e = 0; e < 9; e++) o->x[e] = (alive && e < cfg.dx) ? (float)rec->x[e] : 0.f;
     for (int e = 0; e < 6; e++) o->centroid[e] = alive ? (float)rec->centroid[e] : 0.f;
     for (int e = 0; e < MMW_NKP; e++) o->keypoints[e] = alive ? rec->kp[e] : 0.f;
+    // calc_fade_square (Visualizer.py:14-29) over calc_projection_points (Utils.py:180-219), in the reference's
+    // operation order, fp64 with the float32 keypoints widened (numpy 1.26, the reference's pinned version)
+    double px = 0, pz = 0, size = 0;
+    if (alive) {
+        const double xo = rec->x[0] + (double)rec->kp[3], yo = rec->x[1] + (double)rec->kp[41], zo = (double)rec->kp[22];
+        const double xd = xo - cfg.m_x, yd = yo - cfg.m_y, zd = zo - cfg.m_z;
+        px = xd == 0 ? xo : -cfg.m_y / (yd / xd) + cfg.m_x;
+        pz = zd == 0 ? zo : -cfg.m_y / (yd / zd) + cfg.m_z;
+        const double sz = cfg.fade_max - (rec->x[1] + (double)rec->kp[12]) * cfg.fade_weight;
+        size = fmax(cfg.fade_min, fmin(cfg.fade_max, sz));
+    }
+    o->fade_x = (float)px;
+    o->fade_z = (float)pz;
+    o->fade_size = (float)size;
 }
 
 __global__ void k_reset(DevCfg cfg, DevState st)

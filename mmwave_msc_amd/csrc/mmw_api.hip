@@ -170,6 +170,9 @@ int mmw_config_default(mmw_config *c)
     memset(c, 0, sizeof(*c));
     c->fb_frames_batch = 2; c->db_min_samples = 35; c->tr_max_tracks = 4; c->kf_enable_est = 0;
     c->model_min_input = 0; c->dim_x = 9; c->ring_rows = 64; c->track_cap = 0; c->kalman_dense_min_units = 0;
+    c->seek_inner = 0; c->db_points_thres = 40; c->fb_frames_batch_static = 2; c->db_spread_thres = 0.7; c->db_inner_eps = 0.1;
+    c->m_x = 0.32; c->m_y = -0.6; c->m_z = 1.3;
+    c->v_screen_fade_size_max = 0.3; c->v_screen_fade_size_min = 0.2; c->v_screen_fade_weight = 0.08;
     c->db_z_weight = 0.4; c->db_range_weight = 0.03; c->db_eps = 0.3;
     c->tr_lifetime_dynamic = 3; c->tr_lifetime_static = 7; c->tr_vel_thres = 0.12; c->tr_gate = 4.5;
     c->kf_q_std = 1; c->kf_p_init = 0.1; c->kf_group_disp_est_init = 0.1; c->kf_a_n = 0.9; c->kf_est_pointnum = 10;
@@ -230,6 +233,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     for (int i = 0; i < 6; i++) d.kf_spread_lim[i] = cfg->kf_spread_lim[i];
     d.kf_a_spr = cfg->kf_a_spr; d.intensity_mu = cfg->intensity_mu; d.intensity_std = cfg->intensity_std;
     d.s_height = cfg->s_height; d.tilt_cos = cfg->tilt_cos; d.tilt_sin = cfg->tilt_sin;
+    d.m_x = cfg->m_x; d.m_y = cfg->m_y; d.m_z = cfg->m_z;
+    d.fade_max = cfg->v_screen_fade_size_max; d.fade_min = cfg->v_screen_fade_size_min; d.fade_weight = cfg->v_screen_fade_weight;
     c->UM = ring * max_pts;
 
 #define ALLOC(ptr, bytes)                                                                                   \

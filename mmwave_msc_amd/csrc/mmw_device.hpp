@@ -40,6 +40,7 @@ struct DevCfg {
     double kf_a_spr;
     double intensity_mu, intensity_std;
     double s_height, tilt_cos, tilt_sin;
+    double m_x, m_y, m_z, fade_max, fade_min, fade_weight;   // output step (k_table)
 };
 
 // 64 B header per scene

@@ -36,7 +36,7 @@ def test_config_struct_matches_header_layout():
     import numpy as np
     assert cfg.tilt_cos == float(np.cos(np.radians(-5))) and cfg.tilt_sin == float(np.sin(np.radians(-5)))
     assert L.mmw_version().startswith(b"mmw-hip")
-    assert C.sizeof(_lib.MmwConfig) == 8 * 4 + 24 * 8 + 57 * 4 + 3 * 4  # 8 ints, 24 doubles, 57 floats, 3 ints
+    assert C.sizeof(_lib.MmwConfig) == 8 * 4 + 24 * 8 + 57 * 4 + 5 * 4 + 8 * 8  # 8 ints, 24 doubles, 57 floats, 5 ints, 8 doubles
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():
@@ -55,7 +55,7 @@ def test_create_fails_loudly_without_gpu_or_with_bad_args():
 def test_track_record_dtype_matches_c_struct():
     # x9 P81 c6 mn6 mx6 sp6 gd36 n_est lifetime = 152 doubles; 8 ints; 57 floats (+pad to 8)
     assert _lib.TRACK_DTYPE.itemsize == 152 * 8 + 8 * 4 + 57 * 4 + 4
-    assert _lib.SUMMARY_DTYPE.itemsize == 5 * 4 + 4 + (9 + 6 + 57) * 4
+    assert _lib.SUMMARY_DTYPE.itemsize == 5 * 4 + 4 + (9 + 6 + 57) * 4 + 3 * 4
 
 
 def test_step_kernels_compile_without_scratch():

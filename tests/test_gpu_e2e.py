@@ -196,3 +196,49 @@ def test_two_ranks_two_contexts_track_table_gather():
         assert np.array_equal(got["slot"], np.repeat(np.arange(slots)[None, :], total, 0))
         for name in want.dtype.names:
             assert np.array_equal(got[name], want[name]), name
+
+
+def test_track_table_carries_the_fade_square_of_the_output_step():
+    """k_table's epilogue = Visualizer.calc_fade_square over Utils.calc_projection_points (Visualizer.py:14-29,
+    Utils.py:180-219): equal, after the one rounding to float32, to utils.fade_squares -- which tests/test_host_logic.py
+    pins bit-equal to values recorded from the reference's own functions -- on the fp64 state and the float32 keypoints."""
+    from mmwave_msc_amd import _lib, utils
+    from mmwave_msc_amd import constants as const
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.synth import make_batch
+    S, N, F, slots = 5, 256, 6, 4
+    pts, cnt, dts = make_batch(range(60, 60 + S), F, N, 3)
+    sb = SceneBatch(const.to_config(), S, N, device=0)
+    for f in range(F):
+        sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    _, owner = sb.features_host()
+    rng = np.random.default_rng(11)
+    kp = rng.normal(0, 0.5, size=(len(owner), 57)).astype(np.float32)
+    sb.set_keypoints_host(kp, owner)
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=slots)
+    tab = sb.track_table_host(slots)
+    assert int(ntr.sum()) == len(owner) >= S
+    for s in range(S):
+        for j in range(slots):
+            row = tab[s, j]
+            if j >= ntr[s]:
+                assert row["alive"] == 0 and row["fade_x"] == 0 and row["fade_z"] == 0 and row["fade_size"] == 0
+                continue
+            px, pz, size = utils.fade_squares(trk[s, j]["x"], trk[s, j]["keypoints"])
+            assert row["fade_x"] == np.float32(px) and row["fade_z"] == np.float32(pz) and row["fade_size"] == np.float32(size)
+            assert const.V_SCREEN_FADE_SIZE_MIN - 1e-7 <= row["fade_size"] <= const.V_SCREEN_FADE_SIZE_MAX + 1e-7
+    # other monitoring point / fade limits travel through mmw_config
+    sb2 = SceneBatch(const.to_config(m_x=-0.5, m_y=-1.25, m_z=0.9, v_screen_fade_size_max=0.5, v_screen_fade_weight=0.02), S, N, device=0)
+    for f in range(F):
+        sb2.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    sb2.set_keypoints_host(kp, owner)
+    tab2, trk2 = sb2.track_table_host(slots), sb2.tracks(cap=slots)
+    old = (const.M_X, const.M_Y, const.M_Z, const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_WEIGHT)
+    try:
+        const.M_X, const.M_Y, const.M_Z, const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_WEIGHT = -0.5, -1.25, 0.9, 0.5, 0.02
+        px, pz, size = utils.fade_squares(trk2[0, 0]["x"], trk2[0, 0]["keypoints"])
+    finally:
+        const.M_X, const.M_Y, const.M_Z, const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_WEIGHT = old
+    assert (tab2[0, 0]["fade_x"], tab2[0, 0]["fade_z"], tab2[0, 0]["fade_size"]) == (np.float32(px), np.float32(pz), np.float32(size))
+    sb.close(); sb2.close()
