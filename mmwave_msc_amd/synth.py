@@ -82,6 +82,41 @@ def make_scene(scene_id: int, n_frames: int, n_pts: int, n_targets: int,
     return pts32, counts, dt
 
 
+def make_pair_scene(scene_id: int, n_frames: int, n_pts: int, n_pairs: int = 1, sep: float = 0.8, static: bool = False):
+    """Scenes for `seek_inner_clusters` (reference Tracking.py:409-448): `n_pairs` pairs of people walking side by
+    side, `sep` metres apart -- one DBSCAN cluster at DB_EPS, two at DB_INNER_EPS -- plus 10 % uniform clutter.
+    `static` pairs stand still (cluster status STATIC).  Returns (points[F, n_pts, 8] float32, counts[F], dt[F])."""
+    rng = np.random.default_rng(int(scene_id))
+    f, k = int(n_frames), int(n_pairs)
+    per = int(0.45 * n_pts / k)
+    c0 = _place_targets(rng, k, min_sep=2.2)
+    vel = np.zeros((k, 2)) if static else rng.normal(0.0, 0.3, size=(k, 2))
+    out = np.zeros((f, n_pts, 8), dtype=np.float64)
+    for i in range(f):
+        row = 0
+        for p in range(k):
+            c = c0[p] + vel[p] * FRAME_DT * i
+            for off in (-sep / 2, sep / 2):
+                blk = out[i, row: row + per]
+                blk[:, 0] = c[0] + off + rng.normal(0.0, 0.08, per)
+                blk[:, 1] = c[1] + rng.normal(0.0, 0.08, per)
+                blk[:, 2] = rng.uniform(0.6, 1.4, per)
+                blk[:, 3:5] = vel[p] + rng.normal(0.0, 0.02 if static else 0.05, (per, 2))
+                blk[:, 5] = rng.normal(0.0, 0.02 if static else 0.05, per)
+                row += per
+        cl = out[i, row:]
+        m = n_pts - row
+        cl[:, 0] = rng.uniform(-3.0, 3.0, m)
+        cl[:, 1] = rng.uniform(0.2, 8.0, m)
+        cl[:, 2] = rng.uniform(0.05, 2.4, m)
+        cl[:, 3:6] = rng.normal(0.0, 0.05, (m, 3))
+        out[i, :, 6] = rng.normal(0.0, 0.3, n_pts)
+        out[i, :, 7] = rng.gamma(1.0, 30.0, n_pts)
+        out[i] = out[i][rng.permutation(n_pts)]
+    out[..., 1] = np.maximum(out[..., 1], 0.05)
+    return out.astype(np.float32), np.full(f, n_pts, dtype=np.int32), np.full(f, FRAME_DT, dtype=np.float64)
+
+
 def make_batch(scene_ids, n_frames: int, n_pts: int, n_targets: int, ragged: bool = False):
     """Stack scenes: points[F, S, n_pts, 8] float32, counts[F, S] int32, dt[F, S] float64."""
     ps, cs, ds = [], [], []

@@ -31,6 +31,7 @@ typedef struct {
     int32_t ring_n[ORC_RING_MAX];
     double *ring[ORC_RING_MAX]; /* each [ring_rows][8], oldest first */
     float keypoints[ORC_NKP];
+    int32_t ring_size;          /* track.batch.size: FB_FRAMES_BATCH + 1 until change_buffer_size (Tracking.py:60-64) */
 } trk_t;
 
 struct orc_scene {
@@ -48,6 +49,13 @@ struct orc_scene {
     double *cloud;   /* [ring*max_pts][8] */
     double *prod;    /* [ring*max_pts] */
     int32_t *tmp_i;
+    /* seek_inner_clusters of the last frame (cfg.seek_inner only) */
+    int inner_calls;
+    int32_t *inner_track, *inner_n;  /* [track_cap] */
+    int32_t *inner_labels;           /* [track_cap][ring*max_pts] */
+    double *inner_rows;              /* [track_cap][ring*max_pts][8]: the cluster a call returned (label 1) */
+    int32_t *inner_m;                /* [track_cap] its row count, 0 = none */
+    int overflow;                    /* a ring frame longer than ring_rows under seek_inner */
 };
 
 /* ------------------------------------------------------------------ */
@@ -163,6 +171,11 @@ void orc_config_default(orc_config *c)
         c->tilt_sin = sin(ang);
     }
     memcpy(c->default_posture, posture, sizeof(posture));
+    c->seek_inner = 0;
+    c->db_points_thres = 40;
+    c->fb_frames_batch_static = 2;
+    c->db_spread_thres = 0.7;
+    c->db_inner_eps = 0.1;
 }
 
 static int default_track_cap(const orc_config *c, int max_pts)
@@ -185,6 +198,9 @@ orc_scene *orc_scene_new(const orc_config *cfg, int max_pts)
     if (s->cfg.dim_x != 9 && s->cfg.dim_x != 6) { free(s); return NULL; }
     s->max_pts = max_pts;
     s->ring_size = s->cfg.fb_frames_batch + 1;
+    /* seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
+     * ring*max_pts rows: frames are stored whole (a longer one is a capacity error, not a truncation) */
+    if (s->cfg.seek_inner && s->cfg.ring_rows < s->ring_size * max_pts) s->cfg.ring_rows = s->ring_size * max_pts;
     if (s->cfg.track_cap <= 0) s->cfg.track_cap = default_track_cap(&s->cfg, max_pts);
     s->tracks = (trk_t *)calloc((size_t)s->cfg.track_cap, sizeof(trk_t));
     for (int t = 0; t < s->cfg.track_cap; t++)
@@ -196,6 +212,20 @@ orc_scene *orc_scene_new(const orc_config *cfg, int max_pts)
     s->cloud = (double *)calloc((size_t)s->ring_size * max_pts * 8, sizeof(double));
     s->prod = (double *)calloc((size_t)s->ring_size * max_pts + 8, sizeof(double));
     s->tmp_i = (int32_t *)calloc((size_t)s->ring_size * max_pts + 8, sizeof(int32_t));
+    if (s->cfg.seek_inner) {
+        const size_t cap = (size_t)s->cfg.track_cap, um = (size_t)s->ring_size * s->cfg.ring_rows;
+        if (s->cfg.fb_frames_batch < 1 || s->cfg.fb_frames_batch > s->ring_size ||
+            s->cfg.fb_frames_batch_static < 1 || s->cfg.fb_frames_batch_static > s->ring_size) {
+            /* the inner DBSCAN reads whole clouds from the track rings, and a ring of size 0 never terminates add_frame */
+            orc_scene_free(s);
+            return NULL;
+        }
+        s->inner_track = (int32_t *)calloc(cap, sizeof(int32_t));
+        s->inner_n = (int32_t *)calloc(cap, sizeof(int32_t));
+        s->inner_m = (int32_t *)calloc(cap, sizeof(int32_t));
+        s->inner_labels = (int32_t *)calloc(cap * um, sizeof(int32_t));
+        s->inner_rows = (double *)calloc(cap * um * 8, sizeof(double));
+    }
     orc_scene_reset(s);
     return s;
 }
@@ -207,6 +237,7 @@ void orc_scene_free(orc_scene *s)
         for (int k = 0; k < ORC_RING_MAX; k++) free(s->tracks[t].ring[k]);
     for (int k = 0; k < ORC_RING_MAX; k++) free(s->g_frame[k]);
     free(s->tracks); free(s->concat); free(s->cloud); free(s->prod); free(s->tmp_i);
+    free(s->inner_track); free(s->inner_n); free(s->inner_m); free(s->inner_labels); free(s->inner_rows);
     free(s);
 }
 
@@ -216,6 +247,8 @@ void orc_scene_reset(orc_scene *s)
 {
     s->n_tracks = 0;
     s->g_len = 1;
+    s->inner_calls = 0;
+    s->overflow = 0;
     memset(s->g_n, 0, sizeof(s->g_n));
 }
 
@@ -349,7 +382,8 @@ static void cluster_stats(const orc_config *c, trk_t *t, const double *rows, int
 static void track_ring_push(const orc_scene *s, trk_t *t, const double *rows, int n)
 {
     int keep = n < s->cfg.ring_rows ? n : s->cfg.ring_rows;
-    while (t->ring_len >= s->ring_size) {
+    if (s->cfg.seek_inner && n > s->cfg.ring_rows) ((orc_scene *)s)->overflow = 1;
+    while (t->ring_len >= t->ring_size) {
         double *first = t->ring[0];
         for (int k = 1; k < t->ring_len; k++) { t->ring[k - 1] = t->ring[k]; t->ring_n[k - 1] = t->ring_n[k]; }
         t->ring[t->ring_len - 1] = first;
@@ -371,6 +405,7 @@ static void track_init(const orc_scene *s, trk_t *t, const double *rows, int n)
     memcpy(t->ring, ring, sizeof(ring));
     cluster_stats(c, t, rows, n);
     t->ring_len = 0;
+    t->ring_size = s->ring_size;   /* a fresh BatchedData (Tracking.py:38-41) */
     track_ring_push(s, t, rows, n);
     for (int i = 0; i < 6; i++) t->x[i] = t->centroid[i];
     for (int i = 0; i < dx; i++) t->P[i * dx + i] = 1.0 * c->kf_p_init;
@@ -419,6 +454,44 @@ static int track_associate(orc_scene *s, trk_t *t, const double *rows, int n)
             }
     }
     return 0;
+}
+
+int orc_dbscan(const orc_config *cfg, const double *pts, int n, double eps, int min_samples, int32_t *labels);
+
+/* ClusterTrack.seek_inner_clusters Tracking.py:409-448, for the track at list position j whose associate_pointcloud
+ * has just run on `rows`.  Quirks kept: `spread.any() > DB_SPREAD_THRES` compares a bool (x-spread != 0) with the
+ * threshold; the cluster's cloud is added to the ring a second time; change_buffer_size is permanent;
+ * apply_DBscan is called with eps = DB_INNER_EPS and the DEFAULT min_samples (DB_INNER_MIN_SAMPLES is unused);
+ * only the cluster with label 1 is returned. */
+static void seek_inner(orc_scene *s, trk_t *t, int j, const double *rows, int n)
+{
+    const orc_config *c = &s->cfg;
+    const size_t um = (size_t)s->ring_size * s->cfg.ring_rows;
+    const double xspread = t->maxv[0] - t->minv[0];
+    const double any = (xspread != 0.0) ? 1.0 : 0.0;   /* numpy: bool(spread.any()) */
+    int k = s->inner_calls, U = 0, ncl;
+    double *cat;
+    int32_t *lab;
+    if (!(t->point_num > c->db_points_thres && any > c->db_spread_thres)) return;
+    t->ring_size = t->is_static ? c->fb_frames_batch_static : c->fb_frames_batch;
+    track_ring_push(s, t, rows, n);
+    cat = s->inner_rows + (size_t)k * um * 8;   /* effective_data, then overwritten by the returned cluster */
+    lab = s->inner_labels + (size_t)k * um;
+    for (int f = 0; f < t->ring_len; f++) {
+        memcpy(cat + (size_t)U * 8, t->ring[f], sizeof(double) * 8 * (size_t)t->ring_n[f]);
+        U += t->ring_n[f];
+    }
+    ncl = orc_dbscan(c, cat, U, c->db_inner_eps, c->db_min_samples, lab);
+    s->inner_track[k] = j;
+    s->inner_n[k] = U;
+    s->inner_m[k] = 0;
+    if (ncl > 1) {
+        int m = 0;
+        for (int i = 0; i < U; i++)
+            if (lab[i] == 1) { if (m != i) memcpy(cat + (size_t)m * 8, cat + (size_t)i * 8, 64); m++; }
+        s->inner_m[k] = m;
+    }
+    s->inner_calls = k + 1;
 }
 
 /* ClusterTrack.update_state Tracking.py:387-398 + filterpy update + _get_Rc 299-312 */
@@ -681,6 +754,7 @@ int orc_track_frame(orc_scene *s, const double *pts, int n, double dt, int32_t *
     int rc = 0;
     if (n > s->max_pts || n < 0) return -1;
     *db_n = -1;
+    s->inner_calls = 0;
 
     /* _predict_all Tracking.py:591-596 */
     for (int j = 0; j < T; j++) kf_predict(c, &s->tracks[j], s->tracks[j].lifetime + dt);
@@ -730,8 +804,17 @@ int orc_track_frame(orc_scene *s, const double *pts, int n, double dt, int32_t *
             t->lifetime = 0.0;
             rc = track_associate(s, t, s->cloud, m);
             if (rc) return rc;
+            if (c->seek_inner) seek_inner(s, t, j, s->cloud, m);   /* Tracking.py:656 */
         }
     }
+    /* Tracking.py:658-660: a track for every inner cluster found, appended BEFORE _maintain_tracks / _update_all */
+    for (int k = 0; k < s->inner_calls; k++) {
+        if (s->inner_m[k] == 0) continue;
+        if (s->n_tracks >= c->track_cap) return -4;
+        track_init(s, &s->tracks[s->n_tracks], s->inner_rows + (size_t)k * (size_t)s->ring_size * s->cfg.ring_rows * 8, s->inner_m[k]);
+        s->n_tracks++;
+    }
+    T = s->n_tracks;
 
     /* _maintain_tracks Tracking.py:513-528 */
     {
@@ -779,10 +862,25 @@ int orc_track_frame(orc_scene *s, const double *pts, int n, double dt, int32_t *
             }
         }
     }
-    return 0;
+    return s->overflow ? -4 : 0;
 }
 
 int orc_num_tracks(const orc_scene *s) { return s->n_tracks; }
+
+int orc_get_inner(const orc_scene *s, int32_t *track, int32_t *n, int32_t *labels, int cap_calls, int cap_labels)
+{
+    const size_t um = (size_t)s->ring_size * s->cfg.ring_rows;
+    int off = 0;
+    for (int k = 0; k < s->inner_calls && k < cap_calls; k++) {
+        if (track) track[k] = s->inner_track[k];
+        if (n) n[k] = s->inner_n[k];
+        if (labels && off + s->inner_n[k] <= cap_labels) memcpy(labels + off, s->inner_labels + (size_t)k * um, sizeof(int32_t) * (size_t)s->inner_n[k]);
+        off += s->inner_n[k];
+    }
+    return s->inner_calls;
+}
+
+int orc_get_track_ring_size(const orc_scene *s, int t) { return (t >= 0 && t < s->n_tracks) ? s->tracks[t].ring_size : -1; }
 
 int orc_get_tracks(const orc_scene *s, orc_track_record *out, int cap)
 {

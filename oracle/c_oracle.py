@@ -48,6 +48,11 @@ class OrcConfig(C.Structure):
         ("tilt_cos", C.c_double),
         ("tilt_sin", C.c_double),
         ("default_posture", C.c_float * NKP),
+        ("seek_inner", C.c_int32),
+        ("db_points_thres", C.c_int32),
+        ("fb_frames_batch_static", C.c_int32),
+        ("db_spread_thres", C.c_double),
+        ("db_inner_eps", C.c_double),
     ]
 
 
@@ -110,6 +115,8 @@ def lib():
     L.orc_num_tracks.argtypes = [vp]
     L.orc_get_tracks.argtypes = [vp, C.c_void_p, C.c_int]
     L.orc_get_batch_ring.argtypes = [vp, i32p]
+    L.orc_get_inner.argtypes = [vp, i32p, i32p, i32p, C.c_int, C.c_int]
+    L.orc_get_track_ring_size.argtypes = [vp, C.c_int]
     L.orc_pop_frame.argtypes = [vp]
     L.orc_pop_frame.restype = None
     L.orc_get_track_ring_frame.argtypes = [vp, C.c_int, C.c_int, f64p, C.c_int]
@@ -168,6 +175,8 @@ def config_from_constants(const, **overrides) -> OrcConfig:
         kf_a_spr=float(const.KF_A_SPR), intensity_mu=float(const.INTENSITY_MU),
         intensity_std=float(const.INTENSITY_STD), s_height=float(const.S_HEIGHT),
         s_tilt=float(const.S_TILT), default_posture=list(np.asarray(const.MODEL_DEFAULT_POSTURE, dtype=np.float32)),
+        db_points_thres=int(const.DB_POINTS_THRES), fb_frames_batch_static=int(const.FB_FRAMES_BATCH_STATIC),
+        db_spread_thres=float(const.DB_SPREAD_THRES), db_inner_eps=float(const.DB_INNER_EPS),
     )
     kw.update(overrides)
     return default_config(**kw)
@@ -216,6 +225,23 @@ class OracleScene:
         self.L.orc_get_tracks(self.h, out.ctypes.data_as(C.c_void_p), n)
         return out[:n]
 
+    def inner_calls(self):
+        """seek_inner_clusters calls of the last frame: list of (pre-maintenance track position, labels[n])."""
+        cap = max(self.cfg.track_cap, 64)
+        trk = np.zeros(cap, dtype=np.int32)
+        n = np.zeros(cap, dtype=np.int32)
+        lab = np.zeros(cap * self.ring * self.ring * self.max_pts, dtype=np.int32)
+        k = self.L.orc_get_inner(self.h, _p(trk, C.c_int32), _p(n, C.c_int32), _p(lab, C.c_int32), cap, lab.size)
+        out, off = [], 0
+        for i in range(k):
+            out.append((int(trk[i]), lab[off: off + n[i]].copy()))
+            off += int(n[i])
+        return out
+
+    def track_ring_size(self, t: int) -> int:
+        """track.batch.size (what BatchedData.change_buffer_size sets, Tracking.py:60-64)."""
+        return self.L.orc_get_track_ring_size(self.h, int(t))
+
     def pop_frame(self):
         """BatchedData.pop_frame() (Tracking.py:66-71)."""
         self.L.orc_pop_frame(self.h)
@@ -226,7 +252,7 @@ class OracleScene:
         return a[:k].copy()
 
     def track_ring_frame(self, t: int, k: int) -> np.ndarray:
-        rows = np.zeros((self.cfg.ring_rows if self.cfg.ring_rows >= 64 else 64, 8))
+        rows = np.zeros((max(self.cfg.ring_rows, 64, self.ring * self.max_pts if self.cfg.seek_inner else 0), 8))
         m = self.L.orc_get_track_ring_frame(self.h, t, k, _p(rows, C.c_double), rows.shape[0])
         if m < 0:
             raise IndexError((t, k))

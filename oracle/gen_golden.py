@@ -29,7 +29,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-from mmwave_msc_amd.synth import make_scene  # noqa: E402
+from mmwave_msc_amd.synth import make_pair_scene, make_scene  # noqa: E402
 from oracle.c_oracle import TRACK_DTYPE  # noqa: E402
 from oracle.ref_import import have_reference, load_reference  # noqa: E402
 from oracle.ref_runner import RefScene  # noqa: E402
@@ -53,6 +53,11 @@ SCENARIOS = {
     "empty_frames": dict(seed=113, N=96, K=1, F=16, over={}, zero_frames=(3, 9)),
     "kf_est": dict(seed=114, N=128, K=2, F=20, over={"KF_ENABLE_EST": True}, presence="flicker"),
     "max_size": dict(seed=115, N=640, K=0, F=4, over={}),
+    # ClusterTrack.seek_inner_clusters with its call site (Tracking.py:656) active: pairs of people one outer cluster wide
+    "inner_pair": dict(seed=116, N=256, K=1, F=14, over={"SEEK_INNER": True}, pairs=dict(sep=0.8)),
+    "inner_static": dict(seed=117, N=256, K=1, F=12, over={"SEEK_INNER": True, "FB_FRAMES_BATCH_STATIC": 3}, pairs=dict(sep=0.9, static=True)),
+    "inner_two_pairs": dict(seed=118, N=512, K=2, F=10, over={"SEEK_INNER": True, "TR_MAX_TRACKS": 4}, pairs=dict(sep=0.8)),
+    "inner_close": dict(seed=119, N=200, K=1, F=10, over={"SEEK_INNER": True, "DB_POINTS_THRES": 60}, pairs=dict(sep=0.45)),
 }
 
 
@@ -83,8 +88,11 @@ def gen_scenario(name, sc):
     dt_seq = None
     if sc.get("dt") == "var":
         dt_seq = np.round(rng.uniform(0.05, 0.3, size=f), 3)
-    pts, cnt, dt = make_scene(sc["seed"], f, n, k, ragged=sc.get("ragged", False),
-                              presence=_presence(sc.get("presence"), f, k), dt_seq=dt_seq)
+    if "pairs" in sc:
+        pts, cnt, dt = make_pair_scene(sc["seed"], f, n, k, **sc["pairs"])
+    else:
+        pts, cnt, dt = make_scene(sc["seed"], f, n, k, ragged=sc.get("ragged", False),
+                                  presence=_presence(sc.get("presence"), f, k), dt_seq=dt_seq)
     for zf in sc.get("zero_frames", ()):
         cnt[zf] = 0
         pts[zf] = 0
@@ -98,6 +106,10 @@ def gen_scenario(name, sc):
     rec = dict(assoc=np.full((f, n), -2, np.int16), db_n=np.full(f, -1, np.int32),
                labels=np.full((f, ring * n), -2, np.int16), n_tracks=np.zeros(f, np.int32),
                ring_len=np.zeros(f, np.int32), ring_n=np.zeros((f, 4), np.int32))
+    inner = over.get("SEEK_INNER", False)
+    if inner:   # per frame: the seek_inner_clusters calls (pre-maintenance track position, labels) and every track's batch.size
+        rec.update(inner_calls=np.zeros(f, np.int32), inner_track=np.full((f, 8), -1, np.int32), inner_n=np.zeros((f, 8), np.int32),
+                   inner_labels=np.full((f, 8, ring * n), -2, np.int16), ring_size=np.zeros((f, 16), np.int32))
     tracks, feats, owners = [], [], []
     for i in range(f):
         if cnt[i] == 0:
@@ -115,6 +127,14 @@ def gen_scenario(name, sc):
             rec["db_n"][i] = len(lab)
             rec["labels"][i, : len(lab)] = lab
         rec["n_tracks"][i] = ref.n_tracks
+        if inner:
+            rec["inner_calls"][i] = len(ref.inner)
+            for q, (tpos, lab_in) in enumerate(ref.inner):
+                rec["inner_track"][i, q] = tpos
+                rec["inner_n"][i, q] = len(lab_in)
+                rec["inner_labels"][i, q, : len(lab_in)] = lab_in
+            rs = ref.track_ring_sizes()
+            rec["ring_size"][i, : len(rs)] = rs
         br = ref.batch_ring()
         rec["ring_len"][i] = len(br)
         rec["ring_n"][i, : len(br)] = br

@@ -16,6 +16,38 @@ from .ref_import import load_reference
 class _Recorder:
     assoc = None
     labels = None
+    inner = []      # seek_inner_clusters calls of the frame: (pre-maintenance track position, labels)
+
+
+def _enable_seek_inner(tracking):
+    """Tracking.py:656 (`# new_inner_clusters.append(track.seek_inner_clusters())`) is commented out in the reference.
+    For the seek_inner goldens the method is re-compiled from the reference's OWN source text with exactly that line
+    un-commented (at generation time, in this container; nothing of it is stored), and `seek_inner_clusters` is wrapped
+    so that the labels of its apply_DBscan call are recorded per call instead of being mistaken for the frame's."""
+    import inspect
+    import textwrap
+    if getattr(tracking, "_mmw_inner", False):
+        return
+    src = textwrap.dedent(inspect.getsource(tracking.TrackBuffer._associate_points_to_tracks))
+    marker = "# new_inner_clusters.append(track.seek_inner_clusters())"
+    assert src.count(marker) == 1, "the reference's call site moved"
+    src = src.replace(marker, "new_inner_clusters.append(track.seek_inner_clusters())")
+    ns = {}
+    exec(compile(src, "<Tracking.py:_associate_points_to_tracks with line 656 active>", "exec"), tracking.__dict__, ns)
+    tracking.TrackBuffer._associate_points_to_tracks_shipped = tracking.TrackBuffer._associate_points_to_tracks
+    tracking.TrackBuffer._associate_points_to_tracks_inner = ns["_associate_points_to_tracks"]
+    orig = tracking.ClusterTrack.seek_inner_clusters
+
+    def seek(self):
+        saved, _Recorder.labels = _Recorder.labels, None
+        out = orig(self)
+        if _Recorder.labels is not None:
+            _Recorder.inner.append((_Recorder.current_tracks.index(self), _Recorder.labels))
+        _Recorder.labels = saved
+        return out
+
+    tracking.ClusterTrack.seek_inner_clusters = seek
+    tracking._mmw_inner = True
 
 
 def _install_hooks(utils, tracking):
@@ -46,7 +78,11 @@ class RefScene:
         self.const, self.utils, self.tracking = load_reference()
         _install_hooks(self.utils, self.tracking)
         self._saved = {}
-        for k, v in (overrides or {}).items():
+        overrides = dict(overrides or {})
+        self.seek_inner = bool(overrides.pop("SEEK_INNER", False))
+        if self.seek_inner:
+            _enable_seek_inner(self.tracking)
+        for k, v in overrides.items():
             self._saved[k] = getattr(self.const, k)
             setattr(self.const, k, v)
         self.tb = self.tracking.TrackBuffer()
@@ -61,8 +97,15 @@ class RefScene:
         pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 8)
         _Recorder.assoc = np.full(pts.shape[0], -1, dtype=np.int32)
         _Recorder.labels = None
+        _Recorder.inner = []
+        _Recorder.current_tracks = list(self.tb.effective_tracks)
+        tb_cls = self.tracking.TrackBuffer
+        if hasattr(tb_cls, "_associate_points_to_tracks_inner"):
+            tb_cls._associate_points_to_tracks = (tb_cls._associate_points_to_tracks_inner if self.seek_inner
+                                                  else tb_cls._associate_points_to_tracks_shipped)
         self.tb.dt = dt
         self.tb.track(pts, self.batch)
+        self.inner = list(_Recorder.inner)
         return _Recorder.assoc.copy(), (None if _Recorder.labels is None else _Recorder.labels.copy())
 
     @property
@@ -89,6 +132,9 @@ class RefScene:
                 out[j]["ring_n"][k] = len(fr)
             out[j]["keypoints"] = np.asarray(t.keypoints, dtype=np.float32)
         return out
+
+    def track_ring_sizes(self):
+        return np.array([t.batch.size for t in self.tb.effective_tracks], dtype=np.int32)
 
     def batch_ring(self):
         return np.array([len(f) for f in self.batch.buffer], dtype=np.int32)

@@ -66,6 +66,12 @@ def overrides_to_cfg_kwargs(over):
             kw["fb_frames_batch"] = int(v)
         elif k == "KF_ENABLE_EST":
             kw["kf_enable_est"] = int(bool(v))
+        elif k == "SEEK_INNER":
+            kw["seek_inner"] = int(bool(v))
+        elif k == "FB_FRAMES_BATCH_STATIC":
+            kw["fb_frames_batch_static"] = int(v)
+        elif k == "DB_POINTS_THRES":
+            kw["db_points_thres"] = int(v)
         else:
             raise KeyError(k)
     return kw

@@ -13,8 +13,9 @@ import os
 @pytest.mark.parametrize("name", scenario_names())
 def test_tracker_matches_reference_golden(name):
     g = load_scenario(name)
-    cfg = co.default_config(**overrides_to_cfg_kwargs(g["overrides"]))
+    kw = overrides_to_cfg_kwargs(g["overrides"])
     n = g["pts"].shape[1]
+    cfg = co.default_config(**kw)
     sc = co.OracleScene(cfg, n)
     ring = cfg.fb_frames_batch + 1
     for f in range(g["pts"].shape[0]):
@@ -32,6 +33,13 @@ def test_tracker_matches_reference_golden(name):
         nt = int(g["n_tracks"][f])
         assert sc.n_tracks == nt
         assert_tracks_match(sc.tracks(), g["tracks"][f, :nt], ctx=f"{name} f{f}")
+        if kw.get("seek_inner"):   # ClusterTrack.seek_inner_clusters (Tracking.py:409-448) with its call site active
+            calls = sc.inner_calls()
+            assert len(calls) == int(g["inner_calls"][f]), f"{name} f{f}: seek_inner_clusters call count"
+            for q, (tpos, lab_in) in enumerate(calls):
+                assert tpos == g["inner_track"][f, q] and len(lab_in) == g["inner_n"][f, q]
+                assert np.array_equal(lab_in, g["inner_labels"][f, q, : len(lab_in)]), f"{name} f{f}: inner labels of call {q}"
+            assert [sc.track_ring_size(t) for t in range(nt)] == list(g["ring_size"][f, :nt]), f"{name} f{f}: batch.size"
         br = sc.batch_ring()
         assert len(br) == g["ring_len"][f] and np.array_equal(br, g["ring_n"][f, : len(br)])
         feat, owner = sc.features()
