@@ -226,6 +226,16 @@ int mmw_get_batch_ring(mmw_ctx *ctx, int32_t *ring_len /*[S]*/, int32_t *ring_n 
 int mmw_get_track_ring_frame(mmw_ctx *ctx, int32_t scene, int32_t track, int32_t k, double *out, int32_t *n_rows);
 int mmw_get_batch_ring_frame(mmw_ctx *ctx, int32_t scene, int32_t k, double *out /*[max_pts][8]*/, int32_t *n_rows);
 
+/* ClusterTrack.seek_inner_clusters (Tracking.py:409-448) runs inside mmw_step when mmw_config.seek_inner = 1, i.e. as if
+ * its call site Tracking.py:656 were active: per-track ring sizes follow change_buffer_size (Tracking.py:60-64), the
+ * cluster's cloud is added to the track's ring a second time, apply_DBscan(eps = DB_INNER_EPS) runs on the ring and a
+ * track is appended for clusters[1] before _update_all.  Such a context stores ring frames whole (ring_rows is raised
+ * to ring * max_pts); a cloud of more than min(1920, ring * ring_rows) rows, or a frame longer than ring_rows, is
+ * MMW_E_CAPACITY.  This read-back (sync) returns the calls of the LAST mmw_step: n_calls[S]; rows[S][16] = points
+ * clustered by each of the first 16 calls, in track-list order; labels[S][cap_labels] = their sklearn labels back to
+ * back (as many as fit).  rows / labels may be NULL. */
+int mmw_get_inner(mmw_ctx *ctx, int32_t *n_calls, int32_t *rows, int32_t *labels, int32_t cap_labels);
+
 /* Per-scene track table for the multi-GPU all-gather:
  * table[S][slots] (dev), scene ids offset by scene_base.  Async. */
 int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32_t scene_base);

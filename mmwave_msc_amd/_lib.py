@@ -29,7 +29,7 @@ EXPORTS = [
     "mmw_get_num_tracks", "mmw_get_tracks", "mmw_get_batch_ring", "mmw_get_track_ring_frame",
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
-    "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid",
+    "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
 ]
 
 
@@ -149,6 +149,7 @@ def load():
         "mmw_features_async": (C.c_int, [vp, vp, vp, vp, i32, i32]),
         "mmw_features_wait": (C.c_int, [vp, i32, i32p]),
         "mmw_set_keypoints_uid": (C.c_int, [vp, vp, vp, vp, i32]),
+        "mmw_get_inner": (C.c_int, [vp, vp, vp, vp, i32]),
         "mmw_check": (C.c_int, [vp]),
         "mmw_get_num_tracks": (C.c_int, [vp, vp]),
         "mmw_get_tracks": (C.c_int, [vp, vp, i32]),

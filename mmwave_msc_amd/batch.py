@@ -257,6 +257,23 @@ class SceneBatch:
         self._chk(self.L.mmw_get_batch_ring_frame(self.h, scene, k, out.ctypes.data, C.byref(n)))
         return out[: n.value].copy()
 
+    def inner_calls(self, cap_labels=None):
+        """seek_inner_clusters calls of the last step (contexts with seek_inner = 1): per scene a list of label arrays,
+        one per call, in track-list order (mmw_get_inner)."""
+        cap = int(cap_labels if cap_labels is not None else 2 * self.ring * self.ring_rows)
+        n = np.zeros(self.S, dtype=np.int32)
+        rows = np.zeros((self.S, 16), dtype=np.int32)
+        lab = np.full((self.S, cap), -2, dtype=np.int32)
+        self._chk(self.L.mmw_get_inner(self.h, n.ctypes.data, rows.ctypes.data, lab.ctypes.data, cap))
+        out = []
+        for s in range(self.S):
+            calls, off = [], 0
+            for k in range(min(int(n[s]), 16)):
+                calls.append(lab[s, off: off + rows[s, k]].copy())
+                off += int(rows[s, k])
+            out.append(calls)
+        return out
+
     def track_table_dev(self, table_ptr, slots: int, scene_base: int = 0):
         self._chk(self.L.mmw_track_table(self.h, table_ptr, int(slots), int(scene_base)))
 

@@ -816,50 +816,20 @@ __device__ __forceinline__ void finish_scene_stats(const DevState &st, int s, in
     }
 }
 
-template <int NT, bool ALL8>
-__device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &st, const DbLds &L, int s, int UMc, int CL, int UM_out,
-                                            bool screened, int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+// _add_tracks (Tracking.py:576-589) for `nspawn` clusters of the cloud dbscan_core has just labelled: cluster c is
+// the set of points with label lab0 + c (rows keep input order, Utils.py:285-287); its track is appended at list
+// position T0 + c.  All threads of the workgroup call; L.misc[4] holds the first creation ordinal.
+template <int NT>
+__device__ __forceinline__ void add_clusters(const DevCfg &cfg, const DevState &st, const DbLds &L, const RowSrc src, int s, int U, int CL,
+                                             int lab0, int nspawn, int T0)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    SceneHdr *hdr = st.hdr + s;
-    const int U = hdr->db_u;
-    const RowSrc src = ring_rows_of(cfg, st, hdr, s);
-    __syncthreads();  // every thread has read the header before anyone rewrites it below
-    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, stats_slot(st, s), screened);
     const int *labi = L.idx2;
-    if (labels_out)
-        for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM_out + i] = labi[i];
-    if (tid == 0) {
-        if (db_n_out) db_n_out[s] = U;
-        hdr->need_db = 0;
-        finish_scene_stats(st, s, U, ncl);
-    }
-    if (ncl == 0) return;
-
-    // ---- batch.clear() (Tracking.py:53-58) + _add_tracks (Tracking.py:576-589) ----
-    const int T0 = hdr->n_tracks;
-    int nspawn = ncl;
-    int err = 0;
-    if (T0 + ncl > cfg.t_cap || ncl > CL) { nspawn = min(max(cfg.t_cap - T0, 0), CL); err |= ERR_CAPACITY; }
-    __syncthreads();
-    if (tid == 0) {
-        hdr->g_len = 0;
-        for (int k = 0; k < MMW_RING_MAX; k++) hdr->g_n[k] = 0;
-        hdr->n_tracks = T0 + nspawn;
-        if (nspawn > 0) {  // the next k_predict takes the new tracks T0.. from here (the older ones from the update lists)
-            const int pos = atomicAdd(&st.spc_count[parity], 1);
-            st.spc_list[((size_t)parity * cfg.n_scenes + pos) * 2] = s;
-            st.spc_list[((size_t)parity * cfg.n_scenes + pos) * 2 + 1] = T0;
-        }
-        L.misc[4] = hdr->next_uid;
-        hdr->next_uid += nspawn;
-        if (err) atomicOr(&hdr->err, err);
-    }
-    // members of every cluster in ascending point index (rows keep input order, Utils.py:285-287)
+    // members of every cluster in ascending point index
     const int NB = (U + 63) / 64, CLS = CL + 1;
     for (int i0 = 0; i0 < U; i0 += NT) {
         const int i = i0 + tid;
-        const int cls_i = (i < U) ? labi[i] : -1;
+        const int cls_i = (i < U) ? labi[i] - lab0 : -1;
         const int b = i >> 6;
         if (i0 + (tid & ~63) < U) {
             unsigned long long mine = 0;
@@ -886,7 +856,7 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
     __syncthreads();
     int *memb = L.front;  // free after labelling
     for (int i = tid; i < U; i += NT) {
-        const int c = labi[i];
+        const int c = labi[i] - lab0;
         if (c >= 0 && c < nspawn) memb[L.cl_off[c] + L.cnt[(i >> 6) * CLS + c] + L.lab[i]] = i;
     }
     __syncthreads();
@@ -897,7 +867,7 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
         const int c = t / 6, m = t % 6;
         const int n = L.cl_n[c], off = L.cl_off[c];
         TrackRec *rec = trk + order[T0 + c];
-        // (rows come from the global ring -- the LDS x,y,z are in tree-position order by now --: eight loads in
+        // (rows come from the ring -- the LDS x,y,z are in tree-position order by now --: eight loads in
         //  flight per round trip, the sum itself stays sequential in row order)
         double sum = 0.0, mn = 0.0, mx = 0.0;
         int r = 0;
@@ -946,12 +916,185 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
             rec->lifetime = 0.0;
             rec->ring_len = 1;
             rec->uid = L.misc[4] + c;
+            rec->inner = cfg.ring;  // a fresh BatchedData: size FB_FRAMES_BATCH + 1, associate_pointcloud has not run on it
             for (int k = 0; k < MMW_RING_MAX; k++) { rec->ring_slot[k] = k; rec->ring_n[k] = 0; }
             rec->ring_n[0] = n;
         }
         const int keep = min(n, cfg.ring_rows);
         double *dst = st.trk_ring + (((size_t)s * cfg.t_cap + slot) * cfg.ring + 0) * (size_t)cfg.ring_rows * 8;
         for (int e = tid; e < keep * 8; e += NT) dst[e] = src.row(memb[off + (e >> 3)])[e & 7];
+    }
+}
+
+template <int NT, bool ALL8>
+__device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &st, const DbLds &L, int s, int UMc, int CL, int UM_out,
+                                            bool screened, int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    const int tid = threadIdx.x;
+    SceneHdr *hdr = st.hdr + s;
+    const int U = hdr->db_u;
+    const RowSrc src = ring_rows_of(cfg, st, hdr, s);
+    __syncthreads();  // every thread has read the header before anyone rewrites it below
+    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, stats_slot(st, s), screened);
+    const int *labi = L.idx2;
+    if (labels_out)
+        for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM_out + i] = labi[i];
+    if (tid == 0) {
+        if (db_n_out) db_n_out[s] = U;
+        hdr->need_db = 0;
+        finish_scene_stats(st, s, U, ncl);
+    }
+    if (ncl == 0) return;
+
+    // ---- batch.clear() (Tracking.py:53-58) + _add_tracks (Tracking.py:576-589) ----
+    const int T0 = hdr->n_tracks;
+    int nspawn = ncl;
+    int err = 0;
+    if (T0 + ncl > cfg.t_cap || ncl > CL) { nspawn = min(max(cfg.t_cap - T0, 0), CL); err |= ERR_CAPACITY; }
+    __syncthreads();
+    if (tid == 0) {
+        hdr->g_len = 0;
+        for (int k = 0; k < MMW_RING_MAX; k++) hdr->g_n[k] = 0;
+        hdr->n_tracks = T0 + nspawn;
+        if (nspawn > 0) {  // the next k_predict takes the new tracks T0.. from here (the older ones from the update lists)
+            const int pos = atomicAdd(&st.spc_count[parity], 1);
+            st.spc_list[((size_t)parity * cfg.n_scenes + pos) * 2] = s;
+            st.spc_list[((size_t)parity * cfg.n_scenes + pos) * 2 + 1] = T0;
+        }
+        L.misc[4] = hdr->next_uid;
+        hdr->next_uid += nspawn;
+        if (err) atomicOr(&hdr->err, err);
+    }
+    add_clusters<NT>(cfg, st, L, src, s, U, CL, 0, nspawn, T0);
+}
+
+// ClusterTrack.seek_inner_clusters (Tracking.py:409-448) with its call site (Tracking.py:656) active, cfg.seek_inner:
+// one launch between k_track and k_post, one workgroup per scene.  For every track whose associate_pointcloud ran
+// this frame (k_track marks them), in list order:
+//   * `cluster.point_num > DB_POINTS_THRES and spread.any() > DB_SPREAD_THRES` -- the second term compares a BOOL
+//     (x-spread != 0) with the threshold, as the reference does;
+//   * change_buffer_size(FB_FRAMES_BATCH_STATIC | FB_FRAMES_BATCH) -- permanent -- and add_frame(cluster.pointcloud): the
+//     cloud k_track has just appended is appended a second time;
+//   * apply_DBscan(effective_data, eps = DB_INNER_EPS) with the default min_samples; more than one cluster ->
+//     _add_tracks([clusters[1]]) (Tracking.py:658-660): the track is appended BEFORE _update_all (k_post) and before
+//     the frame's own DBSCAN trigger, which is re-evaluated here (`len(effective_tracks) < TR_MAX_TRACKS`).
+// The per-scene layout of the Kalman kernels is forced for such contexts (hdr->n_upd is all k_post needs).
+constexpr int kInnerThreads = 512;
+__global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int UMc,
+                                                         int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int n = n_pts[s];
+    int32_t *ib = st.inner_buf + (size_t)s * (kInnerHdr + st.inner_cap);
+    if (tid < kInnerHdr) ib[tid] = 0;
+    if (n <= 0 || n > cfg.max_pts) return;  // the frame never reached track()
+    SceneHdr *hdr = st.hdr + s;
+    int32_t *order = st.order + (size_t)s * cfg.t_cap;
+    TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
+    const int Tin = hdr->n_tracks;  // after _maintain_tracks: tracks with points are never removed and keep their order
+    int T = Tin, calls = 0, stored = 0, err = 0;
+    DbLds L;
+    __syncthreads();
+    for (int j = 0; j < Tin; j++) {
+        const int slot = order[j];
+        TrackRec *rec = trk + slot;
+        const int inner = rec->inner;
+        if (!(inner & kInnerTouched)) continue;  // uniform
+        const double xspread = rec->maxv[0] - rec->minv[0];
+        const double any = xspread != 0.0 ? 1.0 : 0.0;
+        const bool go = rec->point_num > cfg.db_points_thres && any > cfg.db_spread_thres;
+        int len = rec->ring_len, rn[MMW_RING_MAX], rs[MMW_RING_MAX];
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) { rn[k] = rec->ring_n[k]; rs[k] = rec->ring_slot[k]; }
+        const bool is_static = rec->is_static != 0;
+        __syncthreads();  // everyone has read the record
+        if (!go) {
+            if (tid == 0) rec->inner = inner & 255;
+            continue;
+        }
+        // ---- change_buffer_size + add_frame(cluster.pointcloud) ----
+        const int size = is_static ? cfg.fb_frames_batch_static : cfg.ring - 1;  // FB_FRAMES_BATCH_STATIC | FB_FRAMES_BATCH
+        const int src_slot = rs[len - 1], rows = rn[len - 1];  // the cloud associate_pointcloud appended
+        while (len >= size && len > 0) {
+            const int first = rs[0];
+#pragma unroll
+            for (int k = 1; k < MMW_RING_MAX; k++) if (k < len) { rs[k - 1] = rs[k]; rn[k - 1] = rn[k]; }
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) if (k == len - 1) rs[k] = first;
+            len--;
+        }
+        int dst_slot = rs[0];
+#pragma unroll
+        for (int k = 1; k < MMW_RING_MAX; k++) if (k == len) dst_slot = rs[k];
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) if (k == len) rn[k] = rows;
+        len++;
+        double *ring = st.trk_ring + ((size_t)s * cfg.t_cap + slot) * cfg.ring * (size_t)cfg.ring_rows * 8;
+        const int keep = min(rows, cfg.ring_rows);
+        if (dst_slot != src_slot) {
+            const double2 *a = reinterpret_cast<const double2 *>(ring + (size_t)src_slot * cfg.ring_rows * 8);
+            double2 *b = reinterpret_cast<double2 *>(ring + (size_t)dst_slot * cfg.ring_rows * 8);
+            for (int e = tid; e < keep * 4; e += kInnerThreads) b[e] = a[e];
+        }
+        if (tid == 0) {
+            rec->ring_len = len;
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) { rec->ring_n[k] = k < len ? rn[k] : 0; rec->ring_slot[k] = rs[k]; }
+            rec->inner = size;
+        }
+        // ---- apply_DBscan(self.batch.effective_data, eps=DB_INNER_EPS) ----
+        RowSrc src;
+        const int big = 0x7fffffff;
+        src.gb = ring;
+        src.stride = (size_t)cfg.ring_rows * 8;
+        src.slots = (unsigned)rs[0] | ((unsigned)rs[1] << 8) | ((unsigned)rs[2] << 16) | ((unsigned)rs[3] << 24);
+        src.c1 = len > 1 ? rn[0] : big;
+        src.c2 = len > 2 ? rn[0] + rn[1] : big;
+        src.c3 = len > 3 ? rn[0] + rn[1] + rn[2] : big;
+        int U = 0;
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) if (k < len) U += rn[k];
+        bool whole = true;
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) if (k < len && rn[k] > cfg.ring_rows) whole = false;
+        if (U > UMc || !whole) { err |= ERR_CAPACITY; continue; }  // a frame that was not stored whole, or more points than the BallTree holds
+        __syncthreads();  // the copied rows are visible to the whole workgroup (this barrier is also a global-memory fence)
+        const bool tpp = U <= kInnerThreads;  // uniform
+        db_lds_layout<true>(UMc, 2, tpp, lds_raw, &L);
+        const int ncl = tpp ? dbscan_core<kInnerThreads, true>(cfg, L, src, U, UMc, cfg.db_inner_eps, cfg.db_min_samples, nullptr)
+                            : dbscan_core<kInnerThreads, false>(cfg, L, src, U, UMc, cfg.db_inner_eps, cfg.db_min_samples, nullptr);
+        // the call, for mmw_get_inner: rows and labels in call order
+        if (calls < 16 && tid == 0) ib[2 + calls] = U;
+        if (stored + U <= st.inner_cap) {
+            for (int i = tid; i < U; i += kInnerThreads) ib[kInnerHdr + stored + i] = L.idx2[i];
+            stored += U;
+        }
+        calls++;
+        if (ncl > 1) {  // new_track_clusters = [track_clusters[1]]
+            if (T + 1 > cfg.t_cap) { err |= ERR_CAPACITY; }
+            else {
+                __syncthreads();
+                if (tid == 0) { L.misc[4] = hdr->next_uid; hdr->next_uid += 1; }
+                __syncthreads();
+                add_clusters<kInnerThreads>(cfg, st, L, src, s, U, 2, 1, 1, T);
+                T++;
+            }
+        }
+        __syncthreads();  // LDS and the scene's records are reused by the next track
+    }
+    if (tid == 0) {
+        ib[0] = calls;
+        ib[1] = stored;
+        if (err) atomicOr(&hdr->err, err);
+        if (T != Tin) {
+            hdr->n_tracks = T;
+            hdr->n_upd = T;   // _update_all covers the inner tracks as well
+            if (T >= cfg.tr_max_tracks) {  // Tracking.py:693-697: apply_DBscan is not called this frame after all
+                hdr->need_db = 0;
+                if (db_n_out) db_n_out[s] = -1;
+            }
+        }
     }
 }
 
@@ -1019,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             const int s = st.db_list[(size_t)3 * cfg.n_scenes + w];
             SceneHdr *hdr = st.hdr + s;
             const int U = hdr->db_u;
+            if (cfg.seek_inner && !hdr->need_db) continue;  // k_inner filled the track list: no apply_DBscan this frame (uniform)
             // k_track's cell count left this cloud undecided: the exact pair count first (mmw_cloud.hpp), the
             // BallTree only if a core point is still possible
             if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
@@ -1057,6 +1201,7 @@ __global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState
     const int count = st.db_count[parity * 4 + cls];
     for (int w = b0; w < count; w += nb) {
         const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
+        if (cfg.seek_inner && !st.hdr[s].need_db) continue;  // cancelled by k_inner (uniform)
         // a cloud that fits one point per thread takes the thread-per-point build of the small class (registers
         // hold the 8 columns, one bitonic sort per level): 3-4x less tree-build time than the strided build
         const bool tpp = st.hdr[s].db_u <= kBigThreads;  // uniform
@@ -1126,6 +1271,27 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
+}
+
+int inner_um(const DevCfg &cfg)
+{
+    const long long v = (long long)cfg.ring * cfg.ring_rows;
+    return (int)(v < 30 * 64 ? v : 30 * 64);  // the BallTree emulation holds <= 32 leaves
+}
+static size_t inner_lds_bytes(const DevCfg &cfg)
+{
+    const int um = inner_um(cfg);
+    const size_t a = db_lds_layout<false>(um, 2, false, nullptr, nullptr), b = db_lds_layout<false>(um, 2, true, nullptr, nullptr);
+    return a > b ? a : b;
+}
+hipError_t prepare_inner(const DevCfg &cfg)
+{
+    return hipFuncSetAttribute((const void *)k_inner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inner_lds_bytes(cfg));
+}
+size_t inner_lds_demand(const DevCfg &cfg) { return inner_lds_bytes(cfg); }
+void launch_inner(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int32_t *db_n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_inner, dim3(cfg.n_scenes), dim3(kInnerThreads), inner_lds_bytes(cfg), stream, cfg, st, n_pts, inner_um(cfg), db_n);
 }
 
 // _update_all + the BallTree DBSCAN of the small clouds (work list 3)

@@ -309,10 +309,11 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         unsigned long long mybal[PPT];
         // ring state of track `tid` (thread T: of the global ring), needed after the scans below: requested now so
         // that the global round trip runs under the ballots and scans (T <= t_cap <= 64 < 256 threads)
-        int sd_len = 0, sd_rs[MMW_RING_MAX] = {0, 0, 0, 0};
+        int sd_len = 0, sd_rs[MMW_RING_MAX] = {0, 0, 0, 0}, sd_size = cfg.ring;
         if (tid < T) {
             const TrackRec *rec = trk + L.slot[tid];
             sd_len = rec->ring_len;
+            if (cfg.seek_inner) sd_size = rec->inner & 255;  // track.batch.size after change_buffer_size (Tracking.py:60-64)
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = rec->ring_slot[k];
         } else if (tid == T) {
@@ -359,8 +360,23 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         // split, see there): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
         if (tid <= T) {
             int phys = sd_rs[0];
+            if (cfg.seek_inner) {  // a ring whose size has shrunk pops more than one frame: run add_frame's loop on the copies
+                int len = sd_len;
+                while (len >= sd_size && len > 0) {
+                    const int first = sd_rs[0];
 #pragma unroll
-            for (int k = 1; k < MMW_RING_MAX; k++) if (sd_len < cfg.ring && k == sd_len) phys = sd_rs[k];
+                    for (int k = 1; k < MMW_RING_MAX; k++) if (k < len) sd_rs[k - 1] = sd_rs[k];
+#pragma unroll
+                    for (int k = 0; k < MMW_RING_MAX; k++) if (k == len - 1) sd_rs[k] = first;
+                    len--;
+                }
+                phys = sd_rs[0];
+#pragma unroll
+                for (int k = 1; k < MMW_RING_MAX; k++) if (k == len) phys = sd_rs[k];
+            } else {
+#pragma unroll
+                for (int k = 1; k < MMW_RING_MAX; k++) if (sd_len < cfg.ring && k == sd_len) phys = sd_rs[k];
+            }
             L.seg_dst[tid] = tid < T ? (((long long)s * cfg.t_cap + L.slot[tid]) * cfg.ring + phys) * (long long)cfg.ring_rows * 8
                                      : ((long long)s * cfg.ring + phys) * (long long)NP * 8;
         }
@@ -575,8 +591,10 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     //  global round trips)
     for (int j = kThreads - 1 - tid; j < T; j += kThreads) {
         const int nj = L.cls_n[j + 1];
+        if (nj == 0 && cfg.seek_inner) trk[L.slot[j]].inner &= 255;  // associate_pointcloud did not run on this track
         if (nj > 0) {
             TrackRec *rec = trk + L.slot[j];
+            const int rsize = cfg.seek_inner ? (rec->inner & 255) : cfg.ring;
             const double v3 = L.cen[j * 6 + 3], v4 = L.cen[j * 6 + 4], v5 = L.cen[j * 6 + 5];
             rec->is_static = sqrt((v3 * v3 + v4 * v4) + v5 * v5) < cfg.tr_vel_thres ? 1 : 0;
             // BatchedData.add_frame on the track ring (Tracking.py:43-51); the rows were written above.
@@ -585,7 +603,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
             int rn[MMW_RING_MAX], rs[MMW_RING_MAX];
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) { rn[k] = rec->ring_n[k]; rs[k] = rec->ring_slot[k]; }
-            while (len >= cfg.ring) {  // pop_frame: the freed physical slot becomes the first free entry
+            while (len >= rsize && len > 0) {  // pop_frame: the freed physical slot becomes the first free entry
                 const int first = rs[0];
 #pragma unroll
                 for (int k = 1; k < MMW_RING_MAX; k++) if (k < len) { rs[k - 1] = rs[k]; rn[k - 1] = rn[k]; }
@@ -598,6 +616,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) { rec->ring_n[k] = rn[k]; rec->ring_slot[k] = rs[k]; }
             rec->ring_len = len + 1;
+            if (cfg.seek_inner) rec->inner = rsize | kInnerTouched;  // k_inner runs seek_inner_clusters on it
         }
     }
     // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track, each the

@@ -25,6 +25,10 @@ size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
 size_t dbscan_only_lds_bytes(int UM);
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples);
 void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
+hipError_t prepare_inner(const DevCfg &cfg);
+size_t inner_lds_demand(const DevCfg &cfg);
+int inner_um(const DevCfg &cfg);
+void launch_inner(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int32_t *db_n, hipStream_t stream);
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
 void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
@@ -214,6 +218,18 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.ring = ring; d.db_min_samples = cfg->db_min_samples; d.tr_max_tracks = cfg->tr_max_tracks;
     d.kf_enable_est = cfg->kf_enable_est; d.model_min_input = cfg->model_min_input; d.dx = cfg->dim_x;
     d.ring_rows = cfg->ring_rows < 64 ? 64 : cfg->ring_rows;
+    d.seek_inner = cfg->seek_inner ? 1 : 0;
+    d.db_points_thres = cfg->db_points_thres; d.fb_frames_batch_static = cfg->fb_frames_batch_static;
+    d.db_spread_thres = cfg->db_spread_thres; d.db_inner_eps = cfg->db_inner_eps;
+    if (d.seek_inner) {
+        // seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
+        // ring*max_pts rows: frames are stored whole.  A ring of size 0 would never leave add_frame's loop (Tracking.py:47-48).
+        if (cfg->fb_frames_batch < 1 || cfg->fb_frames_batch_static < 1 || cfg->fb_frames_batch_static > ring) {
+            delete c;
+            return fail(nullptr, MMW_E_ARG, "seek_inner: FB_FRAMES_BATCH and FB_FRAMES_BATCH_STATIC must be in [1, FB_FRAMES_BATCH + 1 = %d]", ring);
+        }
+        if (d.ring_rows < ring * max_pts) d.ring_rows = ring * max_pts;
+    }
     int cap = cfg->track_cap;
     if (cap <= 0) {
         const int ms = cfg->db_min_samples > 0 ? cfg->db_min_samples : 1;
@@ -225,7 +241,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     // layout of the Kalman kernels (mmw_kalman.hpp: tracks_dense): laid out over tracks when the context holds more
     // four-track waves than this; 0 = the default threshold (one wave per CU x 4), < 0 = always per scene
     d.dense_min_units = cfg->kalman_dense_min_units == 0 ? 1024 : (cfg->kalman_dense_min_units < 0 ? 0x7fffffff : cfg->kalman_dense_min_units - 1);
-    d.pad0 = 0;
+    if (d.seek_inner) d.dense_min_units = 0x7fffffff;  // k_inner changes a scene's track count between k_track and k_post: per-scene layout
     d.db_z_weight = cfg->db_z_weight; d.db_range_weight = cfg->db_range_weight; d.db_eps = cfg->db_eps;
     d.tr_lifetime_dynamic = cfg->tr_lifetime_dynamic; d.tr_lifetime_static = cfg->tr_lifetime_static;
     d.tr_vel_thres = cfg->tr_vel_thres; d.tr_gate = cfg->tr_gate; d.kf_q_std = cfg->kf_q_std; d.kf_p_init = cfg->kf_p_init;
@@ -259,6 +275,12 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.upd_list, 2 * (size_t)(cap + 1) * S * sizeof(int32_t));
     ALLOC(c->st.spc_count, 2 * sizeof(int32_t));
     ALLOC(c->st.spc_list, 4 * S * sizeof(int32_t));
+    c->st.inner_buf = nullptr;
+    c->st.inner_cap = 0;
+    if (d.seek_inner) {
+        c->st.inner_cap = 2 * inner_um(d);
+        ALLOC(c->st.inner_buf, S * (size_t)(kInnerHdr + c->st.inner_cap) * sizeof(int32_t));
+    }
 #undef ALLOC
     c->st.default_posture = c->d_posture;
     c->st.stats = c->d_stats;
@@ -281,6 +303,11 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
     const size_t lds_a = track_lds_bytes(d);
     if (lds_a > 160 * 1024 || lds_b > 160 * 1024) { mmw_destroy(c); return fail(nullptr, MMW_E_ARG, "LDS demand too large (track %zu B, dbscan %zu B > 160 KiB)", lds_a, lds_b); }
+    if (d.seek_inner) {
+        if (inner_lds_demand(d) > 160 * 1024) { mmw_destroy(c); return fail(nullptr, MMW_E_ARG, "seek_inner: LDS demand too large (%zu B)", inner_lds_demand(d)); }
+        if (prepare_inner(d) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(k_inner) failed"); }
+        if (hipMemset(c->st.inner_buf, 0, S * (size_t)(kInnerHdr + c->st.inner_cap) * sizeof(int32_t)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
+    }
     hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap, cfg->db_min_samples);
     if (e1 != hipSuccess || e2 != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
     launch_reset(d, c->st, c->stream);
@@ -296,7 +323,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
@@ -414,6 +441,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     prof_arm(c, MMW_K_TRACK, ep);
     launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
     prof_armed_done(c, ep);
+    if (c->dc.seek_inner) launch_inner(c->dc, c->st, n_pts, db_n, c->stream);  // Tracking.py:656 active
     prof_arm(c, MMW_K_POST, ep);
     launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
@@ -633,6 +661,27 @@ int mmw_get_batch_ring_frame(mmw_ctx *c, int32_t scene, int32_t k, double *out, 
     HIPCHK(c, hipMemcpyAsync(out, src, (size_t)h.g_n[k] * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *n_rows = h.g_n[k];
+    return MMW_OK;
+}
+
+int mmw_get_inner(mmw_ctx *c, int32_t *n_calls, int32_t *rows, int32_t *labels, int32_t cap_labels)
+{
+    if (!c || !n_calls || cap_labels < 0) return MMW_E_ARG;
+    if (!c->dc.seek_inner) return fail(c, MMW_E_ARG, "mmw_get_inner: the context was created with seek_inner = 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t S = c->dc.n_scenes, W = kInnerHdr + c->st.inner_cap;
+    std::vector<int32_t> h(S * W);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->st.inner_buf, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t s = 0; s < S; s++) {
+        const int32_t *b = h.data() + s * W;
+        n_calls[s] = b[0];
+        if (rows) for (int k = 0; k < 16; k++) rows[s * 16 + k] = b[2 + k];
+        if (labels) {
+            const int m = b[1] < cap_labels ? b[1] : cap_labels;
+            memcpy(labels + s * (size_t)cap_labels, b + kInnerHdr, sizeof(int32_t) * (size_t)m);
+        }
+    }
     return MMW_OK;
 }
 

@@ -32,7 +32,9 @@ struct DevCfg {
     int32_t max_pts;
     int32_t n_scenes;
     int32_t dense_min_units;  // Kalman kernels laid out over tracks when the context has more 4-track waves than this (mmw_kalman.hpp)
-    int32_t pad0;
+    int32_t seek_inner;       // Tracking.py:656 active: seek_inner_clusters after every associate_pointcloud (k_inner)
+    int32_t db_points_thres, fb_frames_batch_static;
+    double db_spread_thres, db_inner_eps;
     double db_z_weight, db_range_weight, db_eps;
     double tr_lifetime_dynamic, tr_lifetime_static, tr_vel_thres, tr_gate;
     double kf_q_std, kf_p_init, kf_group_disp_est_init, kf_a_n, kf_est_pointnum;
@@ -76,8 +78,10 @@ struct TrackRec {
     int32_t ring_n[MMW_RING_MAX];
     int32_t ring_slot[MMW_RING_MAX];
     float kp[MMW_NKP];
-    float pad1;
+    int32_t inner;                 // seek_inner_clusters state (cfg.seek_inner only): bits 0..7 = track.batch.size (what
+                                   // BatchedData.change_buffer_size set, Tracking.py:60-64), bit 8 = associate_pointcloud ran this frame
 };
+constexpr int kInnerTouched = 256;
 static_assert(sizeof(TrackRec) == 187 * 8, "TrackRec");
 
 struct DevState {
@@ -96,7 +100,10 @@ struct DevState {
     int32_t *upd_list;             // [2][t_cap+1][S] ... and which ones: _update_all is laid out over the TRACKS, four per wave
     int32_t *spc_count;            // [2] by step parity: scenes the next k_predict cannot take from the update lists ...
     int32_t *spc_list;             // [2][S][2] ... (scene, first new track): scenes that spawned tracks this frame
+    int32_t *inner_buf;            // [S][kInnerHdr + inner_cap] seek_inner_clusters calls of the last frame (cfg.seek_inner; mmw_get_inner)
+    int32_t inner_cap;             // label words per scene
 };
+constexpr int kInnerHdr = 2 + 16;  // calls, labels stored, rows of the first 16 calls
 
 // Counters are spread over kStatSlots copies (one 256-byte line each, picked by scene index): thousands of
 // workgroups adding to ONE address serialise in the memory-side atomic unit and that tail was longer than

@@ -69,6 +69,12 @@ def test_golden_scenario(name):
         if o_lab is not None:
             assert np.array_equal(labels[0, : dbn[0]], o_lab)
         assert_tracks_match(trk, orc.tracks(), ctx=f"{name} f{f} vs oracle", exact=True)
+        if kw.get("seek_inner"):   # ClusterTrack.seek_inner_clusters: the calls of this frame, golden and oracle
+            calls = sb.inner_calls()[0]
+            assert len(calls) == int(g["inner_calls"][f]) == len(orc.inner_calls()), f"{name} f{f}: seek_inner_clusters calls"
+            for q, lab_in in enumerate(calls):
+                assert np.array_equal(lab_in, g["inner_labels"][f, q, : g["inner_n"][f, q]]), f"{name} f{f}: inner labels of call {q}"
+                assert np.array_equal(lab_in, orc.inner_calls()[q][1])
         feat, owner = sb.features_host()
         nf = int(g["n_feat"][f])
         assert len(owner) == nf
@@ -334,4 +340,52 @@ def test_error_paths_are_loud():
     with pytest.raises(_lib.MmwError) as ei:
         sb.step_dev(buf.ptr + 8, nb.ptr, db.ptr)
     assert ei.value.code == _lib.E_ARG
+    sb.close()
+
+
+def test_seek_inner_many_scenes_vs_oracle():
+    """ClusterTrack.seek_inner_clusters (Tracking.py:409-448, call site Tracking.py:656 active) over a batch: pairs of
+    people one outer cluster wide split into two tracks, standing pairs take the FB_FRAMES_BATCH_STATIC ring size, scenes
+    whose track list the inner tracks fill skip the frame's own apply_DBscan.  Ints, fp64 state, rings, inner labels
+    and features bit-equal to the oracle, which tests/test_oracle_golden.py pins on recordings of the reference."""
+    from mmwave_msc_amd.synth import make_pair_scene, make_scene
+    from oracle import c_oracle as co
+    S, N, F = 12, 256, 10
+    kw = dict(seek_inner=1, tr_max_tracks=3, fb_frames_batch_static=3)
+    ps, cs, ds = [], [], []
+    for s in range(S):
+        if s % 4 == 3:
+            p, c, d = make_scene(4000 + s, F, N, 2)                       # no pairs: calls that find one cluster
+        else:
+            p, c, d = make_pair_scene(4000 + s, F, N, 1 + s % 2, sep=0.7 + 0.1 * (s % 3), static=(s % 4 == 1))
+        ps.append(p); cs.append(c); ds.append(d)
+    pts, cnt, dts = np.stack(ps, 1), np.stack(cs, 1), np.stack(ds, 1)
+    sb = _mk(S, N, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    split = 0
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        calls = sb.inner_calls()
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=max(int(ntr.max()), 1))
+        for s in range(S):
+            oa, ol = scenes[s].track(pts[f, s].astype(np.float64), float(dts[f, s]))
+            assert np.array_equal(assoc[s], oa), (f, s)
+            assert (ol is None) == (dbn[s] < 0), (f, s, dbn[s])
+            if ol is not None:
+                assert np.array_equal(labels[s, : dbn[s]], ol), (f, s)
+            oc = scenes[s].inner_calls()
+            assert len(calls[s]) == len(oc), (f, s)
+            for a, (_, b) in zip(calls[s], oc):
+                assert np.array_equal(a, b), (f, s)
+                split += int(b.max() >= 1)
+            assert ntr[s] == scenes[s].n_tracks, (f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
+        feat, owner = sb.features_host()
+        ofeat = [scenes[s].features()[0] for s in range(S)]
+        ofeat = np.concatenate([x for x in ofeat if len(x)], axis=0)
+        assert np.array_equal(feat, ofeat), f
+    assert split >= 4, "no inner split happened: the scenario does not exercise the spawn"
+    sb.check()
     sb.close()
