@@ -360,19 +360,14 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         // split, see there): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
         if (tid <= T) {
             int phys = sd_rs[0];
-            if (cfg.seek_inner) {  // a ring whose size has shrunk pops more than one frame: run add_frame's loop on the copies
-                int len = sd_len;
-                while (len >= sd_size && len > 0) {
-                    const int first = sd_rs[0];
+            if (cfg.seek_inner) {
+                // a ring whose size has shrunk pops p > 1 frames (add_frame's loop, Tracking.py:47-48); each pop rotates the
+                // freed physical slot behind the live ones, so the new frame lands in the slot popped LAST (or, without a
+                // pop, in the first unused one)
+                const int keepn = sd_len < sd_size - 1 ? sd_len : (sd_size - 1 > 0 ? sd_size - 1 : 0);
+                const int want = sd_len > keepn ? sd_len - keepn - 1 : sd_len;
 #pragma unroll
-                    for (int k = 1; k < MMW_RING_MAX; k++) if (k < len) sd_rs[k - 1] = sd_rs[k];
-#pragma unroll
-                    for (int k = 0; k < MMW_RING_MAX; k++) if (k == len - 1) sd_rs[k] = first;
-                    len--;
-                }
-                phys = sd_rs[0];
-#pragma unroll
-                for (int k = 1; k < MMW_RING_MAX; k++) if (k == len) phys = sd_rs[k];
+                for (int k = 1; k < MMW_RING_MAX; k++) if (k == want) phys = sd_rs[k];
             } else {
 #pragma unroll
                 for (int k = 1; k < MMW_RING_MAX; k++) if (sd_len < cfg.ring && k == sd_len) phys = sd_rs[k];
