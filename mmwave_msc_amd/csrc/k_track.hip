@@ -186,7 +186,9 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 
 // PPT = points per thread = ceil(max_pts / 256): a template so that per-point registers are not
 // reserved for points a configuration can never have.
-template <int PPT>
+// INNER = mmw_config.seek_inner (per-track ring sizes, see k_inner in k_dbscan.hip): a template so that the default
+// instantiation carries none of it.
+template <int PPT, bool INNER>
 __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out,
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         if (tid < T) {
             const TrackRec *rec = trk + L.slot[tid];
             sd_len = rec->ring_len;
-            if (cfg.seek_inner) sd_size = rec->inner & 255;  // track.batch.size after change_buffer_size (Tracking.py:60-64)
+            if (INNER) sd_size = rec->inner & 255;  // track.batch.size after change_buffer_size (Tracking.py:60-64)
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = rec->ring_slot[k];
         } else if (tid == T) {
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         // split, see there): a full ring recycles its oldest slot (BatchedData.add_frame, Tracking.py:43-51)
         if (tid <= T) {
             int phys = sd_rs[0];
-            if (cfg.seek_inner) {
+            if (INNER) {
                 // a ring whose size has shrunk pops p > 1 frames (add_frame's loop, Tracking.py:47-48); each pop rotates the
                 // freed physical slot behind the live ones, so the new frame lands in the slot popped LAST (or, without a
                 // pop, in the first unused one)
@@ -586,10 +588,10 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     //  global round trips)
     for (int j = kThreads - 1 - tid; j < T; j += kThreads) {
         const int nj = L.cls_n[j + 1];
-        if (nj == 0 && cfg.seek_inner) trk[L.slot[j]].inner &= 255;  // associate_pointcloud did not run on this track
+        if (nj == 0 && INNER) trk[L.slot[j]].inner &= 255;  // associate_pointcloud did not run on this track
         if (nj > 0) {
             TrackRec *rec = trk + L.slot[j];
-            const int rsize = cfg.seek_inner ? (rec->inner & 255) : cfg.ring;
+            const int rsize = INNER ? (rec->inner & 255) : cfg.ring;
             const double v3 = L.cen[j * 6 + 3], v4 = L.cen[j * 6 + 4], v5 = L.cen[j * 6 + 5];
             rec->is_static = sqrt((v3 * v3 + v4 * v4) + v5 * v5) < cfg.tr_vel_thres ? 1 : 0;
             // BatchedData.add_frame on the track ring (Tracking.py:43-51); the rows were written above.
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) { rec->ring_n[k] = rn[k]; rec->ring_slot[k] = rs[k]; }
             rec->ring_len = len + 1;
-            if (cfg.seek_inner) rec->inner = rsize | kInnerTouched;  // k_inner runs seek_inner_clusters on it
+            if (INNER) rec->inner = rsize | kInnerTouched;  // k_inner runs seek_inner_clusters on it
         }
     }
     // _estimate_group_disp_matrix + _get_D (Tracking.py:270-297): 21 symmetric entries per track, each the
@@ -778,8 +780,12 @@ template <int PPT>
 static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                            int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
-    mmw_launch(k_track<PPT>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
-                       db_labels, UM, parity);
+    if (cfg.seek_inner)
+        mmw_launch(k_track<PPT, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
+                   db_labels, UM, parity);
+    else
+        mmw_launch(k_track<PPT, false>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
+                   db_labels, UM, parity);
 }
 
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
@@ -794,11 +800,13 @@ void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, cons
 hipError_t prepare_track(const DevCfg &cfg)
 {
     const int lds = (int)track_lds_bytes(cfg);
-    hipError_t e = hipFuncSetAttribute((const void *)k_track<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_track<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)k_track<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void *fns[6] = {(const void *)k_track<1, false>, (const void *)k_track<2, false>, (const void *)k_track<4, false>,
+                          (const void *)k_track<1, true>, (const void *)k_track<2, true>, (const void *)k_track<4, true>};
+    for (const void *f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace mmw
