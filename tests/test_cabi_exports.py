@@ -78,5 +78,8 @@ def test_step_kernels_compile_without_scratch():
     rep = out.stderr
     names = re.findall(r"Function Name: (\S*k_track\S*)", rep)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", rep)]
-    assert len(names) >= 3 and len(scratch) >= 3, rep[-2000:]
-    assert all(v == 0 for v in scratch[:len(names)]), list(zip(names, scratch))
+    assert len(names) >= 6 and len(scratch) >= 6, rep[-2000:]
+    # k_track<PPT, INNER>: the default instantiations (INNER = false, mangled "Lb0E") are the tuned hot path; the
+    # seek_inner ones (optional, Tracking.py:656 active) may keep an SGPR-spill stack slot the compiler never touches
+    default = [(n, v) for n, v in zip(names, scratch) if "Lb0E" in n]
+    assert len(default) == 3 and all(v == 0 for _, v in default), list(zip(names, scratch))
