@@ -69,6 +69,33 @@ def generate(scene_ids, frames, n_pts, tracks, workers):
     return np.ascontiguousarray(pts), np.ascontiguousarray(cnt), np.ascontiguousarray(dts)
 
 
+def effective_cores():
+    """CPUs this process may actually use: the smallest of the logical CPU count, the affinity mask and the cgroup
+    CPU quota (a container on a 256-thread host may be capped at 16 CPUs' worth of time: 256 busy processes then
+    only throttle each other)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]      # cgroup v2: "max 100000" or "1600000 100000"
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def cpu_legs(pts, cnt, dts, tracks, cores, W, py_scenes_per_core, py_frames, c_scenes):
     """CPU baselines on a bounded sample of the SAME workload and the SAME frame window as the GPU (frames
     W.. of every sampled scene; frames 0..W-1 advance the state untimed), before the GPU is touched.
@@ -244,7 +271,7 @@ def main():
     if S < 1:
         raise SystemExit(f"rank {rank}: no scenes to own ({S_total} scenes over {world} ranks)")
     F = K + W
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     single = world == 1 and rank == 0
 
     if args.dry_run:
@@ -495,7 +522,8 @@ def main():
             "work": {"dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(mean_U, 1),
                      "gate_evals_per_step": round(gate_evals / K, 1), "tracks_per_scene": round(mean_T, 2),
                      "clusters_found_per_step": round(float(stats[7]) / K, 2)},
-            "host": {"cores": cores, "gen_s": round(t_gen, 1)},
+            "host": {"cores": cores, "logical_cpus": os.cpu_count(), "gen_s": round(t_gen, 1),
+                     "note": "cores = min(logical CPUs, affinity mask, cgroup CPU quota): what the CPU baselines can really use"},
         }
         line.update(cpu)
         if parity is not None:
