@@ -37,6 +37,7 @@ extern "C" {
 #define MMW_NKP 57          /* 19 joints x (x,y,z)  (preprocessing.py:377) */
 #define MMW_MAX_PTS_LIMIT 1024
 #define MMW_TRACK_CAP_LIMIT 64
+#define MMW_EMPTY_FRAME (-1) /* n_pts value: TrackBuffer.track() on an empty point cloud (0 = frame skipped) */
 
 #define MMW_OK 0
 #define MMW_E_ARG (-1)        /* bad argument / size */
@@ -170,7 +171,9 @@ int mmw_normalize(mmw_ctx *ctx, const double *raw, const int32_t *n_raw, double 
 
 /* TrackBuffer.track(pointcloud, batch) for every scene (Tracking.py:664-703):
  *   pts[S][max_pts][8] fp64 (x,y,z,vx,vy,vz,doppler,peakVal), n_pts[S], dt[S] (= trackbuffer.dt).
- *   A scene with n_pts[s] == 0 is skipped entirely (offline_main.py:56).
+ *   A scene with n_pts[s] == 0 is skipped entirely (offline_main.py:56 never calls track() on an empty frame);
+ *   n_pts[s] == MMW_EMPTY_FRAME is track() called ON an empty point cloud: tracks are predicted, aged and expired,
+ *   _update_all runs, an empty frame enters the ring (what the reference does when a caller does call it).
  * Outputs (dev, each may be NULL):
  *   assoc[S][max_pts]      _calc_dist_fun result: -1 = None, else index into the
  *                          track list as it was BEFORE _maintain_tracks (Tracking.py:530-574)

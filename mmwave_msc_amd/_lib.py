@@ -22,6 +22,8 @@ MMW_OK = 0
 E_ARG, E_SINGULAR, E_DIVZERO, E_CAPACITY, E_HIP, E_NODEVICE = -1, -2, -3, -4, -5, -6
 K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE, K_PREDICT, K_POST = range(7)
 
+EMPTY_FRAME = -1   # MMW_EMPTY_FRAME (include/mmw.h)
+
 EXPORTS = [
     "mmw_config_default", "mmw_create", "mmw_destroy", "mmw_last_error", "mmw_reset", "mmw_pop_frame", "mmw_set_stream",
     "mmw_synchronize", "mmw_get_dims", "mmw_dev_alloc", "mmw_dev_free", "mmw_memcpy_h2d", "mmw_memcpy_d2h",

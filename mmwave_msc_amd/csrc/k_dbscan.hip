@@ -988,7 +988,7 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
     const int n = n_pts[s];
     int32_t *ib = st.inner_buf + (size_t)s * (kInnerHdr + st.inner_cap);
     if (tid < kInnerHdr) ib[tid] = 0;
-    if (n <= 0 || n > cfg.max_pts) return;  // the frame never reached track()
+    if (!frame_reaches_track(n, cfg.max_pts)) return;  // the frame never reached track()
     SceneHdr *hdr = st.hdr + s;
     int32_t *order = st.order + (size_t)s * cfg.t_cap;
     TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;

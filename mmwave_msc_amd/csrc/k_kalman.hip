@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
                 int s, j;
                 bool live = dense_pick(cfg, st, prev, B, unit, lane, g, s, j);
                 const int n = n_pts[s];
-                live = live && n > 0 && n <= cfg.max_pts;
+                live = live && frame_reaches_track(n, cfg.max_pts);
                 if (!__any(live)) continue;
                 TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? st.order[(size_t)s * cfg.t_cap + j] : 0);
                 int e1 = 0;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
         for (int i = (int)blockIdx.x - n_dense; i < count; i += kSpecialUnits) {
             const int s = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2], first = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2 + 1];
             const int n = n_pts[s];
-            if (n <= 0 || n > cfg.max_pts) continue;
+            if (!frame_reaches_track(n, cfg.max_pts)) continue;
             const int T = st.hdr[s].n_tracks;
             const int32_t *order = st.order + (size_t)s * cfg.t_cap;
             TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
             bool mine = false;
             if (sl < cfg.n_scenes) {
                 const int n = n_pts[sl];
-                mine = st.hdr[sl].skipped != 0 && st.hdr[sl].n_tracks > 0 && n > 0 && n <= cfg.max_pts;
+                mine = st.hdr[sl].skipped != 0 && st.hdr[sl].n_tracks > 0 && frame_reaches_track(n, cfg.max_pts);
             }
             unsigned long long todo = __ballot(mine);
             while (todo) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
     const int us = blockIdx.x / nq, q = blockIdx.x - us * nq;
     const int s = st.perm[(size_t)parity * cfg.n_scenes + us];  // heaviest scenes first (see k_track)
     const int n = n_pts[s];
-    if (n <= 0 || n > cfg.max_pts) return;  // offline_main.py:56: empty frames never reach track()
+    if (!frame_reaches_track(n, cfg.max_pts)) return;  // offline_main.py:56: empty frames never reach track()
     const SceneHdr *hdr = st.hdr + s;
     const int T = hdr->n_tracks;
     if (q * 4 >= T) return;

@@ -224,17 +224,18 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
             for (int u = 0; u < 4; u++) pr[q][u] = (i < NP) ? src2[i * 4 + u] : double2{0.0, 0.0};
         }
     }
-    const int n = n_pts[s];
+    const int n_raw = n_pts[s];
+    const int n = n_raw < 0 ? 0 : n_raw;  // MMW_EMPTY_FRAME: track() on an empty cloud
     SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
     if (s == 0 && tid == kThreads - 1) st.spc_count[parity ^ 1] = 0;
-    if (n <= 0 || n > NP) {  // offline_main.py:56: empty frames never reach track()
+    if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
             hdr->skipped = 1;  // not in this frame's update lists: the next k_predict finds its tracks by this flag
-            if (n < 0 || n > NP) atomicOr(&hdr->err, ERR_BADCOUNT);  // a count the context was not sized for
+            if (n_raw != 0) atomicOr(&hdr->err, ERR_BADCOUNT);  // a count the context was not sized for
         }
         return;
     }

@@ -105,6 +105,11 @@ struct DevState {
 };
 constexpr int kInnerHdr = 2 + 16;  // calls, labels stored, rows of the first 16 calls
 
+// n_pts[s] of a step: 1..max_pts = track() on that many points; 0 = the frame never reaches track() (offline_main.py:56
+// skips empty frames); MMW_EMPTY_FRAME (-1) = track() IS called, on an empty point cloud (the reference then predicts,
+// ages and expires tracks, runs _update_all and pushes an empty frame into the ring); anything else is ERR_BADCOUNT.
+__device__ __forceinline__ bool frame_reaches_track(int n, int max_pts) { return n != 0 && n >= -1 && n <= max_pts; }
+
 // Counters are spread over kStatSlots copies (one 256-byte line each, picked by scene index): thousands of
 // workgroups adding to ONE address serialise in the memory-side atomic unit and that tail was longer than
 // the kernels themselves.

@@ -207,7 +207,7 @@ __device__ __forceinline__ void update_tracks_wave(const DevCfg &cfg, const DevS
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int n = n_pts[s];
-    if (n <= 0 || n > cfg.max_pts) return;
+    if (!frame_reaches_track(n, cfg.max_pts)) return;
     const SceneHdr *hdr = st.hdr + s;
     const int T = hdr->n_upd;
     if (q * 4 >= T) return;

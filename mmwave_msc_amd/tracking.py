@@ -22,6 +22,7 @@ from typing import List
 
 import numpy as np
 
+from . import _lib
 from . import constants as const
 from .batch import SceneBatch
 
@@ -152,7 +153,9 @@ class TrackBuffer:
             raise ValueError(f"frame has {n} points; TrackBuffer(max_pts={self._max_pts})")
         pts = np.zeros((1, self._max_pts, 8))
         pts[0, :n] = pc
-        assoc, labels, dbn = sb.step_host(pts, np.array([n], np.int32), np.array([float(self.dt)]))
+        # an empty cloud still IS a track() call (predict, ageing / expiry, _update_all, an empty ring frame): the C-ABI's
+        # count 0 means "frame skipped" (offline_main.py:56), MMW_EMPTY_FRAME means this
+        assoc, labels, dbn = sb.step_host(pts, np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]))
         self.last_assoc = assoc[0, :n].copy()
         self.last_db_labels = labels[0, : dbn[0]].copy() if dbn[0] >= 0 else None
         self._tracks_cache = None

@@ -51,6 +51,9 @@ SCENARIOS = {
     "clutter_only": dict(seed=111, N=400, K=0, F=5, over={}),
     "fb0": dict(seed=112, N=128, K=2, F=16, over={"FB_FRAMES_BATCH": 0}),
     "empty_frames": dict(seed=113, N=96, K=1, F=16, over={}, zero_frames=(3, 9)),
+    # track() CALLED on empty point clouds (offline_main.py:56 never does; a drop-in caller may): long enough runs of them
+    # for the dynamic track to expire (TR_LIFETIME_DYNAMIC = 3 s) while the ring empties
+    "empty_tracked": dict(seed=120, N=128, K=2, F=60, over={"TRACK_EMPTY": True}, zero_frames=tuple(range(8, 12)) + tuple(range(20, 54))),
     "kf_est": dict(seed=114, N=128, K=2, F=20, over={"KF_ENABLE_EST": True}, presence="flicker"),
     "max_size": dict(seed=115, N=640, K=0, F=4, over={}),
     # ClusterTrack.seek_inner_clusters with its call site (Tracking.py:656) active: pairs of people one outer cluster wide
@@ -100,7 +103,7 @@ def gen_scenario(name, sc):
     const, _, _ = load_reference()
     if "MOTION_MODEL" in over:
         over["MOTION_MODEL"] = getattr(const, over["MOTION_MODEL"])
-    ref = RefScene(over)
+    ref = RefScene({k2: v for k2, v in over.items() if k2 != "TRACK_EMPTY"})
     ring = ref.const.FB_FRAMES_BATCH + 1
     tmax = 0
     rec = dict(assoc=np.full((f, n), -2, np.int16), db_n=np.full(f, -1, np.int32),
@@ -112,7 +115,7 @@ def gen_scenario(name, sc):
                    inner_labels=np.full((f, 8, ring * n), -2, np.int16), ring_size=np.zeros((f, 16), np.int32))
     tracks, feats, owners = [], [], []
     for i in range(f):
-        if cnt[i] == 0:
+        if cnt[i] == 0 and not over.get("TRACK_EMPTY"):
             # offline_main.py:56 skips track()/estimate_posture() for empty frames
             rec["n_tracks"][i] = ref.n_tracks
             rec["ring_len"][i] = len(ref.batch_ring())

@@ -35,6 +35,14 @@ def load_scenario(name):
     return d
 
 
+def scenario_tol(g):
+    """fp64 tolerance against the recording of a scenario.  Runs of measurement-free frames (track() on empty clouds:
+    the reference keeps updating with the stale centroid) multiply ULP-level differences by 1.5-2x per frame -- 3e-9
+    after 28 such frames in `empty_tracked` --, so those scenarios are compared at 1e-7; integers stay exact and the GPU
+    still equals the C oracle bit for bit."""
+    return 1e-7 if g["overrides"].get("TRACK_EMPTY") else F64_TOL
+
+
 def close64(a, b, tol=F64_TOL):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -66,6 +74,8 @@ def overrides_to_cfg_kwargs(over):
             kw["fb_frames_batch"] = int(v)
         elif k == "KF_ENABLE_EST":
             kw["kf_enable_est"] = int(bool(v))
+        elif k == "TRACK_EMPTY":
+            pass   # not a constant: the scenario calls track() on its empty frames (see tests)
         elif k == "SEEK_INNER":
             kw["seek_inner"] = int(bool(v))
         elif k == "FB_FRAMES_BATCH_STATIC":

@@ -194,3 +194,23 @@ def test_batcheddata_pop_frame_matches_reference_recording():
         got = np.asarray(eff, dtype=np.float64).reshape(-1, 8) if n else np.zeros((0, 8))
         assert np.array_equal(got, g["ring_rows"][f, :n]), f
     tb.close()
+
+
+def test_trackbuffer_track_on_an_empty_cloud_is_a_real_call():
+    """TrackBuffer.track(empty) is not a no-op in the reference (Tracking.py:664-703 on an empty array: predict, lifetime
+    += dt, expiry, _update_all, an empty frame pushed into the ring); the golden `empty_tracked` holds such a run."""
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    g = load_scenario("empty_tracked")
+    tb, batch = TrackBuffer(max_pts=128), BatchedData()
+    for f in range(52):
+        c = int(g["cnt"][f])
+        tb.dt = float(g["dt"][f])
+        tb.track(g["pts"][f, :c].astype(np.float64) if c else np.empty((0, 8)), batch)
+        nt = int(g["n_tracks"][f])
+        tracks = tb.effective_tracks
+        assert len(tracks) == nt, f
+        for j, t in enumerate(tracks):
+            assert t.lifetime == g["tracks"][f, j]["lifetime"] and t.cluster.point_num == g["tracks"][f, j]["point_num"]
+        assert [len(fr) for fr in batch.buffer] == list(g["ring_n"][f, : g["ring_len"][f]])
+    assert len(tb.effective_tracks) == 0 and g["n_tracks"][48] == 2   # both tracks expired during the empty run
+    tb.close()
