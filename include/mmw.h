@@ -148,6 +148,14 @@ int mmw_reset(mmw_ctx *ctx);
 /* BatchedData.pop_frame() (Tracking.py:66-71; its caller is preprocessing.py:264): drop the oldest frame of the global
  * ring of every scene whose flag is non-zero (host array of n_scenes words; NULL = every scene). */
 int mmw_pop_frame(mmw_ctx *ctx, const int32_t *scene_flags);
+/* BatchedData.change_buffer_size(new_size) (Tracking.py:60-64) on the global ring of the flagged scenes (host array of
+ * n_scenes words; NULL = every scene): from the next add_frame on, frames are popped while len >= new_size.  Sizes
+ * above FB_FRAMES_BATCH + 1 act like it (the reference's deque has that maxlen); new_size < 1 is MMW_E_ARG (the
+ * reference's add_frame would never terminate).  mmw_reset restores the default. */
+int mmw_set_batch_size(mmw_ctx *ctx, const int32_t *scene_flags, int32_t new_size);
+/* BatchedData(init_data) (Tracking.py:38-41): the global ring of `scene` becomes ONE frame holding rows[n][8] (host,
+ * n <= max_pts) instead of the empty frame a default BatchedData() starts with.  Sync. */
+int mmw_set_batch_frame(mmw_ctx *ctx, int32_t scene, const double *rows, int32_t n);
 /* Run on a caller-owned hipStream_t; NULL = the context's own (non-blocking) stream.
  * Note for callers that share device buffers with another runtime: calls on DEVICE pointers are ordered with that
  * runtime's work only if both use the same stream.  torch reports the legacy default stream as

@@ -32,6 +32,7 @@ EXPORTS = [
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
+    "mmw_set_batch_size", "mmw_set_batch_frame",
 ]
 
 
@@ -152,6 +153,8 @@ def load():
         "mmw_features_wait": (C.c_int, [vp, i32, i32p]),
         "mmw_set_keypoints_uid": (C.c_int, [vp, vp, vp, vp, i32]),
         "mmw_get_inner": (C.c_int, [vp, vp, vp, vp, i32]),
+        "mmw_set_batch_size": (C.c_int, [vp, vp, i32]),
+        "mmw_set_batch_frame": (C.c_int, [vp, i32, vp, i32]),
         "mmw_check": (C.c_int, [vp]),
         "mmw_get_num_tracks": (C.c_int, [vp, vp]),
         "mmw_get_tracks": (C.c_int, [vp, vp, i32]),

@@ -121,6 +121,20 @@ class SceneBatch:
         flags[np.asarray(scenes, dtype=np.int64)] = 1
         self._chk(self.L.mmw_pop_frame(self.h, flags.ctypes.data))
 
+    def set_batch_size(self, new_size: int, scenes=None):
+        """BatchedData.change_buffer_size(new_size) on the global ring of the given scenes (default: all)."""
+        if scenes is None:
+            self._chk(self.L.mmw_set_batch_size(self.h, None, int(new_size)))
+            return
+        flags = np.zeros(self.S, dtype=np.int32)
+        flags[np.asarray(scenes, dtype=np.int64)] = 1
+        self._chk(self.L.mmw_set_batch_size(self.h, flags.ctypes.data, int(new_size)))
+
+    def set_batch_frame(self, scene: int, rows: np.ndarray):
+        """BatchedData(init_data): the scene's global ring becomes one frame holding `rows` (n, 8)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 8)
+        self._chk(self.L.mmw_set_batch_frame(self.h, int(scene), rows.ctypes.data, len(rows)))
+
     def reset(self):
         self._chk(self.L.mmw_reset(self.h))
 

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
             bool mine = false;
             if (sl < cfg.n_scenes) {
                 const int n = n_pts[sl];
-                mine = st.hdr[sl].skipped != 0 && st.hdr[sl].n_tracks > 0 && frame_reaches_track(n, cfg.max_pts);
+                mine = (st.hdr[sl].skipped & 1) != 0 && st.hdr[sl].n_tracks > 0 && frame_reaches_track(n, cfg.max_pts);
             }
             unsigned long long todo = __ballot(mine);
             while (todo) {

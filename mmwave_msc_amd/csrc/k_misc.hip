@@ -386,6 +386,19 @@ __global__ void k_pop_frame(DevCfg cfg, DevState st, const int32_t *__restrict__
     hdr->g_n[len - 1] = 0;
     hdr->g_len = len - 1;
 }
+// BatchedData.change_buffer_size (Tracking.py:60-64) on the global ring of the flagged scenes: from the next
+// add_frame on, frames are popped while len >= new_size.
+__global__ void k_set_batch_size(DevCfg cfg, DevState st, const int32_t *__restrict__ flags, int new_size)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cfg.n_scenes || (flags && !flags[s])) return;
+    SceneHdr *hdr = st.hdr + s;
+    hdr->skipped = (hdr->skipped & 255) | (new_size << 8);
+}
+void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_set_batch_size, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, flags, new_size);
+}
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st)
 {
     hipLaunchKernelGGL(k_pop_frame, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, flags);

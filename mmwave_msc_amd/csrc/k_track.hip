@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
-            hdr->skipped = 1;  // not in this frame's update lists: the next k_predict finds its tracks by this flag
+            hdr->skipped = INNER ? ((hdr->skipped & ~255) | 1) : 1;  // not in this frame's update lists: the next k_predict finds its tracks by this flag
             if (n_raw != 0) atomicOr(&hdr->err, ERR_BADCOUNT);  // a count the context was not sized for
         }
         return;
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = rec->ring_slot[k];
         } else if (tid == T) {
             sd_len = hdr->g_len;
+            if (INNER && (hdr->skipped >> 8)) sd_size = hdr->skipped >> 8;  // BatchedData.change_buffer_size on the global ring
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = hdr->g_slot[k];
         }
@@ -413,7 +414,8 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         int len = hdr->g_len;
         int *gs = L.misc + 4, *gn = L.misc + 8;  // small indexed arrays live in LDS, not in scratch
         for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
-        while (len >= cfg.ring) {
+        const int gsz = (INNER && (hdr->skipped >> 8)) ? (hdr->skipped >> 8) : cfg.ring;
+        while (len >= gsz && len > 0) {
             const int first = gs[0];
             for (int k = 1; k < len; k++) { gs[k - 1] = gs[k]; gn[k - 1] = gn[k]; }
             gs[len - 1] = first;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
         const int U = L.misc[13];
         hdr->n_tracks = T;
         hdr->n_upd = T;
-        hdr->skipped = 0;
+        hdr->skipped = INNER ? (hdr->skipped & ~255) : 0;
         // this scene's tracks join the update list of their count (k_post lays _update_all out over tracks): the
         // slot is requested here and written at the very end of the kernel -- the atomic's round trip (a microsecond
         // under 4096 workgroups) must not sit in front of the screen below
@@ -781,7 +783,7 @@ template <int PPT>
 static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                            int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
-    if (cfg.seek_inner)
+    if (cfg.seek_inner || cfg.var_ring)
         mmw_launch(k_track<PPT, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
                    db_labels, UM, parity);
     else

@@ -43,6 +43,7 @@ void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, 
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
 void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st);
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
+void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
                       hipStream_t stream);
 }  // namespace mmw
@@ -221,6 +222,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.seek_inner = cfg->seek_inner ? 1 : 0;
     d.db_points_thres = cfg->db_points_thres; d.fb_frames_batch_static = cfg->fb_frames_batch_static;
     d.db_spread_thres = cfg->db_spread_thres; d.db_inner_eps = cfg->db_inner_eps;
+    d.var_ring = 0; d.pad1 = 0;
     if (d.seek_inner) {
         // seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
         // ring*max_pts rows: frames are stored whole.  A ring of size 0 would never leave add_frame's loop (Tracking.py:47-48).
@@ -339,6 +341,7 @@ int mmw_reset(mmw_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     launch_reset(c->dc, c->st, c->stream);
     HIPCHK(c, hipGetLastError());
+    c->dc.var_ring = 0;   // fresh BatchedData objects: default sizes again
     return MMW_OK;
 }
 
@@ -354,6 +357,43 @@ int mmw_pop_frame(mmw_ctx *c, const int32_t *scene_flags)
     launch_pop_frame(c->dc, c->st, d_flags, c->stream);
     HIPCHK(c, hipGetLastError());
     if (scene_flags) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's array may go away
+    return MMW_OK;
+}
+
+int mmw_set_batch_size(mmw_ctx *c, const int32_t *scene_flags, int32_t new_size)
+{
+    if (!c) return MMW_E_ARG;
+    // a deque(maxlen = FB_FRAMES_BATCH + 1) never holds more than that whatever `size` says; size <= 0 would never leave
+    // add_frame's `while len(buffer) >= size: pop_frame()` in the reference
+    if (new_size < 1) return fail(c, MMW_E_ARG, "mmw_set_batch_size: new_size = %d (BatchedData.add_frame would not terminate)", new_size);
+    if (new_size > c->dc.ring) new_size = c->dc.ring;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int32_t *d_flags = nullptr;
+    if (scene_flags) {
+        HIPCHK(c, hipMemcpyAsync(c->d_row_off, scene_flags, sizeof(int32_t) * c->dc.n_scenes, hipMemcpyHostToDevice, c->stream));
+        d_flags = c->d_row_off;
+    }
+    launch_set_batch_size(c->dc, c->st, d_flags, new_size, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (scene_flags) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->dc.var_ring = 1;
+    return MMW_OK;
+}
+
+int mmw_set_batch_frame(mmw_ctx *c, int32_t scene, const double *rows, int32_t n)
+{
+    if (!c || scene < 0 || scene >= c->dc.n_scenes || n < 0 || n > c->dc.max_pts || (n > 0 && !rows)) return fail(c, MMW_E_ARG, "mmw_set_batch_frame: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    SceneHdr h;
+    HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    h.g_len = 1;
+    for (int k = 0; k < MMW_RING_MAX; k++) h.g_n[k] = 0;
+    h.g_n[0] = n;
+    double *dst = c->st.g_ring + ((size_t)scene * c->dc.ring + h.g_slot[0]) * (size_t)c->dc.max_pts * 8;
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(dst, rows, (size_t)n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st.hdr + scene, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
 }
 

@@ -34,6 +34,7 @@ struct DevCfg {
     int32_t dense_min_units;  // Kalman kernels laid out over tracks when the context has more 4-track waves than this (mmw_kalman.hpp)
     int32_t seek_inner;       // Tracking.py:656 active: seek_inner_clusters after every associate_pointcloud (k_inner)
     int32_t db_points_thres, fb_frames_batch_static;
+    int32_t var_ring, pad1;   // a global ring size was changed (mmw_set_batch_size): k_track reads ring sizes from the headers
     double db_spread_thres, db_inner_eps;
     double db_z_weight, db_range_weight, db_eps;
     double tr_lifetime_dynamic, tr_lifetime_static, tr_vel_thres, tr_gate;
@@ -56,7 +57,8 @@ struct SceneHdr {
     int32_t db_u;
     int32_t next_uid;              // TrackBuffer.next_track_id (Tracking.py:509,588)
     int32_t n_upd;                 // tracks after _maintain_tracks of this frame = what _update_all covers (k_track -> k_post)
-    int32_t skipped;               // the last frame was empty for this scene (k_track returned at once): its tracks are in no update list
+    int32_t skipped;               // bit 0: the last frame was empty for this scene (k_track returned at once): its tracks are in no update list;
+                                   // bits 8..15: size of the global ring after BatchedData.change_buffer_size (0 = FB_FRAMES_BATCH + 1)
 };
 static_assert(sizeof(SceneHdr) == 64, "SceneHdr");
 

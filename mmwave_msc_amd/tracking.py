@@ -36,15 +36,30 @@ class BatchedData:
 
     def __init__(self, init_data=None):
         self._owner = None   # bound TrackBuffer
+        # BatchedData(init_data) (Tracking.py:38-41): the ring starts with this frame instead of an empty one; it is
+        # uploaded when a TrackBuffer binds the object (its first track() call)
         self._init = None if init_data is None else np.asarray(init_data, dtype=np.float64).reshape(-1, 8)
-        if self._init is not None and len(self._init):
-            raise NotImplementedError("a pre-filled global BatchedData is not supported by the GPU path")
         self.size = const.FB_FRAMES_BATCH + 1
+        self._size_changed = False
+
+    def _bind(self, owner):
+        self._owner = owner
+        if self._init is not None and len(self._init):
+            owner._sb.set_batch_frame(0, self._init)
+        if self._size_changed:
+            owner._sb.set_batch_size(self.size, [0])
+
+    def change_buffer_size(self, new_size):
+        """Tracking.py:60-64: from the next add_frame on, frames are popped while len(buffer) >= new_size."""
+        self.size = new_size
+        self._size_changed = True
+        if self._owner is not None and self._owner._sb is not None:
+            self._owner._sb.set_batch_size(int(new_size), [0])
 
     @property
     def buffer(self):
         if self._owner is None or self._owner._sb is None:
-            return [np.empty((0, 8))]
+            return [np.empty((0, 8)) if self._init is None else self._init.copy()]
         sb = self._owner._sb
         ln, _ = sb.batch_ring()
         return [sb.batch_ring_frame(0, k) for k in range(int(ln[0]))]
@@ -144,7 +159,7 @@ class TrackBuffer:
         sb = self._ensure()
         if self._batch is None:
             self._batch = batch
-            batch._owner = self
+            batch._bind(self)
         elif batch is not self._batch:
             raise ValueError("this TrackBuffer is bound to another BatchedData (one global ring per scene)")
         pc = np.asarray(pointcloud, dtype=np.float64).reshape(-1, 8)

@@ -41,6 +41,7 @@ struct orc_scene {
     int n_tracks;
     trk_t *tracks;
     /* global BatchedData (Tracking.py:21-71) */
+    int g_size;                      /* batch.size: FB_FRAMES_BATCH + 1 until change_buffer_size */
     int g_len;
     int32_t g_n[ORC_RING_MAX];
     double *g_frame[ORC_RING_MAX]; /* each [max_pts][8] */
@@ -247,6 +248,7 @@ void orc_scene_reset(orc_scene *s)
 {
     s->n_tracks = 0;
     s->g_len = 1;
+    s->g_size = s->ring_size;
     s->inner_calls = 0;
     s->overflow = 0;
     memset(s->g_n, 0, sizeof(s->g_n));
@@ -729,11 +731,29 @@ void orc_pop_frame(orc_scene *s)
     s->g_len--;
 }
 
+/* BatchedData.change_buffer_size on the global ring (Tracking.py:60-64); the deque keeps maxlen FB_FRAMES_BATCH + 1 */
+int orc_set_batch_size(orc_scene *s, int new_size)
+{
+    if (new_size < 1) return -1;
+    s->g_size = new_size > s->ring_size ? s->ring_size : new_size;
+    return 0;
+}
+/* BatchedData(init_data) (Tracking.py:38-41): one frame holding rows[n][8] */
+int orc_set_batch_frame(orc_scene *s, const double *rows, int n)
+{
+    if (n < 0 || n > s->max_pts) return -1;
+    s->g_len = 1;
+    memset(s->g_n, 0, sizeof(s->g_n));
+    s->g_n[0] = n;
+    if (n > 0) memcpy(s->g_frame[0], rows, sizeof(double) * 8 * (size_t)n);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* BatchedData.add_frame on the global ring Tracking.py:43-51 */
 static void global_ring_push(orc_scene *s, const double *rows, int n)
 {
-    while (s->g_len >= s->ring_size) {
+    while (s->g_len >= s->g_size && s->g_len > 0) {
         double *first = s->g_frame[0];
         for (int k = 1; k < s->g_len; k++) { s->g_frame[k - 1] = s->g_frame[k]; s->g_n[k - 1] = s->g_n[k]; }
         s->g_frame[s->g_len - 1] = first;

@@ -115,6 +115,8 @@ def lib():
     L.orc_num_tracks.argtypes = [vp]
     L.orc_get_tracks.argtypes = [vp, C.c_void_p, C.c_int]
     L.orc_get_batch_ring.argtypes = [vp, i32p]
+    L.orc_set_batch_size.argtypes = [vp, C.c_int]
+    L.orc_set_batch_frame.argtypes = [vp, f64p, C.c_int]
     L.orc_get_inner.argtypes = [vp, i32p, i32p, i32p, C.c_int, C.c_int]
     L.orc_get_track_ring_size.argtypes = [vp, C.c_int]
     L.orc_pop_frame.argtypes = [vp]
@@ -224,6 +226,15 @@ class OracleScene:
         out = np.zeros(max(n, 1), dtype=TRACK_DTYPE)
         self.L.orc_get_tracks(self.h, out.ctypes.data_as(C.c_void_p), n)
         return out[:n]
+
+    def set_batch_size(self, new_size: int):
+        if self.L.orc_set_batch_size(self.h, int(new_size)):
+            raise ValueError(new_size)
+
+    def set_batch_frame(self, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 8)
+        if self.L.orc_set_batch_frame(self.h, _p(rows, C.c_double), len(rows)):
+            raise ValueError(len(rows))
 
     def inner_calls(self):
         """seek_inner_clusters calls of the last frame: list of (pre-maintenance track position, labels[n])."""

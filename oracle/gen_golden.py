@@ -56,6 +56,9 @@ SCENARIOS = {
     "empty_tracked": dict(seed=120, N=128, K=2, F=60, over={"TRACK_EMPTY": True}, zero_frames=tuple(range(8, 12)) + tuple(range(20, 54))),
     "kf_est": dict(seed=114, N=128, K=2, F=20, over={"KF_ENABLE_EST": True}, presence="flicker"),
     "max_size": dict(seed=115, N=640, K=0, F=4, over={}),
+    # BatchedData(init_data) (Tracking.py:38-41) and BatchedData.change_buffer_size (Tracking.py:60-64) on the GLOBAL ring:
+    # the ring starts with 40 clutter rows, shrinks to size 2 before frame 6 and to 1 before frame 14, back to 3 at 20
+    "batch_init_resize": dict(seed=121, N=160, K=2, F=26, over={"BATCH_INIT": 40, "BATCH_RESIZE": [[6, 2], [14, 1], [20, 3]]}, presence="flicker"),
     # ClusterTrack.seek_inner_clusters with its call site (Tracking.py:656) active: pairs of people one outer cluster wide
     "inner_pair": dict(seed=116, N=256, K=1, F=14, over={"SEEK_INNER": True}, pairs=dict(sep=0.8)),
     "inner_static": dict(seed=117, N=256, K=1, F=12, over={"SEEK_INNER": True, "FB_FRAMES_BATCH_STATIC": 3}, pairs=dict(sep=0.9, static=True)),
@@ -103,7 +106,11 @@ def gen_scenario(name, sc):
     const, _, _ = load_reference()
     if "MOTION_MODEL" in over:
         over["MOTION_MODEL"] = getattr(const, over["MOTION_MODEL"])
-    ref = RefScene({k2: v for k2, v in over.items() if k2 != "TRACK_EMPTY"})
+    init_rows = None
+    if "BATCH_INIT" in over:   # the rows BatchedData(init_data) starts with: clutter of another seed
+        init_rows = make_scene(sc["seed"] + 500, 1, int(over["BATCH_INIT"]), 0)[0][0].astype(np.float64)
+    resize = {int(a): int(b) for a, b in over.get("BATCH_RESIZE", [])}
+    ref = RefScene({k2: v for k2, v in over.items() if k2 not in ("TRACK_EMPTY", "BATCH_INIT", "BATCH_RESIZE")}, init_data=init_rows)
     ring = ref.const.FB_FRAMES_BATCH + 1
     tmax = 0
     rec = dict(assoc=np.full((f, n), -2, np.int16), db_n=np.full(f, -1, np.int32),
@@ -124,6 +131,8 @@ def gen_scenario(name, sc):
             feats.append(None)
             owners.append(None)
             continue
+        if i in resize:
+            ref.batch.change_buffer_size(resize[i])
         a, lab = ref.track(pts[i, : cnt[i]].astype(np.float64), float(dt[i]))
         rec["assoc"][i, : cnt[i]] = a
         if lab is not None:
@@ -163,6 +172,8 @@ def gen_scenario(name, sc):
                 feat[i, : len(owners[i])] = feats[i]
                 owner[i, : len(owners[i])] = owners[i]
     over_json = {k2: (v.__name__ if hasattr(v, "__name__") else v) for k2, v in over.items()}
+    if init_rows is not None:
+        rec["batch_init"] = init_rows
     np.savez_compressed(
         os.path.join(GOLDEN_DIR, f"track_{name}.npz"), pts=pts, cnt=cnt, dt=dt, tracks=trk,
         feat=feat, n_feat=n_feat, owner=owner, overrides=json.dumps(over_json), meta=_meta(), **rec)

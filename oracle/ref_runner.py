@@ -74,7 +74,7 @@ def _install_hooks(utils, tracking):
 
 
 class RefScene:
-    def __init__(self, overrides=None):
+    def __init__(self, overrides=None, init_data=None):
         self.const, self.utils, self.tracking = load_reference()
         _install_hooks(self.utils, self.tracking)
         self._saved = {}
@@ -86,7 +86,7 @@ class RefScene:
             self._saved[k] = getattr(self.const, k)
             setattr(self.const, k, v)
         self.tb = self.tracking.TrackBuffer()
-        self.batch = self.tracking.BatchedData()
+        self.batch = self.tracking.BatchedData() if init_data is None else self.tracking.BatchedData(np.asarray(init_data, dtype=np.float64))
 
     def close(self):
         for k, v in self._saved.items():

@@ -74,7 +74,7 @@ def overrides_to_cfg_kwargs(over):
             kw["fb_frames_batch"] = int(v)
         elif k == "KF_ENABLE_EST":
             kw["kf_enable_est"] = int(bool(v))
-        elif k == "TRACK_EMPTY":
+        elif k in ("TRACK_EMPTY", "BATCH_INIT", "BATCH_RESIZE"):
             pass   # not a constant: the scenario calls track() on its empty frames (see tests)
         elif k == "SEEK_INNER":
             kw["seek_inner"] = int(bool(v))

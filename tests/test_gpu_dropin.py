@@ -214,3 +214,42 @@ def test_trackbuffer_track_on_an_empty_cloud_is_a_real_call():
         assert [len(fr) for fr in batch.buffer] == list(g["ring_n"][f, : g["ring_len"][f]])
     assert len(tb.effective_tracks) == 0 and g["n_tracks"][48] == 2   # both tracks expired during the empty run
     tb.close()
+
+
+def test_batcheddata_init_data_and_change_buffer_size():
+    """BatchedData(init_data) (Tracking.py:38-41) and BatchedData.change_buffer_size (Tracking.py:60-64) through the
+    reference-shaped objects, against the recording `batch_init_resize` of the reference doing the same."""
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    g = load_scenario("batch_init_resize")
+    resize = {int(a): int(b) for a, b in g["overrides"]["BATCH_RESIZE"]}
+    tb, batch = TrackBuffer(max_pts=160), BatchedData(g["batch_init"])
+    assert [len(fr) for fr in batch.buffer] == [40] and batch.effective_data.shape == (40, 8)   # before any track()
+    for f in range(g["pts"].shape[0]):
+        c = int(g["cnt"][f])
+        if f in resize:
+            batch.change_buffer_size(resize[f])
+            assert batch.size == resize[f]
+        tb.dt = float(g["dt"][f])
+        tb.track(g["pts"][f, :c].astype(np.float64), batch)
+        assert np.array_equal(tb.last_assoc, g["assoc"][f, :c]), f
+        dbn = int(g["db_n"][f])
+        assert (tb.last_db_labels is None) == (dbn < 0)
+        if dbn >= 0:
+            assert np.array_equal(tb.last_db_labels, g["labels"][f, :dbn]), f
+        assert len(tb.effective_tracks) == g["n_tracks"][f]
+        assert [len(fr) for fr in batch.buffer] == list(g["ring_n"][f, : g["ring_len"][f]]), f
+    tb.close()
+    # a size change BEFORE the first track() call is applied when the TrackBuffer binds the object
+    tb, batch = TrackBuffer(max_pts=160), BatchedData()
+    batch.change_buffer_size(1)
+    for f in range(4):
+        tb.dt = 0.1
+        tb.track(g["pts"][f, : int(g["cnt"][f])].astype(np.float64), batch)
+        assert len(batch.buffer) <= 1
+    tb.close()
+    with pytest.raises(Exception):
+        batch2 = BatchedData()
+        tb2 = TrackBuffer(max_pts=64)
+        tb2.dt = 0.1
+        tb2.track(g["pts"][0, :32].astype(np.float64), batch2)
+        batch2.change_buffer_size(0)   # the reference's add_frame would spin forever: MMW_E_ARG here

@@ -42,8 +42,15 @@ def test_golden_scenario(name):
     n = g["pts"].shape[1]
     sb = _mk(1, n, **kw)
     orc = co.OracleScene(co.default_config(**kw), n)
+    if "batch_init" in g:   # BatchedData(init_data) (Tracking.py:38-41)
+        sb.set_batch_frame(0, g["batch_init"])
+        orc.set_batch_frame(g["batch_init"])
+    resize = {int(a): int(b) for a, b in g["overrides"].get("BATCH_RESIZE", [])}
     for f in range(g["pts"].shape[0]):
         c = int(g["cnt"][f])
+        if f in resize:     # BatchedData.change_buffer_size (Tracking.py:60-64) before this frame's track()
+            sb.set_batch_size(resize[f])
+            orc.set_batch_size(resize[f])
         pts = np.zeros((1, n, 8))
         pts[0, :c] = g["pts"][f, :c]
         track_empty = bool(g["overrides"].get("TRACK_EMPTY"))   # the scenario calls track() on its empty frames

@@ -18,8 +18,13 @@ def test_tracker_matches_reference_golden(name):
     cfg = co.default_config(**kw)
     sc = co.OracleScene(cfg, n)
     ring = cfg.fb_frames_batch + 1
+    if "batch_init" in g:   # BatchedData(init_data)
+        sc.set_batch_frame(g["batch_init"])
+    resize = {int(a): int(b) for a, b in g["overrides"].get("BATCH_RESIZE", [])}
     for f in range(g["pts"].shape[0]):
         c = int(g["cnt"][f])
+        if f in resize:     # BatchedData.change_buffer_size before this frame's track()
+            sc.set_batch_size(resize[f])
         if c == 0 and not g["overrides"].get("TRACK_EMPTY"):  # offline_main.py:56: empty frames never reach track()
             continue
         assoc, labels = sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
