@@ -41,7 +41,7 @@ constexpr int kProbeScene = 1234;
 #define PROBE(id)
 #endif
 
-constexpr int kGateStride = 44;   // per track: Ci[36] | log|det| | hx[6] (k_predict's gate record)
+
 // Columns of the point tile are NP + 2 doubles apart: with a power-of-two stride the same row of all six
 // columns -- what the lanes of one track read together -- would sit in one LDS bank (6-way conflicts).
 constexpr int kTilePad = 2;
@@ -78,10 +78,10 @@ template <bool WRITE>
 __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, char *base, TrackLds *L)
 {
     const int NP = c.max_pts, NB = (NP + 63) / 64, CLS = c.t_cap + 1;
-    // One region, three lives: (1) the gate records of a chunk of tracks while the points are gated (points
-    // sit in registers then); (2) the SoA point tile + the leaf sums of the pairwise recursion while cluster
-    // statistics are formed; (3) the cell grid of the DBSCAN screen at the very end.
-    const int work_a = kGateChunk * kGateStride, work_b = 6 * (NP + kTilePad) + pw_max_leaves(NP) * 21;
+    // One region, two lives: (1) the SoA point tile + the leaf sums of the pairwise recursion while cluster
+    // statistics are formed; (2) the cell grid of the DBSCAN screen at the very end.  (The gate records of the
+    // tracks, once staged here, are read through the scalar cache now.)
+    const int work_a = 0, work_b = 6 * (NP + kTilePad) + pw_max_leaves(NP) * 21;
     size_t off = 0;
 #define CARVE(field, type, count)                            \
     if constexpr (WRITE) L->field = (type *)(base + off);    \
@@ -248,7 +248,6 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
 #ifdef MMW_STAMPS
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
-    double *gate = L.work;
 
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
     for (int j = tid + kThreads; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
@@ -262,50 +261,55 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
 #pragma unroll
     for (int q = 0; q < PPT; q++) { bestd[q] = 0.0; bestj[q] = -1; }
 
-    for (int c0 = 0; c0 < T; c0 += kGateChunk) {
-        const int tc = min(kGateChunk, T - c0);
-        // ---- the chunk's gate matrices (inverse, log|det|, predicted position) as k_predict left them ----
-        for (int e = tid; e < tc * kGateRec; e += kThreads) {
-            const int jl = e / kGateRec, k = e - jl * kGateRec;
-            gate[jl * kGateStride + k] = st.gate_buf[((size_t)s * cfg.t_cap + c0 + jl) * kGateRec + k];
-        }
-        lds_barrier();
-        STAMP(1);  // predict + gate matrices
-        PROBE(1);
-        // ---- gate every point against the chunk's tracks (Tracking.py:553-572) ----
-        // (points in registers, the 6x6 inverse read from LDS as wave-uniform broadcasts: keeping it
-        //  in registers as well costs 72 VGPRs and a workgroup per CU)
+    // ---- gate every point against the scene's tracks (Tracking.py:553-572) ----
+    // The gate record of a track (C^-1, log|det C|, predicted position: 43 doubles, k_predict -> gate_buf) is the same
+    // for every point, i.e. wave-uniform: it is read through the SCALAR cache (constant address space, uniform address
+    // -> s_load) and enters the fp64 VALU ops as their SGPR operand (no LDS staging, no barriers in this phase).
+    // y' C^-1 y as k-ordered FUSED chains, v_k = fma(y_a, Ci[a][k], v_k) row by row over C^-1, then q = fma(v_k, y_k, q):
+    // the arithmetic definition the oracle shares (oracle/c/mmw_oracle.c, _calc_dist_fun); with the operands in SGPRs the
+    // phase is bound by fp64 issue, and the fused form is 49 instead of 84 instructions per (point, track).
+    {
+        typedef const double __attribute__((address_space(4))) *gate_ptr;
+        const int su = __builtin_amdgcn_readfirstlane(s), Tu = __builtin_amdgcn_readfirstlane(T);
+        gate_ptr gb = (gate_ptr)(st.gate_buf + (size_t)su * cfg.t_cap * kGateRec);
+        for (int j = 0; j < Tu; j++) {
+            gate_ptr G = gb + j * kGateRec;
 #pragma unroll
-        for (int q = 0; q < PPT; q++) {
-            const int i = q * kThreads + tid;
-            if (q * kThreads < n) {  // wave-uniform
-                const double p0 = pr[q][0].x, p1 = pr[q][0].y, p2 = pr[q][1].x, p3 = pr[q][1].y, p4 = pr[q][2].x, p5 = pr[q][2].y;
-                for (int jl = 0; jl < tc; jl++) {
-                    const double *G = gate + jl * kGateStride;
-                    const double y0 = p0 - G[37], y1 = p1 - G[38], y2 = p2 - G[39], y3 = p3 - G[40], y4 = p4 - G[41], y5 = p5 - G[42];
-                    double quad = 0.0;
+            for (int q = 0; q < PPT; q++) {
+                const int i = q * kThreads + tid;
+                if (q * kThreads < n) {  // wave-uniform
+                    const double y0 = pr[q][0].x - G[37], y1 = pr[q][0].y - G[38], y2 = pr[q][1].x - G[39], y3 = pr[q][1].y - G[40],
+                                 y4 = pr[q][2].x - G[41], y5 = pr[q][2].y - G[42];
+                    double v[6];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        double v = y0 * G[k];
-                        v += y1 * G[6 + k];
-                        v += y2 * G[12 + k];
-                        v += y3 * G[18 + k];
-                        v += y4 * G[24 + k];
-                        v += y5 * G[30 + k];
-                        const double yk = k == 0 ? y0 : k == 1 ? y1 : k == 2 ? y2 : k == 3 ? y3 : k == 4 ? y4 : y5;
-                        if (k == 0) quad = v * yk; else quad += v * yk;
-                    }
+                    for (int k = 0; k < 6; k++) v[k] = y0 * G[k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = __builtin_fma(y1, G[6 + k], v[k]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = __builtin_fma(y2, G[12 + k], v[k]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = __builtin_fma(y3, G[18 + k], v[k]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = __builtin_fma(y4, G[24 + k], v[k]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = __builtin_fma(y5, G[30 + k], v[k]);
+                    double quad = v[0] * y0;
+                    quad = __builtin_fma(v[1], y1, quad);
+                    quad = __builtin_fma(v[2], y2, quad);
+                    quad = __builtin_fma(v[3], y3, quad);
+                    quad = __builtin_fma(v[4], y4, quad);
+                    quad = __builtin_fma(v[5], y5, quad);
                     const double d = G[36] + quad;
                     if (i < n && d < cfg.tr_gate) {
-                        if (bestj[q] < 0 || d < bestd[q]) { bestj[q] = c0 + jl; bestd[q] = d; }
+                        if (bestj[q] < 0 || d < bestd[q]) { bestj[q] = j; bestd[q] = d; }
                     }
                 }
             }
         }
-        lds_barrier();
-        STAMP(2);  // gating
-        PROBE(2);
     }
+    STAMP(1);
+    STAMP(2);  // gating
+    PROBE(2);
     // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
     {
         const int NB = (n + 63) / 64;

@@ -797,11 +797,14 @@ int orc_track_frame(orc_scene *s, const double *pts, int n, double dt, int32_t *
             for (int i = 0; i < n; i++) {
                 double y[6], q, d;
                 for (int a = 0; a < 6; a++) y[a] = pts[i * 8 + a] - t->x[a];
+                /* y' C^-1 y as k-ordered FUSED multiply-add chains (one rounding per step, like the dot kernels of the
+                 * BLAS numpy calls at Tracking.py:556-560): v_k = fma(y_a, Ci[a][k], v_k), q = fma(v_k, y_k, q).
+                 * The kernels evaluate the same chain (k_track.hip); built with -mfma so fma() is one instruction. */
                 q = 0;
                 for (int k = 0; k < 6; k++) {
                     double v = y[0] * Ci[k];
-                    for (int a = 1; a < 6; a++) v += y[a] * Ci[a * 6 + k];
-                    if (k == 0) q = v * y[0]; else q += v * y[k];
+                    for (int a = 1; a < 6; a++) v = fma(y[a], Ci[a * 6 + k], v);
+                    if (k == 0) q = v * y[0]; else q = fma(v, y[k], q);
                 }
                 d = logdet + q;
                 if (d < c->tr_gate) {
