@@ -29,9 +29,12 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
     from mmwave_msc_amd.posture import PosturePipeline
 
     cap = S * min(sb.track_cap, 2 * sb.cfg.tr_max_tracks)
-    model = MarsCNN.from_keras_weights(random_keras_weights(0, sb.ring)).to(dev)
+    weights = random_keras_weights(0, sb.ring)
+    models = {a: MarsCNN.from_keras_weights(weights, arith=a).to(dev) for a in ("f16x3", "f32")}
     out = {}
-    for mode in ("overlap", "serial"):
+    # (schedule, Dense-1 arithmetic): the default build of the product, then the two alternatives beside it
+    for mode, arith in (("serial", "f16x3"), ("serial", "f32"), ("overlap", "f16x3")):
+        model = models[arith]
         pipe = PosturePipeline(sb, model, cap, tracker_stream=stream_a, overlap=(mode == "overlap"), time_cnn=True)
         sb.reset()
         sb.profile(False)
@@ -65,29 +68,39 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
         f_avg = f_ms / max(f_cnt, 1)
         cnn_ms = pipe.cnn_ms()
         flop = CNN_FLOP[3 if sb.ring == 3 else 1]
+        split = arith == "f16x3" and model.use_hip_conv
+        # matrix-core work actually issued: Dense-1 (18.87 MFLOP of the 25.19) three times on the fp16 cores when split
+        d1 = 2.0 * 6144 * 1536
+        issued = (flop - d1) + 3.0 * d1 if split else flop
         res = {
             "value": round(S * world * K / el, 1), "unit": "scene-frames/s", "ms_per_step": round(el / K * 1e3, 4),
             "samples_per_step": round(rows / max(K, 1), 1), "samples_per_s": round(rows / el, 1),
             "cnn_ms_per_step": round(cnn_ms, 4) if cnn_ms is not None else None,
+            "cnn_arith": ("fp32 conv on the fp32 matrix cores; Dense-1 = fp32 operands split hi + 2^-11 lo' into fp16, 3 exact partial "
+                          "products on the fp16 matrix cores, fp32 accumulation (closer to the fp64 oracle than the fp32 GEMM)") if split
+                         else "fp32 on the fp32 matrix cores throughout",
             "roofline_cnn": {"bound": "mfma", "dtype": "f32", "achieved": round(rows * flop / el / 1e12, 2), "peak": MFMA_FP32_PEAK_TF,
                              "unit": "TFLOP/s", "frac": round(rows * flop / el / 1e12 / MFMA_FP32_PEAK_TF, 6),
                              "flop_per_sample": flop,
-                             "cnn_only_tflops": round(rows / max(K, 1) * flop / (cnn_ms * 1e-3) / 1e12, 2) if cnn_ms else None},
+                             "cnn_only_tflops": round(rows / max(K, 1) * flop / (cnn_ms * 1e-3) / 1e12, 2) if cnn_ms else None,
+                             "note": "algorithmic flops (25.19 MFLOP per sample) against the fp32 matrix-core peak, the roof of the "
+                                     "reference's arithmetic; with the split Dense-1 the issued matrix-core work is "
+                                     f"{issued / 1e6:.2f} MFLOP per sample, 56.6 of them on the fp16 cores (2.5 PFLOP/s peak)"},
             "roofline_features": {"kernel": "k_features", "bound": "hbm", "achieved": round(feat_bytes_per_launch / max(f_avg, 1e-9) / 1e6, 2),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(feat_bytes_per_launch / max(f_avg, 1e-9) / 1e6 / HBM_PEAK_GBS, 6),
                                   "algorithmic_bytes_per_launch": round(feat_bytes_per_launch, 1), "avg_launch_ms": round(f_avg, 5),
                                   "launches_timed": int(f_cnt)},
         }
-        out[mode] = res
-    # the line's e2e value is the faster of the two schedules; the other one is kept beside it
-    first, second = ("serial", "overlap") if out["serial"]["value"] >= out["overlap"]["value"] else ("overlap", "serial")
+        out[(mode, arith)] = res
     modes = {"serial": "one stream: track(f), features(f), CNN(f), keypoints(f), track(f+1), ... (the CNN owns the whole chip)",
-             "overlap": "two streams: track(f+1) + features(f+1) beside CNN(f), keypoints scattered by track creation ordinal "
-                        "(the statically tiled GEMM / persistent conv lose more to the shared CUs than the overlap hides)"}
-    best = dict(out[first])
+             "overlap": "two streams: track(f+1) + features(f+1) beside CNN(f), keypoints scattered by track creation ordinal"}
+    first, second = ("serial", "overlap") if out[("serial", "f16x3")]["value"] >= out[("overlap", "f16x3")]["value"] else ("overlap", "serial")
+    best = dict(out[(first, "f16x3")])
     best["mode"] = first + " -- " + modes[first]
-    best["other_schedule"] = {"mode": second + " -- " + modes[second], **{k: out[second][k] for k in ("value", "ms_per_step", "cnn_ms_per_step")}}
-    best["config"] = (f"{S * world} scenes, track -> features -> MARS CNN (fp32, random Keras-layout weights) -> keypoints every frame; "
+    best["other_schedule"] = {"mode": second + " -- " + modes[second],
+                              **{k: out[(second, "f16x3")][k] for k in ("value", "ms_per_step", "cnn_ms_per_step")}}
+    best["fp32_dense1"] = {"mode": "serial", **{k: out[("serial", "f32")][k] for k in ("value", "ms_per_step", "cnn_ms_per_step", "cnn_arith")}}
+    best["config"] = (f"{S * world} scenes, track -> features -> MARS CNN (random Keras-layout weights) -> keypoints every frame; "
                       f"BASELINE.json configs[4] shape at {world} GPU(s)")
     best["steps"] = F - W
     return best

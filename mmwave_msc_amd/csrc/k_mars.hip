@@ -12,6 +12,7 @@
 // Input = mmw_features' channels-last tensor; output [B][192][32] is the Keras Flatten order
 // (d,h,w,c), so Dense-1 takes Keras' weight rows as they are.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 namespace mmw {
@@ -29,6 +30,12 @@ __device__ __forceinline__ int padded_origin(int pos)  // position (d,h,w) -> in
     return d * 100 + h * 10 + w;
 }
 
+// SPLIT = false: out[B][192][32] fp32.  SPLIT = true: the activation leaves the kernel already split for the fp16
+// matrix cores, out16[B][2][6144] fp16 = [hi | lo'] with hi = fp16(a), lo' = fp16((a - hi) * 2^11): Dense-1 is then
+// a @ W = hi.W_hi + 2^-11 (hi.W_lo' + lo'.W_hi) in two fp16 GEMMs with fp32 accumulation (mars.py), every product exact,
+// the dropped lo'.lo' term 2^-22 relative.
+constexpr float kSplitScale = 2048.0f;
+template <bool SPLIT>
 __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ feat, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2,
                                                        const float *__restrict__ b2, float *__restrict__ out, int B)
@@ -104,14 +111,24 @@ __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ 
         }
         // C/D: col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         float *o = out + (size_t)b * 192 * 32;
+        __half *oh = reinterpret_cast<__half *>(out) + (size_t)b * 2 * 6144;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int oc = lane & 31;
-            float v0 = c0[r] + bias2, v1 = c1[r] + bias2, v2 = c2[r] + bias2;
-            o[((wave * 3 + 0) * 32 + row) * 32 + oc] = v0 > 0.f ? v0 : 0.f;
-            o[((wave * 3 + 1) * 32 + row) * 32 + oc] = v1 > 0.f ? v1 : 0.f;
-            o[((wave * 3 + 2) * 32 + row) * 32 + oc] = v2 > 0.f ? v2 : 0.f;
+            float v[3] = {c0[r] + bias2, c1[r] + bias2, c2[r] + bias2};
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const float a = v[t] > 0.f ? v[t] : 0.f;
+                const int e = ((wave * 3 + t) * 32 + row) * 32 + oc;
+                if (SPLIT) {
+                    const __half hi = __float2half_rn(a);
+                    oh[e] = hi;
+                    oh[6144 + e] = __float2half_rn((a - __half2float(hi)) * kSplitScale);
+                } else {
+                    o[e] = a;
+                }
+            }
         }
         __syncthreads();  // both waves are done reading Xp / H1 before the next sample overwrites them
     }
@@ -122,7 +139,14 @@ void launch_mars_conv(const float *feat, const float *w1, const float *b1, const
 {
     if (B <= 0) return;
     const int grid = B < 512 ? B : 512;  // 2 workgroups per CU, persistent over samples
-    hipLaunchKernelGGL(k_mars_conv, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
+    hipLaunchKernelGGL(k_mars_conv<false>, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
+}
+void launch_mars_conv_split(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
+                            hipStream_t stream)
+{
+    if (B <= 0) return;
+    const int grid = B < 512 ? B : 512;
+    hipLaunchKernelGGL(k_mars_conv<true>, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, reinterpret_cast<float *>(out16), B);
 }
 
 }  // namespace mmw

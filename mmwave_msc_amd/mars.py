@@ -26,6 +26,7 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-3
 N_KEYPOINTS = 57
+SPLIT_SCALE = 2048.0   # 2^11: fp16 keeps 11 significant bits (csrc/k_mars.hip: kSplitScale)
 
 
 def random_keras_weights(seed: int = 0, frames: int = 3) -> dict:
@@ -55,8 +56,18 @@ def random_keras_weights(seed: int = 0, frames: int = 3) -> dict:
 
 
 class MarsCNN(nn.Module):
-    def __init__(self, frames: int = 3):
+    def __init__(self, frames: int = 3, arith: str = "f16x3"):
+        """`arith` = how Dense-1 (6144 -> 1536, 75 % of the CNN's multiply-adds) is evaluated on the GPU by the 3-frame model:
+        "f32"   one fp32 GEMM on the fp32 matrix cores (hipBLASLt through torch);
+        "f16x3" the fp32 operands split as a = hi + 2^-11 lo' (hi, lo' fp16) and a.W = hi.W_hi + 2^-11 (hi.W_lo' + lo'.W_hi)
+                on the fp16 matrix cores with fp32 accumulation: every partial product is exact, the dropped lo'.lo' term is
+                2^-22 relative, and the result is CLOSER to the fp64 oracle than the fp32 GEMM (1.2e-6 vs 2.5e-6 max error on
+                Dense-1's outputs, scripts/exp_split_gemm.py) at 2.2x its speed.  Not a reduced-precision mode: fp16 storage
+                never holds a value that is not re-completed by its lo' half."""
         super().__init__()
+        if arith not in ("f32", "f16x3"):
+            raise ValueError(arith)
+        self.arith = arith
         self.frames = int(frames)
         self.three_d = self.frames > 1
         conv = nn.Conv3d if self.three_d else nn.Conv2d
@@ -75,15 +86,18 @@ class MarsCNN(nn.Module):
             self.register_buffer("k_w2", torch.zeros(27 * 16 * 32))
             self.register_buffer("k_b2", torch.zeros(32))
             self.dense1_dhwc = nn.Linear(flat, hidden)
+            # the same matrix split for the fp16 matrix cores: W_hi (K, N) and [W_lo' ; W_hi] (2K, N)
+            self.register_buffer("d1_w_hi", torch.zeros((flat, hidden), dtype=torch.float16))
+            self.register_buffer("d1_w2", torch.zeros((2 * flat, hidden), dtype=torch.float16))
         for p in self.parameters():
             p.requires_grad_(False)
 
     @classmethod
-    def from_keras_weights(cls, w: dict) -> "MarsCNN":
+    def from_keras_weights(cls, w: dict, arith: str = "f16x3") -> "MarsCNN":
         three_d = np.asarray(w["conv1_w"]).ndim == 5
         flat = np.asarray(w["dense1_w"]).shape[0]
         frames = flat // (64 * 32) if three_d else 1
-        m = cls(frames if three_d else 1)
+        m = cls(frames if three_d else 1, arith)
         f64 = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
         perm = (4, 3, 0, 1, 2) if three_d else (3, 2, 0, 1)
         m.conv1.weight.copy_(torch.from_numpy(f64["conv1_w"].transpose(perm).copy()).float())
@@ -105,6 +119,11 @@ class MarsCNN(nn.Module):
             wk = (f64["dense1_w"].reshape(spatial, 32, -1) * a1[None, :, None]).reshape(flat, -1)  # Keras row order kept
             m.dense1_dhwc.weight.copy_(torch.from_numpy(wk.T.copy()).float())
             m.dense1_dhwc.bias.copy_(torch.from_numpy(b1).float())
+            w32 = torch.from_numpy(wk.copy()).float()                    # (K, N), what the fp32 GEMM multiplies with
+            w_hi = w32.half()
+            w_lo = ((w32 - w_hi.float()) * SPLIT_SCALE).half()
+            m.d1_w_hi.copy_(w_hi)
+            m.d1_w2.copy_(torch.cat([w_lo, w_hi], 0))
         m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
         m.dense1.bias.copy_(torch.from_numpy(b1).float())
         a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
@@ -143,11 +162,33 @@ class MarsCNN(nn.Module):
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return out
 
+    def _hip_convs_split(self, x: torch.Tensor) -> torch.Tensor:
+        """The same two layers with the activation already split for the fp16 matrix cores (mmw_mars_conv3d_split):
+        (B, 2 * 6144) fp16 = [hi | lo']."""
+        from . import _lib
+        L = _lib.load()
+        x = x.contiguous()
+        out = torch.empty((x.shape[0], 2 * 6144), dtype=torch.float16, device=x.device)
+        rc = L.mmw_mars_conv3d_split(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), self.k_w1.data_ptr(),
+                                     self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), x.shape[0])
+        if rc != 0:
+            raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
+        return out
+
+    def _dense1_split(self, a2: torch.Tensor) -> torch.Tensor:
+        """bias + hi.W_hi + 2^-11 [hi | lo'].[W_lo' ; W_hi]: two fp16 GEMMs with fp32 accumulation and output."""
+        k = a2.shape[1] // 2
+        g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi, out_dtype=torch.float32)
+        return torch.addmm(g1, a2, self.d1_w2, out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""
         if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32:
             with torch.cuda.device(x.device):
-                h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
+                if self.arith == "f16x3":
+                    h = F.relu_(self._dense1_split(self._hip_convs_split(x)))
+                else:
+                    h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
             return self.dense2(h)
         if self.three_d:
             h = x.permute(0, 4, 1, 2, 3)
