@@ -270,12 +270,15 @@ int mmw_track_table(mmw_ctx *ctx, mmw_track_summary *table, int32_t slots, int32
 int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2,
                     float *out, int32_t n);
 
-/* The same two layers with the activation written ALREADY SPLIT for the fp16 matrix cores:
- *   out16[n][2][6144] fp16 = [hi | lo'],  hi = fp16(a),  lo' = fp16((a - hi) * 2^11)   (a = the fp32 activation above)
- * so that Dense-1 can run as a.W = hi.W_hi + 2^-11 (hi.W_lo' + lo'.W_hi): three exact fp16 products per term, fp32
- * accumulation, the dropped lo'.lo' term 2^-22 relative -- measured closer to the fp64 oracle than the fp32 GEMM. */
-int mmw_mars_conv3d_split(void *hip_stream, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2,
-                          void *out16, int32_t n);
+/* The two convolution layers on the fp16 matrix cores, fp32-exact by operand splitting: every fp32 value a (inputs,
+ * weights, activations) is carried as hi = fp16(a), lo' = fp16((a - hi) * 2^11) and a product a.w accumulates in fp32 as
+ * hi.hi + 2^-11 (hi.lo' + lo'.hi): three exact fp16 products per term, the dropped lo'.lo' term 2^-22 relative --
+ * measured closer to the fp64 oracle than the fp32 kernel above.  frames = 3: define_CNN_3D's Conv3D pair
+ * (train.py:73-82), feat[n][3][8][8][5], kernels (kd,kh,kw,in,out); frames = 1: define_CNN's Conv2D pair
+ * (train.py:35-44), feat[n][8][8][5], kernels (kh,kw,in,out).  The activation leaves the kernel already split, for a
+ * Dense-1 of the same form:  out16[n][2][frames * 2048] fp16 = [hi | lo'] in Keras' Flatten order. */
+int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
+                        const float *b2, void *out16, int32_t n);
 
 /* ReadIWR14xx.read (ReadDataIWR1443.py:27-201) on a byte buffer, host only (no context, no GPU work): the input
  * step before mmw_normalize.  Looks for the LAST 8-byte magic word 02 01 04 03 06 05 08 07 in buf[0 .. len-8),

@@ -46,8 +46,8 @@ void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
                       hipStream_t stream);
-void launch_mars_conv_split(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
-                            hipStream_t stream);
+void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
+                        hipStream_t stream);
 }  // namespace mmw
 
 using namespace mmw;
@@ -749,13 +749,14 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
     return MMW_OK;
 }
 
-int mmw_mars_conv3d_split(void *hip_stream, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2,
-                          void *out16, int32_t n)
+int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
+                        const float *b2, void *out16, int32_t n)
 {
-    if (n < 0 || (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out16))) return fail(nullptr, MMW_E_ARG, "mmw_mars_conv3d_split: bad argument");
-    launch_mars_conv_split(feat, w1, b1, w2, b2, out16, n, (hipStream_t)hip_stream);
+    if ((frames != 3 && frames != 1) || n < 0 || (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out16)))
+        return fail(nullptr, MMW_E_ARG, "mmw_mars_conv_split: bad argument (frames must be 3 or 1)");
+    launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, n, (hipStream_t)hip_stream);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv3d_split launch -> %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv_split launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 

@@ -57,13 +57,14 @@ def random_keras_weights(seed: int = 0, frames: int = 3) -> dict:
 
 class MarsCNN(nn.Module):
     def __init__(self, frames: int = 3, arith: str = "f16x3"):
-        """`arith` = how Dense-1 (6144 -> 1536, 75 % of the CNN's multiply-adds) is evaluated on the GPU by the 3-frame model:
-        "f32"   one fp32 GEMM on the fp32 matrix cores (hipBLASLt through torch);
-        "f16x3" the fp32 operands split as a = hi + 2^-11 lo' (hi, lo' fp16) and a.W = hi.W_hi + 2^-11 (hi.W_lo' + lo'.W_hi)
-                on the fp16 matrix cores with fp32 accumulation: every partial product is exact, the dropped lo'.lo' term is
-                2^-22 relative, and the result is CLOSER to the fp64 oracle than the fp32 GEMM (1.2e-6 vs 2.5e-6 max error on
-                Dense-1's outputs, scripts/exp_split_gemm.py) at 2.2x its speed.  Not a reduced-precision mode: fp16 storage
-                never holds a value that is not re-completed by its lo' half."""
+        """`arith` = how the conv pair and Dense-1 (99.7 % of the CNN's multiply-adds) are evaluated on the GPU:
+        "f32"   on the fp32 matrix cores: the fused conv kernel k_mars_conv (3-frame model; torch convolutions for the
+                single-frame one) and one fp32 GEMM (hipBLASLt through torch);
+        "f16x3" every fp32 operand split as a = hi + 2^-11 lo' (hi, lo' fp16) and a.w = hi.w_hi + 2^-11 (hi.w_lo' + lo'.w_hi)
+                on the fp16 matrix cores with fp32 accumulation (k_mars_conv16 + two fp16 GEMMs): every partial product is
+                exact, the dropped lo'.lo' term is 2^-22 relative, and the result is CLOSER to the fp64 oracle than fp32
+                arithmetic (Dense-1 outputs: 1.2e-6 vs 2.5e-6 max error, scripts/exp_split_gemm.py).  Not a
+                reduced-precision mode: fp16 storage never holds a value that is not re-completed by its lo' half."""
         super().__init__()
         if arith not in ("f32", "f16x3"):
             raise ValueError(arith)
@@ -77,18 +78,20 @@ class MarsCNN(nn.Module):
         hidden = 512 * (3 if self.three_d else 1)
         self.dense1 = nn.Linear(flat, hidden)   # BN1 folded in, rows in channels-first flatten order
         self.dense2 = nn.Linear(hidden, N_KEYPOINTS)  # BN2 folded in
-        # hand-written fused Conv3D x2 on the fp32 matrix cores (csrc/k_mars.hip): Keras-layout kernels
-        # and a Dense-1 whose rows follow Keras' own (d,h,w,c) flatten order
-        self.use_hip_conv = self.three_d and self.frames == 3
-        if self.use_hip_conv:
-            self.register_buffer("k_w1", torch.zeros(27 * 5 * 16))
-            self.register_buffer("k_b1", torch.zeros(16))
-            self.register_buffer("k_w2", torch.zeros(27 * 16 * 32))
-            self.register_buffer("k_b2", torch.zeros(32))
-            self.dense1_dhwc = nn.Linear(flat, hidden)
-            # the same matrix split for the fp16 matrix cores: W_hi (K, N) and [W_lo' ; W_hi] (2K, N)
-            self.register_buffer("d1_w_hi", torch.zeros((flat, hidden), dtype=torch.float16))
-            self.register_buffer("d1_w2", torch.zeros((2 * flat, hidden), dtype=torch.float16))
+        # hand-written fused conv pair (csrc/k_mars.hip): Keras-layout kernels and a Dense-1 whose rows follow Keras' own
+        # (d,h,w,c) flatten order.  The fp16-split kernel (arith "f16x3") serves both models; the fp32-MFMA kernel
+        # (arith "f32") exists for the 3-frame model only -- the single-frame model then uses torch's convolutions.
+        self.use_hip_conv = self.frames in (3, 1)
+        self.use_hip_conv_f32 = self.frames == 3
+        kt = 27 if self.three_d else 9
+        self.register_buffer("k_w1", torch.zeros(kt * 5 * 16))
+        self.register_buffer("k_b1", torch.zeros(16))
+        self.register_buffer("k_w2", torch.zeros(kt * 16 * 32))
+        self.register_buffer("k_b2", torch.zeros(32))
+        self.dense1_dhwc = nn.Linear(flat, hidden)
+        # the same matrix split for the fp16 matrix cores: W_hi (K, N) and [W_lo' ; W_hi] (2K, N)
+        self.register_buffer("d1_w_hi", torch.zeros((flat, hidden), dtype=torch.float16))
+        self.register_buffer("d1_w2", torch.zeros((2 * flat, hidden), dtype=torch.float16))
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -111,19 +114,18 @@ class MarsCNN(nn.Module):
         w1 = f64["dense1_w"].reshape(spatial, 32, -1)            # [s, c, out]
         b1 = f64["dense1_b"] + np.einsum("c,sco->o", c1, w1)
         w1 = (w1 * a1[None, :, None]).transpose(1, 0, 2).reshape(flat, -1)  # [(c,s), out]
-        if m.use_hip_conv:
-            m.k_w1.copy_(torch.from_numpy(f64["conv1_w"].reshape(-1)).float())
-            m.k_b1.copy_(torch.from_numpy(f64["conv1_b"]).float())
-            m.k_w2.copy_(torch.from_numpy(f64["conv2_w"].reshape(-1)).float())
-            m.k_b2.copy_(torch.from_numpy(f64["conv2_b"]).float())
-            wk = (f64["dense1_w"].reshape(spatial, 32, -1) * a1[None, :, None]).reshape(flat, -1)  # Keras row order kept
-            m.dense1_dhwc.weight.copy_(torch.from_numpy(wk.T.copy()).float())
-            m.dense1_dhwc.bias.copy_(torch.from_numpy(b1).float())
-            w32 = torch.from_numpy(wk.copy()).float()                    # (K, N), what the fp32 GEMM multiplies with
-            w_hi = w32.half()
-            w_lo = ((w32 - w_hi.float()) * SPLIT_SCALE).half()
-            m.d1_w_hi.copy_(w_hi)
-            m.d1_w2.copy_(torch.cat([w_lo, w_hi], 0))
+        m.k_w1.copy_(torch.from_numpy(f64["conv1_w"].reshape(-1)).float())
+        m.k_b1.copy_(torch.from_numpy(f64["conv1_b"]).float())
+        m.k_w2.copy_(torch.from_numpy(f64["conv2_w"].reshape(-1)).float())
+        m.k_b2.copy_(torch.from_numpy(f64["conv2_b"]).float())
+        wk = (f64["dense1_w"].reshape(spatial, 32, -1) * a1[None, :, None]).reshape(flat, -1)  # Keras row order kept
+        m.dense1_dhwc.weight.copy_(torch.from_numpy(wk.T.copy()).float())
+        m.dense1_dhwc.bias.copy_(torch.from_numpy(b1).float())
+        w32 = torch.from_numpy(wk.copy()).float()                    # (K, N), what the fp32 GEMM multiplies with
+        w_hi = w32.half()
+        w_lo = ((w32 - w_hi.float()) * SPLIT_SCALE).half()
+        m.d1_w_hi.copy_(w_hi)
+        m.d1_w2.copy_(torch.cat([w_lo, w_hi], 0))
         m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
         m.dense1.bias.copy_(torch.from_numpy(b1).float())
         a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
@@ -151,7 +153,7 @@ class MarsCNN(nn.Module):
         return cls.from_h5(path) if path.lower().endswith((".h5", ".hdf5")) else cls.from_npz(path)
 
     def _hip_convs(self, x: torch.Tensor) -> torch.Tensor:
-        """Conv3D+ReLU twice in one HIP kernel (mmw_mars_conv3d) -> (B, 6144) in (d,h,w,c) order."""
+        """Conv3D+ReLU twice in one HIP kernel on the fp32 matrix cores (mmw_mars_conv3d) -> (B, 6144) in (d,h,w,c) order."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
@@ -163,14 +165,15 @@ class MarsCNN(nn.Module):
         return out
 
     def _hip_convs_split(self, x: torch.Tensor) -> torch.Tensor:
-        """The same two layers with the activation already split for the fp16 matrix cores (mmw_mars_conv3d_split):
-        (B, 2 * 6144) fp16 = [hi | lo']."""
+        """The conv pair on the fp16 matrix cores with split operands (mmw_mars_conv_split), the activation already split
+        for Dense-1: (B, 2 * flat) fp16 = [hi | lo'], flat = frames * 2048 in (d,h,w,c) order."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
-        out = torch.empty((x.shape[0], 2 * 6144), dtype=torch.float16, device=x.device)
-        rc = L.mmw_mars_conv3d_split(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), self.k_w1.data_ptr(),
-                                     self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), x.shape[0])
+        flat = self.frames * 2048
+        out = torch.empty((x.shape[0], 2 * flat), dtype=torch.float16, device=x.device)
+        rc = L.mmw_mars_conv_split(torch.cuda.current_stream(x.device).cuda_stream, self.frames, x.data_ptr(), self.k_w1.data_ptr(),
+                                   self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), x.shape[0])
         if rc != 0:
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return out
@@ -183,7 +186,7 @@ class MarsCNN(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""
-        if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32:
+        if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32 and (self.arith == "f16x3" or self.use_hip_conv_f32):
             with torch.cuda.device(x.device):
                 if self.arith == "f16x3":
                     h = F.relu_(self._dense1_split(self._hip_convs_split(x)))
