@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 MFMA_FP32_PEAK_TF = 157.3
+MFMA_FP16_PEAK_TF = 2500.0   # dense fp16 / bf16 matrix-core peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 CNN_FLOP = {3: 25187328.0, 1: 2837504.0}
 KP_TOL = 1e-4            # max|d| <= 1e-4 (m) and rel 1e-4 on the 57 outputs
@@ -69,23 +70,26 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
         cnn_ms = pipe.cnn_ms()
         flop = CNN_FLOP[3 if sb.ring == 3 else 1]
         split = arith == "f16x3" and model.use_hip_conv
-        # matrix-core work actually issued: Dense-1 (18.87 MFLOP of the 25.19) three times on the fp16 cores when split
-        d1 = 2.0 * 6144 * 1536
-        issued = (flop - d1) + 3.0 * d1 if split else flop
+        # matrix-core work actually issued: with split operands every multiply-add is three fp16 partial products
+        issued = 3.0 * flop if split else flop
+        peak = MFMA_FP16_PEAK_TF if split else MFMA_FP32_PEAK_TF
         res = {
             "value": round(S * world * K / el, 1), "unit": "scene-frames/s", "ms_per_step": round(el / K * 1e3, 4),
             "samples_per_step": round(rows / max(K, 1), 1), "samples_per_s": round(rows / el, 1),
             "cnn_ms_per_step": round(cnn_ms, 4) if cnn_ms is not None else None,
-            "cnn_arith": ("fp32 conv on the fp32 matrix cores; Dense-1 = fp32 operands split hi + 2^-11 lo' into fp16, 3 exact partial "
-                          "products on the fp16 matrix cores, fp32 accumulation (closer to the fp64 oracle than the fp32 GEMM)") if split
-                         else "fp32 on the fp32 matrix cores throughout",
-            "roofline_cnn": {"bound": "mfma", "dtype": "f32", "achieved": round(rows * flop / el / 1e12, 2), "peak": MFMA_FP32_PEAK_TF,
-                             "unit": "TFLOP/s", "frac": round(rows * flop / el / 1e12 / MFMA_FP32_PEAK_TF, 6),
-                             "flop_per_sample": flop,
-                             "cnn_only_tflops": round(rows / max(K, 1) * flop / (cnn_ms * 1e-3) / 1e12, 2) if cnn_ms else None,
-                             "note": "algorithmic flops (25.19 MFLOP per sample) against the fp32 matrix-core peak, the roof of the "
-                                     "reference's arithmetic; with the split Dense-1 the issued matrix-core work is "
-                                     f"{issued / 1e6:.2f} MFLOP per sample, 56.6 of them on the fp16 cores (2.5 PFLOP/s peak)"},
+            "cnn_arith": ("f32 results from fp16 matrix cores: every fp32 operand split hi + 2^-11 lo' (fp16 halves), each product = 3 "
+                          "exact partial products, fp32 accumulation (k_mars_conv16 + two fp16 GEMMs); closer to the fp64 oracle than "
+                          "fp32 arithmetic") if split else "fp32 on the fp32 matrix cores throughout (k_mars_conv + fp32 GEMM)",
+            "roofline_cnn": {"bound": "mfma", "dtype": "f16 x3 (fp32-exact split)" if split else "f32",
+                             "achieved": round(rows * issued / el / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(rows * issued / el / 1e12 / peak, 6),
+                             "flop_per_sample_algorithmic": flop, "flop_per_sample_issued": issued,
+                             "algorithmic_tflops": round(rows * flop / el / 1e12, 2),
+                             "cnn_only_algorithmic_tflops": round(rows / max(K, 1) * flop / (cnn_ms * 1e-3) / 1e12, 2) if cnn_ms else None,
+                             "fp32_mfma_peak": MFMA_FP32_PEAK_TF,
+                             "note": "achieved = matrix-core flops ISSUED over the whole end-to-end step time (tracker and feature kernel "
+                                     "included); algorithmic_tflops = 25.19 MFLOP per sample over the same time, comparable with the fp32 "
+                                     "matrix-core peak, the roof of the reference's own arithmetic"},
             "roofline_features": {"kernel": "k_features", "bound": "hbm", "achieved": round(feat_bytes_per_launch / max(f_avg, 1e-9) / 1e6, 2),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(feat_bytes_per_launch / max(f_avg, 1e-9) / 1e6 / HBM_PEAK_GBS, 6),
                                   "algorithmic_bytes_per_launch": round(feat_bytes_per_launch, 1), "avg_launch_ms": round(f_avg, 5),
