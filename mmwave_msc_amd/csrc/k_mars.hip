@@ -155,9 +155,15 @@ struct Conv16 {
     static constexpr int kPos = NZ * 64;             // output positions per sample
     static constexpr int kPad = NZ * 100;            // padded positions (10 x 10 per plane)
     static constexpr int kS1 = (kTaps + 3) / 4;      // conv1 K-steps: four taps x 8 channels each
-    static constexpr int kWaveLds = (kPad + 1) * 16 * 2 + (kPad + 1) * 32 * 2 + 2 * 32 * 32 * 2;  // X8 hi/lo, H1 hi/lo (+ zero slot), staging
+    // X8 hi/lo, H1 hi/lo (+ zero slot each).  The 4 KiB staging tile of the conv2 epilogue overlays X8 when three planes
+    // make X8 large enough (and LDS scarce); the cells it dirties are zeroed again before the next sample's input is placed
+    static constexpr bool kStageOverX = NZ == 3;
+    static constexpr int kStage = 2 * 32 * 32 * 2;
+    static constexpr int kWaveLds = (kPad + 1) * 16 * 2 + (kPad + 1) * 32 * 2 + (kStageOverX ? 0 : kStage);
     static constexpr int kW1Lds = kS1 * 64 * 16 * 2;
-    static constexpr int kLds = 4 * kWaveLds + kW1Lds;
+    static constexpr int kW2Lds = kTaps * 64 * 16;   // the lo' halves of conv2's weight fragments (the hi halves stay in registers)
+    static constexpr int kLds = 4 * kWaveLds + kW1Lds + kW2Lds;
+    static_assert(!kStageOverX || (kPad + 1) * 16 * 2 >= kStage, "staging tile fits the X8 region");
     __device__ static __forceinline__ int padded(int p) { return (p >> 6) * 100 + (((p >> 3) & 7) + 1) * 10 + (p & 7) + 1; }
     __device__ static __forceinline__ int tap_off(int tap)  // relative to the centre tap
     {
@@ -173,6 +179,20 @@ __device__ __forceinline__ void split16(float a, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)((a - (float)hi) * kSplitScale);
 }
 
+#ifdef MMW_STAMPS
+__device__ unsigned long long g_conv_stamps[8];
+#define CSTAMP(k)                                                                  \
+    do {                                                                           \
+        if (blockIdx.x == 0 && tid == 0) {                                         \
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();        \
+            g_conv_stamps[k] += t_now - t_prev;                                    \
+            t_prev = t_now;                                                        \
+        }                                                                          \
+    } while (0)
+#else
+#define CSTAMP(k)
+#endif
+
 template <int NZ>
 __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict__ feat, const float *__restrict__ w1,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
@@ -184,12 +204,17 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
     // ---- LDS carve-up ----
     h8 *W1hi = reinterpret_cast<h8 *>(lds_raw);                 // [kS1][64] conv1 A fragments (shared)
     h8 *W1lo = W1hi + C::kS1 * 64;
-    char *mine = lds_raw + C::kW1Lds + wave * C::kWaveLds;
-    h8 *Xhi = reinterpret_cast<h8 *>(mine);                     // [kPad + 1] (entry kPad = zero slot)
-    h8 *Xlo = Xhi + (C::kPad + 1);
-    h8 *Hhi = Xlo + (C::kPad + 1);                              // [kPad + 1][2] : 16 channels = two h8
-    h8 *Hlo = Hhi + 2 * (C::kPad + 1);
-    _Float16 *stage = reinterpret_cast<_Float16 *>(Hlo + 2 * (C::kPad + 1));  // [2][32 pos][32 oc]
+    h8 *W2lo = W1lo + C::kS1 * 64;                              // [kTaps][64] lo' halves of conv2's A fragments (shared)
+    char *mine = lds_raw + C::kW1Lds + C::kW2Lds + wave * C::kWaveLds;
+    constexpr int CE = C::kPad + 1;                             // cells per array (entry kPad = zero slot)
+    h8 *Xhi = reinterpret_cast<h8 *>(mine);                     // [CE]  8 channels (5 + 3 zeros) per cell
+    h8 *Xlo = Xhi + CE;
+    // H1: 16 channels per cell as TWO PLANES of 8 (channels 0..7 | 8..15), 16 bytes per cell and plane: the 16 lanes the
+    // LDS serves together read 16 different cells of one plane, i.e. 16 different 16-byte bank groups (see the tiles below)
+    h8 *Hhi = Xlo + CE;                                         // [2][CE]
+    h8 *Hlo = Hhi + 2 * CE;                                     // [2][CE]
+    // [2][32 pos][32 oc]; over X8 (dead once conv1 has run) or behind H1
+    _Float16 *stage = C::kStageOverX ? reinterpret_cast<_Float16 *>(Xhi) : reinterpret_cast<_Float16 *>(Hlo + 2 * CE);
     {   // zero this wave's volumes once: borders and zero slots stay zero, interiors are rewritten per sample
         uint4 *z = reinterpret_cast<uint4 *>(mine);
         for (int i = lane; i < C::kWaveLds / 16; i += 64) z[i] = uint4{0, 0, 0, 0};
@@ -208,16 +233,20 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
         W1hi[i] = hi; W1lo[i] = lo;
     }
     // ---- conv2 fragments (A = weights, 32x32x16): lane (oc = l & 31, h = l >> 5) of tap t holds w2[t][ic 8h+j][oc] ----
-    h8 w2hi[C::kTaps], w2lo[C::kTaps];
+    // (the hi halves stay in registers for the whole kernel; the lo' halves are shared through LDS: with both in registers
+    //  the 256 architectural VGPRs are full and the compiler cannot keep a tap's operands in flight behind the MFMAs)
+    h8 w2hi[C::kTaps];
 #pragma unroll
     for (int t = 0; t < C::kTaps; t++) {
+        h8 lo;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float v = w2[((t * 16) + 8 * (lane >> 5) + j) * 32 + (lane & 31)];
             _Float16 a, b;
             split16(v, a, b);
-            w2hi[t][j] = a; w2lo[t][j] = b;
+            w2hi[t][j] = a; lo[j] = b;
         }
+        if (wave == 0) W2lo[t * 64 + lane] = lo;
     }
     // conv1 D: row = oc = (lane >> 4) * 4 + reg, col = position;  conv2 D: row = oc = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float bias1[4], bias2[16];
@@ -225,10 +254,24 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
     for (int r = 0; r < 4; r++) bias1[r] = b1[(lane >> 4) * 4 + r];
 #pragma unroll
     for (int r = 0; r < 16; r++) bias2[r] = b2[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-    __syncthreads();  // W1 fragments visible; the only block barrier of the kernel
+    __syncthreads();  // W1 / W2lo fragments visible; the only block barrier of the kernel
+
+    // ---- tiles.  The LDS serves a 16-byte-per-lane read 16 lanes at a time, one 16-byte bank group each: the 16 cells
+    //      those lanes address must differ modulo 16.  Rows are 10 cells apart, so a tile pairs rows FOUR apart
+    //      (40 = 8 mod 16): 8 + 8 cells that tile the residues exactly, wherever the tap shifts them.
+    //      conv1 tile (16 positions) c of plane d: rows c and c + 4;  conv2 tile (32 positions) u of plane d: rows
+    //      2u, 2u + 4, 2u + 1, 2u + 5.  Column r of the MFMA's B operand = position (row(r >> 3), x = r & 7). ----
+    const int x8 = lane & 7;
+    const int cell1 = ((lane >> 3) & 1) * 40 + 10 + x8 + 1;                       // conv1: + (d * 100 + c * 10)
+    const int cell2 = (((lane >> 3) & 1) * 4 + ((lane >> 4) & 1)) * 10 + 10 + x8 + 1;  // conv2: + (d * 100 + 2u * 10)
+    const int h2 = lane >> 5;
 
     const int stride = gridDim.x * 4;
     int b = blockIdx.x * 4 + wave;
+#ifdef MMW_STAMPS
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid == 0) g_conv_stamps[7] += 1;
+#endif
     // input of the first sample: lane owns positions lane, lane + 64, (lane + 128): 5 floats each
     constexpr int PPL = C::kPos / 64;
     float xin[PPL][5];
@@ -240,6 +283,11 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
     }
     for (; b < B; b += stride) {
         // ---- this sample's input into the padded channels-last volume, split ----
+        if (C::kStageOverX) {  // the previous sample's staging tile lay over the first cells of X8: borders back to zero
+            uint4 *z = reinterpret_cast<uint4 *>(Xhi);
+#pragma unroll
+            for (int i = 0; i < C::kStage / 16 / 64; i++) z[i * 64 + lane] = uint4{0, 0, 0, 0};
+        }
 #pragma unroll
         for (int q = 0; q < PPL; q++) {
             h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -257,90 +305,145 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- conv1: tiles of 16 positions; D[oc][pos] ----
+        CSTAMP(1);  // input staging
+        // ---- conv1: the four 16-position tiles of a plane at a time (they share the weight fragments); D[oc][pos] ----
 #pragma unroll 1
-        for (int t = 0; t < C::kPos / 16; t++) {
-            const int p = t * 16 + (lane & 15), pc = C::padded(p), d = p >> 6;
-            f32x4 am = {0.f, 0.f, 0.f, 0.f}, ac = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < NZ; d++) {
+            int pc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pc[u] = d * 100 + u * 10 + cell1;
+            f32x4 am[4], ac[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { am[u] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[u] = am[u]; }
 #pragma unroll
             for (int s = 0; s < C::kS1; s++) {
-                const int tap = 4 * s + (lane >> 4);
+                const int g = lane >> 4, tap = 4 * s + g;
                 const int kd = NZ == 3 ? tap / 9 : 1;
                 const bool ok = tap < C::kTaps && (unsigned)(d + kd - 1) < (unsigned)NZ;
-                int off = 0;
-                {   // tap offset of this lane's tap (the four candidates of the step are compile-time constants)
-                    const int g = lane >> 4;
-                    const int o0 = C::tap_off(4 * s + 0 < C::kTaps ? 4 * s + 0 : 0), o1 = C::tap_off(4 * s + 1 < C::kTaps ? 4 * s + 1 : 0),
-                              o2 = C::tap_off(4 * s + 2 < C::kTaps ? 4 * s + 2 : 0), o3 = C::tap_off(4 * s + 3 < C::kTaps ? 4 * s + 3 : 0);
-                    off = g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3;
-                }
-                const int idx = ok ? pc + off : C::kPad;
-                const h8 xh = Xhi[idx], xl = Xlo[idx];
+                // tap offset of this lane's tap (the four candidates of the step are compile-time constants)
+                const int o0 = C::tap_off(4 * s + 0 < C::kTaps ? 4 * s + 0 : 0), o1 = C::tap_off(4 * s + 1 < C::kTaps ? 4 * s + 1 : 0),
+                          o2 = C::tap_off(4 * s + 2 < C::kTaps ? 4 * s + 2 : 0), o3 = C::tap_off(4 * s + 3 < C::kTaps ? 4 * s + 3 : 0);
+                const int off = g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3;
                 const h8 wh = W1hi[s * 64 + lane], wl = W1lo[s * 64 + lane];
-                am = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, am, 0, 0, 0);
-                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, ac, 0, 0, 0);
-                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, ac, 0, 0, 0);
+                h8 xh[4], xl[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = ok ? pc[u] + off : C::kPad; xh[u] = Xhi[i]; xl[u] = Xlo[i]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) am[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[u], am[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) ac[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[u], ac[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) ac[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[u], ac[u], 0, 0, 0);
             }
-            h4 hi, lo;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = (am[r] + ac[r] * (1.0f / kSplitScale)) + bias1[r];
-                v = v > 0.f ? v : 0.f;
-                _Float16 a, l2;
-                split16(v, a, l2);
-                hi[r] = a; lo[r] = l2;
-            }
-            // channels 4g .. 4g+3 of position p
-            reinterpret_cast<h4 *>(Hhi + 2 * pc)[lane >> 4] = hi;
-            reinterpret_cast<h4 *>(Hlo + 2 * pc)[lane >> 4] = lo;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- conv2: tiles of 32 positions (half a plane: the plane d is uniform); D[oc][pos] ----
-        _Float16 *o = out + (size_t)b * 2 * (C::kPos * 32);
-#pragma unroll 1
-        for (int t = 0; t < C::kPos / 32; t++) {
-            const int p = t * 32 + (lane & 31), pc = C::padded(p), d = t >> 1;
-            f32x16 am, ac;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { am[r] = 0.f; ac[r] = 0.f; }
-#pragma unroll
-            for (int tap = 0; tap < C::kTaps; tap++) {
-                if ((unsigned)(d + C::tap_kd(tap) - 1) >= (unsigned)NZ) continue;  // uniform: the tap reads a plane outside the volume
-                const int idx = 2 * (pc + C::tap_off(tap)) + (lane >> 5);
-                const h8 xh = Hhi[idx], xl = Hlo[idx];
-                am = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh, am, 0, 0, 0);
-                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl, ac, 0, 0, 0);
-                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2lo[tap], xh, ac, 0, 0, 0);
-            }
-            // epilogue: bias, relu, split; four consecutive channels per register group -> staging tile [pos][oc]
-#pragma unroll
-            for (int qg = 0; qg < 4; qg++) {
+            for (int u = 0; u < 4; u++) {
                 h4 hi, lo;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float v = (am[qg * 4 + r] + ac[qg * 4 + r] * (1.0f / kSplitScale)) + bias2[qg * 4 + r];
+                    float v = (am[u][r] + ac[u][r] * (1.0f / kSplitScale)) + bias1[r];
                     v = v > 0.f ? v : 0.f;
                     _Float16 a, l2;
                     split16(v, a, l2);
                     hi[r] = a; lo[r] = l2;
                 }
-                const int oc0 = 8 * qg + 4 * (lane >> 5);
-                *reinterpret_cast<h4 *>(stage + (lane & 31) * 32 + oc0) = hi;
-                *reinterpret_cast<h4 *>(stage + 1024 + (lane & 31) * 32 + oc0) = lo;
+                // channels 4g .. 4g+3 of the position: plane g >> 1, half (g & 1) of its 16-byte cell
+                const int g = lane >> 4;
+                reinterpret_cast<h4 *>(Hhi + (g >> 1) * CE + pc[u])[g & 1] = hi;
+                reinterpret_cast<h4 *>(Hlo + (g >> 1) * CE + pc[u])[g & 1] = lo;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // the tile's 32 x 32 halfs are contiguous in the output ([pos][oc]): 2 KiB per half, 16 bytes per lane and pass
-            const uint4 *sv = reinterpret_cast<const uint4 *>(stage);
-            uint4 *gh = reinterpret_cast<uint4 *>(o + t * 1024), *gl = reinterpret_cast<uint4 *>(o + C::kPos * 32 + t * 1024);
-            gh[lane] = sv[lane]; gh[64 + lane] = sv[64 + lane];
-            gl[lane] = sv[128 + lane]; gl[64 + lane] = sv[192 + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        CSTAMP(2);  // conv1
+        // ---- conv2: the two 32-position tiles of a plane at a time (the plane is uniform: taps that read a plane outside
+        //      the volume are skipped at compile time); D[oc][pos] ----
+        _Float16 *o = out + (size_t)b * 2 * (C::kPos * 32);
+        const h8 *Hh = Hhi + h2 * CE, *Hl = Hlo + h2 * CE;   // this lane's channel plane
+#pragma unroll
+        for (int d = 0; d < NZ; d++) {
+            const int pc0 = d * 100 + cell2, pc1 = pc0 + 20;
+            f32x16 am0, ac0, am1, ac1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { am0[r] = 0.f; ac0[r] = 0.f; am1[r] = 0.f; ac1[r] = 0.f; }
+            // Software-pipelined over the plane's valid taps: the operands of tap k+1 are requested BEFORE the six MFMAs
+            // of tap k are issued.
+            h8 xh0, xl0, xh1, xl1, wlo;
+            {
+                int t0 = 0;
+#pragma unroll
+                for (int tt = 0; tt < C::kTaps; tt++) if ((unsigned)(d + C::tap_kd(tt) - 1) < (unsigned)NZ) { t0 = tt; break; }
+                const int i0 = pc0 + C::tap_off(t0), i1 = pc1 + C::tap_off(t0);
+                xh0 = Hh[i0]; xl0 = Hl[i0]; xh1 = Hh[i1]; xl1 = Hl[i1];
+                wlo = W2lo[t0 * 64 + lane];
+            }
+#pragma unroll
+            for (int tap = 0; tap < C::kTaps; tap++) {
+                if ((unsigned)(d + C::tap_kd(tap) - 1) >= (unsigned)NZ) continue;  // compile-time (d and tap are unrolled)
+                int nxt = -1;
+#pragma unroll
+                for (int tt = C::kTaps - 1; tt > tap; tt--) if ((unsigned)(d + C::tap_kd(tt) - 1) < (unsigned)NZ) nxt = tt;
+                h8 nh0 = xh0, nl0 = xl0, nh1 = xh1, nl1 = xl1, nw = wlo;
+                if (nxt >= 0) {
+                    const int i0 = pc0 + C::tap_off(nxt), i1 = pc1 + C::tap_off(nxt);
+                    nh0 = Hh[i0]; nl0 = Hl[i0]; nh1 = Hh[i1]; nl1 = Hl[i1];
+                    nw = W2lo[nxt * 64 + lane];
+                }
+                am0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh0, am0, 0, 0, 0);
+                am1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh1, am1, 0, 0, 0);
+                ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl0, ac0, 0, 0, 0);
+                ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl1, ac1, 0, 0, 0);
+                ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh0, ac0, 0, 0, 0);
+                ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh1, ac1, 0, 0, 0);
+                xh0 = nh0; xl0 = nl0; xh1 = nh1; xl1 = nl1; wlo = nw;
+            }
+            CSTAMP(3);  // conv2 MFMA loop
+            // epilogue: bias, relu, split; four consecutive channels per register group -> staging tile [column r][oc]
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+#pragma unroll
+                for (int qg = 0; qg < 4; qg++) {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float m = u ? am1[qg * 4 + r] : am0[qg * 4 + r], c = u ? ac1[qg * 4 + r] : ac0[qg * 4 + r];
+                        float v = (m + c * (1.0f / kSplitScale)) + bias2[qg * 4 + r];
+                        v = v > 0.f ? v : 0.f;
+                        _Float16 a, l2;
+                        split16(v, a, l2);
+                        hi[r] = a; lo[r] = l2;
+                    }
+                    const int oc0 = 8 * qg + 4 * (lane >> 5);
+                    *reinterpret_cast<h4 *>(stage + (lane & 31) * 32 + oc0) = hi;
+                    *reinterpret_cast<h4 *>(stage + 1024 + (lane & 31) * 32 + oc0) = lo;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // columns 8k .. 8k+7 of the tile are row (2u + (k >> 1) + 4 (k & 1)) of the plane: 512 contiguous bytes of
+                // the output ([pos][oc]) each; 16 bytes per lane and pass, two rows per pass
+                const uint4 *sv = reinterpret_cast<const uint4 *>(stage);
+#pragma unroll
+                for (int ps = 0; ps < 2; ps++) {
+                    const int k = ps * 2 + (lane >> 5);
+                    const int row = 2 * u + (k >> 1) + 4 * (k & 1);
+                    const size_t e = ((size_t)(d * 64 + row * 8) * 32) + (size_t)(lane & 31) * 8;   // halfs
+                    *reinterpret_cast<uint4 *>(o + e) = sv[ps * 64 + lane];
+                    *reinterpret_cast<uint4 *>(o + C::kPos * 32 + e) = sv[128 + ps * 64 + lane];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            CSTAMP(4);  // conv2 epilogue + stores
         }
     }
 }
+#ifdef MMW_STAMPS
+extern "C" int mmw_diag_conv_stamps(unsigned long long *out /*[8]*/, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 template <int NZ>
 static void launch_conv16_t(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
@@ -348,7 +451,7 @@ static void launch_conv16_t(const float *feat, const float *w1, const float *b1,
 {
     static bool prepared = false;
     if (!prepared) {
-        hipFuncSetAttribute((const void *)k_mars_conv16<NZ>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv16<NZ>::kLds);
+        (void)hipFuncSetAttribute((const void *)k_mars_conv16<NZ>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv16<NZ>::kLds);
         prepared = true;
     }
     int grid = (B + 3) / 4;
