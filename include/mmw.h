@@ -84,7 +84,10 @@ typedef struct mmw_config {
                                        ClusterTrack.seek_inner_clusters (Tracking.py:409-448) after every associate_pointcloud */
     int32_t db_points_thres;        /* DB_POINTS_THRES :76   (seek_inner_clusters) */
     int32_t fb_frames_batch_static; /* FB_FRAMES_BATCH_STATIC :67 */
-    int32_t reserved0;
+    int32_t chain_side_stream;      /* not a reference constant: where the small-cloud DBSCAN (pair-count screen, BallTree chain) of a
+                                       frame runs.  0 = automatic (contexts of >= 1024 scenes: worker blocks on a second stream beside
+                                       the association kernel, whatever they have not taken by its end in the post kernel), -1 = post
+                                       kernel only, 1 = always with the side stream (tests run both) */
     double db_spread_thres;         /* DB_SPREAD_THRES :77 */
     double db_inner_eps;            /* DB_INNER_EPS :78 */
     double m_x, m_y, m_z;           /* M_X, M_Y, M_Z :31-33  monitoring point (calc_projection_points, Utils.py:180-219) */
@@ -305,6 +308,10 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
  * [6] gate evaluations (points x tracks)  [7] clusters found.  Definitions: DESIGN.md §4. */
 int mmw_stats_get(mmw_ctx *ctx, uint64_t *out /*[8]*/);
 int mmw_stats_reset(mmw_ctx *ctx);
+/* Diagnostic: the queue of scenes whose small-cloud DBSCAN k_track could not rule out (k_dbscan.hip), per step parity p:
+ * [8p] pushed, [8p+1] claimed, [8p+2] finished this step; [3] last step whose k_post has begun, [4] waits given up (also
+ * reported by mmw_check).  Sync; does not wait for the context's stream. */
+int mmw_diag_queue(mmw_ctx *ctx, int32_t *out /*[16]*/);
 /* [0..7] as mmw_stats_get; [8..29] per-phase cycle sums, non-zero only in the diagnostic build
  * (make -C mmwave_msc_amd/csrc STAMPS=1), see scripts/phase_stamps.py; [30] k_features algorithmic bytes (ring rows
  * read + fp32 tensors written)  [31] feature tensors written. */

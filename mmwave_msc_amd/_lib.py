@@ -32,7 +32,7 @@ EXPORTS = [
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
-    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split",
+    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_diag_queue",
 ]
 
 
@@ -50,7 +50,7 @@ class MmwConfig(C.Structure):
         ("intensity_std", C.c_double), ("s_height", C.c_double), ("tilt_cos", C.c_double), ("tilt_sin", C.c_double),
         ("default_posture", C.c_float * NKP),
         ("kalman_dense_min_units", C.c_int32), ("seek_inner", C.c_int32), ("db_points_thres", C.c_int32),
-        ("fb_frames_batch_static", C.c_int32), ("reserved0", C.c_int32),
+        ("fb_frames_batch_static", C.c_int32), ("chain_side_stream", C.c_int32),
         ("db_spread_thres", C.c_double), ("db_inner_eps", C.c_double),
         ("m_x", C.c_double), ("m_y", C.c_double), ("m_z", C.c_double),
         ("v_screen_fade_size_max", C.c_double), ("v_screen_fade_size_min", C.c_double), ("v_screen_fade_weight", C.c_double),
@@ -169,6 +169,7 @@ def load():
         "mmw_version": (C.c_char_p, []),
         "mmw_stats_get": (C.c_int, [vp, vp]),
         "mmw_stats_reset": (C.c_int, [vp]),
+        "mmw_diag_queue": (C.c_int, [vp, vp]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
         "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),
         "mmw_mars_conv_split": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, i32]),

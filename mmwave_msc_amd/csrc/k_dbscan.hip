@@ -1098,6 +1098,95 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
     }
 }
 
+// The chain workers: claim scenes from the queue over list 3 (k_track pushes them while it runs) and do
+// apply_DBscan + _add_tracks for each: the exact pair count of the screen first, the BallTree only if a core point is
+// still possible.  Run by the blocks of k_chain (a second stream, BESIDE k_track: a ~60 us BallTree chain then sits in
+// k_track's shadow instead of behind the Kalman update) and by the worker blocks of k_post (after k_track: whatever is
+// left; correctness never depends on k_chain having run).  `epoch` = this step's number: k_post raises q[kQStop] to it when
+// it starts, i.e. when no more pushes can come.  Every wait is bounded.
+constexpr int kChainBlocks = 8;
+constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: ~80 ms
+// Polls are RELAXED device-scope atomic loads (served by the L2, no side effects): an ACQUIRE load invalidates the caches of
+// the polling CU -- and the non-coherent lines of its XCD's L2 -- every time, and 64 pollers doing that made k_track, which
+// runs beside them, 50 % slower.  One acquire fence follows a successful claim instead.
+__device__ __forceinline__ int q_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void q_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+// FROM_POST: the caller is k_post (the step's pushes are complete): tickets are taken with one atomicAdd -- a ticket past
+// the count ends the block, and the counters are reset before their parity is used again.  k_chain claims with a
+// compare-and-swap only when an entry is there, so a worker that gives up (bounded wait) never holds a ticket.
+template <bool FROM_POST>
+__device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
+                                                  int epoch, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    DbLds L;
+    db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
+    // screen scratch behind the BallTree carve-up (post_lds_bytes reserves it)
+    char *scr = lds_raw + db_align16(db_lds_layout<false>(UMc, CL, true, nullptr, nullptr));
+    float4 *P4 = reinterpret_cast<float4 *>(scr);
+    int *cnt = reinterpret_cast<int *>(scr + 4096), *flag = cnt + 256;
+    unsigned long long *mm = reinterpret_cast<unsigned long long *>(flag + 2);
+    int *ticket = flag + 8;  // (behind mm[3]; post_lds_bytes reserves it)
+    int32_t *q = st.q + parity * 8;
+    int32_t *ring = st.db_list;  // list 0
+    bool have = false;  // an item of this block is being finished (uniform)
+    for (;;) {
+        __syncthreads();  // every thread is done with the previous scene: its stores are issued, LDS is free again
+        if (threadIdx.x == 0) {
+            if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
+            int s = -1, h = -1;
+            if (FROM_POST) {
+                h = atomicAdd(&q[kQHead], 1);
+                if (h >= q_load(&q[kQCount])) h = -1;
+            } else {
+                for (int spins = 0; spins < kSpinLimit; spins++) {
+                    const int hh = q_load(&q[kQHead]), c = q_load(&q[kQCount]);
+                    if (hh < c) {
+                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh; break; }
+                        continue;
+                    }
+                    if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and the queue is empty: done
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (h >= 0) {
+                // the entry follows its count by a few instructions in the pushing workgroup
+                int32_t *e = ring + h;
+                int v = 0;
+                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&q[kQDone], 1); }
+                else {
+                    __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q_acquire();  // what the pushing workgroup stored for the scene is visible from here on
+                    s = v - 1;
+                }
+            }
+            *ticket = s;
+        }
+        __syncthreads();
+        const int s = *ticket;  // (rewritten only behind the barrier at the top of the next round)
+        if (s < 0) return;
+        have = true;
+        SceneHdr *hdr = st.hdr + s;
+        const int U = hdr->db_u;
+        // (seek_inner contexts run no k_chain; k_inner may have filled the track list after k_track queued the scene: then
+        //  there is no apply_DBscan this frame -- uniform)
+        if (!(cfg.seek_inner && !hdr->need_db)) {
+            if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
+                cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
+            else
+                spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chain(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int epoch,
+                                               int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    chain_worker_loop<false>(cfg, st, lds_raw, UMc, CL, UM_out, parity, epoch, labels_out, db_n_out);
+}
+
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
 //   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
 //                    <= 256 points k_track's cell count could not rule out): the exact pair count, then for
@@ -1109,7 +1198,8 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
 // clusters, the spawn appends records behind them.
 template <int DX>
 __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
-                                              int UM_out, int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+                                              int UM_out, int parity, int epoch, int32_t *__restrict__ labels_out,
+                                              int32_t *__restrict__ db_n_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     if ((int)blockIdx.x < G0) {
@@ -1150,26 +1240,38 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             }
             __syncthreads();
         }
-        DbLds L;
-        db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
-        const int count = st.db_count[parity * 4 + 3];
-        // screen scratch behind the BallTree carve-up (post_lds_bytes reserves it)
-        char *scr = lds_raw + db_align16(db_lds_layout<false>(UMc, CL, true, nullptr, nullptr));
-        float4 *P4 = reinterpret_cast<float4 *>(scr);
-        int *cnt = reinterpret_cast<int *>(scr + 4096), *flag = cnt + 256;
-        unsigned long long *mm = reinterpret_cast<unsigned long long *>(flag + 2);
-        for (int w = blockIdx.x; w < count; w += G0) {
-            const int s = st.db_list[(size_t)3 * cfg.n_scenes + w];
-            SceneHdr *hdr = st.hdr + s;
-            const int U = hdr->db_u;
-            if (cfg.seek_inner && !hdr->need_db) continue;  // k_inner filled the track list: no apply_DBscan this frame (uniform)
-            // k_track's cell count left this cloud undecided: the exact pair count first (mmw_cloud.hpp), the
-            // BallTree only if a core point is still possible
-            if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
-                cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
-            else
-                spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
-            __syncthreads();  // LDS is reused by the next scene
+        // k_track has finished: no more pushes this step.  (Every worker block says so: the first to arrive releases k_chain.)
+        if (threadIdx.x == 0) atomicMax(&st.q[kQStop], epoch);
+        {   // list 3 (the clouds k_track did not queue early): a static share per block, as short as a pair count each
+            DbLds L;
+            db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
+            char *scr = lds_raw + db_align16(db_lds_layout<false>(UMc, CL, true, nullptr, nullptr));
+            float4 *P4 = reinterpret_cast<float4 *>(scr);
+            int *cnt = reinterpret_cast<int *>(scr + 4096), *flag = cnt + 256;
+            unsigned long long *mm = reinterpret_cast<unsigned long long *>(flag + 2);
+            const int count = st.db_count[parity * 4 + 3];
+            for (int w = blockIdx.x; w < count; w += G0) {
+                const int s = st.db_list[(size_t)3 * cfg.n_scenes + w];
+                SceneHdr *hdr = st.hdr + s;
+                const int U = hdr->db_u;
+                if (cfg.seek_inner && !hdr->need_db) continue;  // k_inner filled the track list: no apply_DBscan this frame (uniform)
+                if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
+                    cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
+                else
+                    spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
+                __syncthreads();  // LDS is reused by the next scene
+            }
+        }
+        chain_worker_loop<true>(cfg, st, lds_raw, UMc, CL, UM_out, parity, epoch, labels_out, db_n_out);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // the launch must not end before every claimed scene is finished (k_chain may still hold one): the next
+            // launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
+            const int32_t *qp = st.q + parity * 8;
+            const int want = q_load(&qp[kQCount]);
+            long long spins = 0;
+            while (q_load(&qp[kQDone]) < want && spins < (1LL << 23)) { __builtin_amdgcn_s_sleep(8); spins++; }
+            if (q_load(&qp[kQDone]) < want) atomicAdd(&st.q[kQTimeout], 1);
+            q_acquire();
         }
         return;
     }
@@ -1256,7 +1358,7 @@ size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false,
 static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
 {
     const size_t upd = (size_t)4 * 4 * kUpdScratch * sizeof(double);
-    const size_t db = db_align16(dbscan_lds_bytes(0, UM, t_cap, min_samples)) + 4096 + (256 + 2) * 4 + 3 * 8 + 16;  // + pair-count scratch
+    const size_t db = db_align16(dbscan_lds_bytes(0, UM, t_cap, min_samples)) + 4096 + (256 + 2) * 4 + 3 * 8 + 16 + 64;  // + pair-count scratch + ticket
     return upd > db ? upd : db;
 }
 
@@ -1265,6 +1367,8 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     hipError_t e = hipFuncSetAttribute((const void *)k_post<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_post<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
     size_t big = dbscan_lds_bytes(1, UM, t_cap, min_samples);
     if (dbscan_lds_bytes(2, UM, t_cap, min_samples) > big) big = dbscan_lds_bytes(2, UM, t_cap, min_samples);
@@ -1295,7 +1399,7 @@ void launch_inner(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, i
 }
 
 // _update_all + the BallTree DBSCAN of the small clouds (work list 3)
-void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int32_t *labels, int32_t *db_n,
+void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n,
                  hipStream_t stream)
 {
     int nq = (cfg.tr_max_tracks + 3) / 4;
@@ -1304,8 +1408,16 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
     const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
     const size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
     const dim3 grid(G0 + (units + 3) / 4);
-    if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
-    else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, labels, db_n);
+    if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, epoch, labels, db_n);
+    else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, epoch, labels, db_n);
+}
+
+// The chain workers beside k_track (a second stream; see chain_worker_loop)
+void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side)
+{
+    const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
+    const size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
+    hipLaunchKernelGGL(k_chain, dim3(kChainBlocks), dim3(256), lds, side, cfg, st, umc, cl, UM, parity, epoch, labels, db_n);
 }
 
 // The larger clouds (work lists 1 and 2; the start-up frames of a scene): k_dbscan_big.

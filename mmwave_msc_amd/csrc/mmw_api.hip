@@ -18,7 +18,9 @@ thread_local LaunchProf g_launch_prof;
 size_t track_lds_bytes(const DevCfg &c);
 hipError_t prepare_track(const DevCfg &cfg);
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream);
-void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
+void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n,
+                 hipStream_t stream);
+void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
@@ -63,6 +65,8 @@ struct mmw_ctx {
     int device;
     int UM;                      // ring * max_pts
     hipStream_t own_stream, stream;
+    hipStream_t side_stream = nullptr;   // k_chain beside k_track (contexts with dc.side_worker)
+    int epoch = 0;                       // step number (queue protocol of list 3, k_dbscan.hip)
     std::string err;
     // internal scratch
     int32_t *d_row_off = nullptr;     // [S+1]
@@ -71,7 +75,7 @@ struct mmw_ctx {
     int32_t feat_cap[4] = {0, 0, 0, 0};
     float *d_posture = nullptr;
     unsigned long long *d_stats = nullptr;
-    int32_t *d_db_list = nullptr, *d_db_count = nullptr;
+    int32_t *d_db_list = nullptr, *d_db_count = nullptr, *d_q = nullptr;
     int step_parity = 0;
     // host-convenience staging (lazy)
     double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;
@@ -177,7 +181,7 @@ int mmw_config_default(mmw_config *c)
     memset(c, 0, sizeof(*c));
     c->fb_frames_batch = 2; c->db_min_samples = 35; c->tr_max_tracks = 4; c->kf_enable_est = 0;
     c->model_min_input = 0; c->dim_x = 9; c->ring_rows = 64; c->track_cap = 0; c->kalman_dense_min_units = 0;
-    c->seek_inner = 0; c->db_points_thres = 40; c->fb_frames_batch_static = 2; c->db_spread_thres = 0.7; c->db_inner_eps = 0.1;
+    c->seek_inner = 0; c->chain_side_stream = 0; c->db_points_thres = 40; c->fb_frames_batch_static = 2; c->db_spread_thres = 0.7; c->db_inner_eps = 0.1;
     c->m_x = 0.32; c->m_y = -0.6; c->m_z = 1.3;
     c->v_screen_fade_size_max = 0.3; c->v_screen_fade_size_min = 0.2; c->v_screen_fade_weight = 0.08;
     c->db_z_weight = 0.4; c->db_range_weight = 0.03; c->db_eps = 0.3;
@@ -224,7 +228,10 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.seek_inner = cfg->seek_inner ? 1 : 0;
     d.db_points_thres = cfg->db_points_thres; d.fb_frames_batch_static = cfg->fb_frames_batch_static;
     d.db_spread_thres = cfg->db_spread_thres; d.db_inner_eps = cfg->db_inner_eps;
-    d.var_ring = 0; d.pad1 = 0;
+    d.var_ring = 0;
+    // the BallTree chain workers beside k_track on a second stream: for contexts large enough that k_track is a long launch
+    // (a small context's whole step is shorter than a chain), and not with seek_inner (k_inner may cancel queued scenes)
+    d.side_worker = (!d.seek_inner && (cfg->chain_side_stream > 0 || (cfg->chain_side_stream == 0 && n_scenes >= 1024))) ? 1 : 0;
     if (d.seek_inner) {
         // seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
         // ring*max_pts rows: frames are stored whole.  A ring of size 0 would never leave add_frame's loop (Tracking.py:47-48).
@@ -273,6 +280,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_stats, ((size_t)kStatSlots * kStatWords + 128) * sizeof(unsigned long long));  // + probe words of the diagnostic build
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
+    ALLOC(c->d_q, 16 * sizeof(int32_t));
     ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
     ALLOC(c->st.perm, 2 * S * sizeof(int32_t));
     ALLOC(c->st.upd_count, 2 * (size_t)(cap + 1) * sizeof(int32_t));
@@ -290,9 +298,11 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     c->st.stats = c->d_stats;
     c->st.db_list = c->d_db_list;
     c->st.db_count = c->d_db_count;
+    c->st.q = c->d_q;
     if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(c->d_q, 0, 16 * sizeof(int32_t)) != hipSuccess || hipMemset(c->d_db_list, 0, 4 * S * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.upd_count, 0, 2 * (size_t)(cap + 1) * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.spc_count, 0, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
@@ -303,6 +313,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         if (hipEventCreateWithFlags(&c->feat_ev[k], hipEventDisableTiming) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipEventCreate failed"); }
     }
     c->stream = c->own_stream;
+    if (d.side_worker && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     size_t lds_b = dbscan_only_lds_bytes(c->UM);
     for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
     const size_t lds_a = track_lds_bytes(d);
@@ -327,11 +338,12 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
     if (c->h_rows) hipHostFree(c->h_rows);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return MMW_OK;
@@ -476,6 +488,10 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     if (((uintptr_t)pts & 15) != 0) return fail(c, MMW_E_ARG, "mmw_step: pts must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
+    c->epoch++;
+    // the chain workers of this step wait on the side stream for what k_track queues (nothing orders them with the
+    // context's stream but the queue itself: they only touch scenes k_track has published)
+    if (c->dc.side_worker) launch_chain(c->dc, c->st, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
     prof_arm(c, MMW_K_PREDICT, ep);
     launch_predict(c->dc, c->st, n_pts, dt, c->step_parity, c->stream);
@@ -485,7 +501,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     prof_armed_done(c, ep);
     if (c->dc.seek_inner) launch_inner(c->dc, c->st, n_pts, db_n, c->stream);  // Tracking.py:656 active
     prof_arm(c, MMW_K_POST, ep);
-    launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, db_labels, db_n, c->stream);
+    launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_DBSCAN, ep);
     launch_dbscan_big(c->dc, c->st, c->UM, c->step_parity, db_labels, db_n, c->stream);
@@ -623,6 +639,10 @@ int mmw_check(mmw_ctx *c)
         if (e & ERR_SINGULAR) return fail(c, MMW_E_SINGULAR, "scene %zu: singular 6x6 gate/innovation matrix", s);
         if (e & ERR_DIVZERO) return fail(c, MMW_E_DIVZERO, "scene %zu: (N_est-1)*N == 0 in _get_Rc / N_est == 0", s);
     }
+    int32_t q[16];
+    HIPCHK(c, hipMemcpyAsync(q, c->d_q, sizeof(q), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (q[kQTimeout] != 0) return fail(c, MMW_E_HIP, "a DBSCAN chain worker gave up waiting (%d time(s)): device hung or oversubscribed", q[kQTimeout]);
     return MMW_OK;
 }
 
@@ -847,6 +867,13 @@ int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[128]*/)
     return MMW_OK;
 }
 #endif
+int mmw_diag_queue(mmw_ctx *c, int32_t *out /*[16]*/)
+{
+    if (!c || !out) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->d_q, 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MMW_OK;
+}
 int mmw_stats_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;

@@ -34,7 +34,7 @@ struct DevCfg {
     int32_t dense_min_units;  // Kalman kernels laid out over tracks when the context has more 4-track waves than this (mmw_kalman.hpp)
     int32_t seek_inner;       // Tracking.py:656 active: seek_inner_clusters after every associate_pointcloud (k_inner)
     int32_t db_points_thres, fb_frames_batch_static;
-    int32_t var_ring, pad1;   // a global ring size was changed (mmw_set_batch_size): k_track reads ring sizes from the headers
+    int32_t var_ring, side_worker;   // side_worker: k_chain runs beside k_track on a second stream (mmw_api.hip); var_ring: a global ring size was changed (mmw_set_batch_size): k_track reads ring sizes from the headers
     double db_spread_thres, db_inner_eps;
     double db_z_weight, db_range_weight, db_eps;
     double tr_lifetime_dynamic, tr_lifetime_static, tr_vel_thres, tr_gate;
@@ -95,7 +95,10 @@ struct DevState {
     const float *default_posture;  // [57]
     unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
     int32_t *db_list;              // [4][S] scenes whose apply_DBscan the cell count could not finish this step: list 3 = clouds <= 256 points (k_post), 1 and 2 = larger ones (k_dbscan_big); filled by k_track
-    int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity
+    int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity (lists 1 and 2; list 3 is the queue below)
+    int32_t *q;                    // [16] the early queue = list 0 (n_scenes entries, 0 = empty, else scene + 1), per step parity p at
+                                   // q[8p + ...]: kQCount pushes, kQHead claims, kQDone finished items of the step (reset a step ahead by
+                                   // k_track); shared: q[kQStop] = last step whose k_post has begun (monotonic), q[kQTimeout]
     int32_t *perm;                 // [2][S] by step parity: scene handled by unit b of k_predict / k_track / k_post, heaviest scenes (most tracks) first; k_post builds the next step's
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
     int32_t *upd_count;            // [2][t_cap+1] by step parity: scenes that hold t tracks to update this frame (k_track -> k_post)
@@ -105,6 +108,8 @@ struct DevState {
     int32_t *inner_buf;            // [S][kInnerHdr + inner_cap] seek_inner_clusters calls of the last frame (cfg.seek_inner; mmw_get_inner)
     int32_t inner_cap;             // label words per scene
 };
+constexpr int kQCount = 0, kQHead = 1, kQDone = 2, kQStop = 3, kQTimeout = 4;
+constexpr int kEarlyU = 0;     // clouds of at least this many points go to the early queue (k_track.hip); a threshold above the clutter level (180) measured slower
 constexpr int kInnerHdr = 2 + 16;  // calls, labels stored, rows of the first 16 calls
 
 // n_pts[s] of a step: 1..max_pts = track() on that many points; 0 = the frame never reaches track() (offline_main.py:56

@@ -15,22 +15,27 @@ from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_
 pytestmark = pytest.mark.gpu
 
 
-_LAYOUT = {"value": 0}
+_LAYOUT = {"value": 0, "side": 0}
 
 
-@pytest.fixture(params=["per_scene", "track_wise"], autouse=True)
+@pytest.fixture(params=["per_scene", "track_wise", "track_wise+side_stream"], autouse=True)
 def kalman_layout(request):
-    """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense): by default the
-    track-wise one is only chosen for contexts with more than 1024 four-track waves (mmw_config.kalman_dense_min_units)."""
+    """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense: by default the
+    track-wise one is only chosen for contexts with more than 1024 four-track waves, mmw_config.kalman_dense_min_units), and
+    a third time with the small-cloud DBSCAN workers on the side stream (k_chain beside k_track, mmw_config.chain_side_stream:
+    by default only for contexts of >= 1024 scenes)."""
     _LAYOUT["value"] = -1 if request.param == "per_scene" else 1
+    _LAYOUT["side"] = 1 if request.param.endswith("side_stream") else -1
     yield
     _LAYOUT["value"] = 0
+    _LAYOUT["side"] = 0
 
 
 def _mk(n_scenes, max_pts, **kw):
     from mmwave_msc_amd import _lib
     from mmwave_msc_amd.batch import SceneBatch
     kw.setdefault("kalman_dense_min_units", _LAYOUT["value"])
+    kw.setdefault("chain_side_stream", _LAYOUT["side"])
     return SceneBatch(_lib.default_config(**kw), n_scenes, max_pts)
 
 
