@@ -159,6 +159,10 @@ int mmw_set_batch_size(mmw_ctx *ctx, const int32_t *scene_flags, int32_t new_siz
 /* BatchedData(init_data) (Tracking.py:38-41): the global ring of `scene` becomes ONE frame holding rows[n][8] (host,
  * n <= max_pts) instead of the empty frame a default BatchedData() starts with.  Sync. */
 int mmw_set_batch_frame(mmw_ctx *ctx, int32_t scene, const double *rows, int32_t n);
+/* mmw_config.chain_side_stream at run time: on != 0 -> the small-cloud DBSCAN workers run on a second stream beside the
+ * association kernel from the next mmw_step on, 0 -> in the post kernel only.  A caller that runs its own kernels beside
+ * the tracker (the CNN of the previous frame on another stream) may prefer them off. */
+int mmw_set_chain_side_stream(mmw_ctx *ctx, int32_t on);
 /* Run on a caller-owned hipStream_t; NULL = the context's own (non-blocking) stream.
  * Note for callers that share device buffers with another runtime: calls on DEVICE pointers are ordered with that
  * runtime's work only if both use the same stream.  torch reports the legacy default stream as

@@ -109,6 +109,10 @@ class SceneBatch:
         ptr = int(s.cuda_stream)
         self.set_stream(ptr if ptr else 1)
 
+    def set_chain_side_stream(self, on: bool):
+        """Small-cloud DBSCAN workers beside the association kernel (second stream) on / off, from the next step on."""
+        self._chk(self.L.mmw_set_chain_side_stream(self.h, 1 if on else 0))
+
     def synchronize(self):
         self._chk(self.L.mmw_synchronize(self.h))
 

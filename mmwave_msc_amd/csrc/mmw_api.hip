@@ -66,6 +66,7 @@ struct mmw_ctx {
     int UM;                      // ring * max_pts
     hipStream_t own_stream, stream;
     hipStream_t side_stream = nullptr;   // k_chain beside k_track (contexts with dc.side_worker)
+    hipEvent_t side_gate = nullptr;      // recorded on the context's stream at the head of a step: k_chain does not start before it
     int epoch = 0;                       // step number (queue protocol of list 3, k_dbscan.hip)
     std::string err;
     // internal scratch
@@ -313,7 +314,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         if (hipEventCreateWithFlags(&c->feat_ev[k], hipEventDisableTiming) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipEventCreate failed"); }
     }
     c->stream = c->own_stream;
-    if (d.side_worker && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
+    if (d.side_worker && (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                          hipEventCreateWithFlags(&c->side_gate, hipEventDisableTiming) != hipSuccess)) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     size_t lds_b = dbscan_only_lds_bytes(c->UM);
     for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
     const size_t lds_a = track_lds_bytes(d);
@@ -344,6 +346,7 @@ int mmw_destroy(mmw_ctx *c)
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
     if (c->h_rows) hipHostFree(c->h_rows);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->side_gate) hipEventDestroy(c->side_gate);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return MMW_OK;
@@ -408,6 +411,19 @@ int mmw_set_batch_frame(mmw_ctx *c, int32_t scene, const double *rows, int32_t n
     if (n > 0) HIPCHK(c, hipMemcpyAsync(dst, rows, (size_t)n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->st.hdr + scene, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+
+int mmw_set_chain_side_stream(mmw_ctx *c, int32_t on)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (on && c->dc.seek_inner) return fail(c, MMW_E_ARG, "mmw_set_chain_side_stream: not with seek_inner (k_inner may cancel queued scenes)");
+    if (on && !c->side_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->side_gate, hipEventDisableTiming));
+    }
+    c->dc.side_worker = on ? 1 : 0;   // takes effect with the next mmw_step (the queue is empty between steps)
     return MMW_OK;
 }
 
@@ -491,7 +507,14 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     c->epoch++;
     // the chain workers of this step wait on the side stream for what k_track queues (nothing orders them with the
     // context's stream but the queue itself: they only touch scenes k_track has published)
-    if (c->dc.side_worker) launch_chain(c->dc, c->st, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
+    // They must not start long before k_track does -- a caller may have queued other work on the context's stream (the CNN
+    // of the previous frame), beside which eight polling workgroups are a nuisance --: the side stream waits for an event
+    // recorded here, at the head of the step.
+    if (c->dc.side_worker) {
+        HIPCHK(c, hipEventRecord(c->side_gate, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_gate, 0));
+        launch_chain(c->dc, c->st, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
+    }
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
     prof_arm(c, MMW_K_PREDICT, ep);
     launch_predict(c->dc, c->st, n_pts, dt, c->step_parity, c->stream);

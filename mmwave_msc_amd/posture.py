@@ -33,6 +33,11 @@ class PosturePipeline:
         self.A = tracker_stream if tracker_stream is not None else torch.cuda.Stream(device=self.dev)
         self.B = (cnn_stream if cnn_stream is not None else torch.cuda.Stream(device=self.dev)) if overlap else self.A
         sb.follow_torch_stream(self.A)
+        # with the CNN on its own stream beside the tracker, the tracker's own side-stream workers (k_chain) only take
+        # compute units from the statically tiled GEMMs: off in that schedule, the context's default in the serial one
+        self._side_default = bool(sb.cfg.chain_side_stream > 0 or (sb.cfg.chain_side_stream == 0 and sb.S >= 1024)) and not sb.cfg.seek_inner
+        if self._side_default:
+            sb.set_chain_side_stream(self.B is self.A)
         shape = (self.cap, sb.ring, 8, 8, 5) if sb.ring > 1 else (self.cap, 8, 8, 5)
         with torch.cuda.stream(self.A):
             self.feat = [torch.zeros(shape, dtype=torch.float32, device=self.dev) for _ in range(2)]

@@ -13,10 +13,10 @@ for st in $STAGES; do
     bench)
       timeout 1500 python bench.py 2>&1 | tail -2 | tee gpurun_out/bench_default.json ;;
     bench256)
-      timeout 900 python bench.py --scenes 256 --pts 256 --tracks 4 --c-scenes 256 2>&1 | tail -2 | tee gpurun_out/bench_256.json ;;
+      timeout 900 python bench.py --scenes 256 --pts 256 --tracks 4 --c-scenes 256 --no-e2e --no-e2e-parity 2>&1 | tail -2 | tee gpurun_out/bench_256.json ;;
     prof)
       rm -rf gpurun_out/prof
-      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --steps 40 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1)
+      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --gen-workers 1 --steps 40 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1)
       tail -2 gpurun_out/prof_bench.log
       find gpurun_out/prof -name "*kernel_stats.csv" | head -3
       for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -12 $f; done
@@ -24,8 +24,8 @@ for st in $STAGES; do
       find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
     pmc)
       rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
-      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --steps 10 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log 2>&1)
-      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --steps 10 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log 2>&1)
+      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --gen-workers 1 --steps 10 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch.log 2>&1)
+      (cd /tmp && timeout 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --gen-workers 1 --steps 10 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/pmc_write.log 2>&1)
       python scripts/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write | tee gpurun_out/pmc_summary.json
       find gpurun_out/pmc_fetch gpurun_out/pmc_write -name "*.csv" -size +20M -delete ;;
     posture)
