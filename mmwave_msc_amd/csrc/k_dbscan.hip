@@ -106,11 +106,14 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(Y, double, UM)
     CARVE(Z, double, UM)
     if constexpr (WRITE) L->mask = (unsigned long long *)(base + off);
-    CARVE(key, double, all8 ? UM : db_pow2ceil(UM))   // (generic build: also the 64-bit half of the sort keys, one per slot)
+    // (thread-per-point build: key[] / front[] are also the cross-wave exchange of the sort, one slot per THREAD -- 512
+    // threads wherever the capacity is above 256, see db_mm_copies)
+    const int xslots = UM > 256 && UM < 512 ? 512 : UM;
+    CARVE(key, double, all8 ? xslots : db_pow2ceil(UM))   // (generic build: also the 64-bit half of the sort keys, one per slot)
     CARVE(idx, int, UM)
     CARVE(idx2, int, UM)
     CARVE(lab, int, UM)
-    CARVE(front, int, all8 ? UM : db_pow2ceil(UM))    // (generic build: the 32-bit half of the sort keys)
+    CARVE(front, int, all8 ? xslots : db_pow2ceil(UM))    // (generic build: the 32-bit half of the sort keys)
     CARVE(next, int, UM)
     CARVE(core, unsigned char, UM)
     CARVE(leafpos, unsigned char, UM)
@@ -1314,6 +1317,23 @@ __global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState
     }
 }
 
+// The start-up frames: every cloud of work list 1 fits one point per thread (the launcher knows from the ring bound).  Same
+// code as the thread-per-point branch above under a register budget that lets two workgroups share a CU.
+__global__ __launch_bounds__(kBigThreads, 4) void k_dbscan_startup(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity,
+                                                                   int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    DbLds L;
+    db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
+    const int count = st.db_count[parity * 4 + 1];
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int s = st.db_list[(size_t)cfg.n_scenes + w];
+        if (cfg.seek_inner && !st.hdr[s].need_db) continue;
+        spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+        __syncthreads();
+    }
+}
+
 // Utils.apply_DBscan on caller-provided clouds: pts[S][max_n][8]
 __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const double *__restrict__ pts,
                                                     const int32_t *__restrict__ n_all, int max_n, double eps,
@@ -1374,12 +1394,15 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     if (dbscan_lds_bytes(2, UM, t_cap, min_samples) > big) big = dbscan_lds_bytes(2, UM, t_cap, min_samples);
     e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_dbscan_startup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
 }
 
 int inner_um(const DevCfg &cfg)
 {
-    const long long v = (long long)cfg.ring * cfg.ring_rows;
+    long long v = (long long)cfg.ring * cfg.ring_rows;
+    if (v < 512) v = 512;  // (capacity only: the 512-thread build wants one exchange slot per thread)
     return (int)(v < 30 * 64 ? v : 30 * 64);  // the BallTree emulation holds <= 32 leaves
 }
 static size_t inner_lds_bytes(const DevCfg &cfg)
@@ -1421,14 +1444,25 @@ void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int parity, int
 }
 
 // The larger clouds (work lists 1 and 2; the start-up frames of a scene): k_dbscan_big.
-void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
+void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
-    if (kClassUM[0] >= UM) return;  // no cloud can exceed the small class
+    // `u_bound`: no cloud of this step has more points (the caller knows how many frames the rings can hold so soon after
+    // a reset).  The class capacities -- and with them the LDS per workgroup -- shrink to it: the start-up frame of 4096
+    // scenes (512-point clouds, class 1 only) runs three workgroups per CU instead of the one the 1536-point carve-up allows.
+    const int um = u_bound < UM ? u_bound : UM;
+    if (kClassUM[0] >= um) return;  // no cloud can exceed the small class
     const int S = cfg.n_scenes;
-    const bool two = kClassUM[1] < UM;
-    const int um1 = dbscan_class_um(1, UM), cl1 = dbscan_class_cl(1, UM, cfg.t_cap, cfg.db_min_samples);
-    const int um2 = dbscan_class_um(2, UM), cl2 = dbscan_class_cl(2, UM, cfg.t_cap, cfg.db_min_samples);
-    const size_t lds1 = dbscan_lds_bytes(1, UM, cfg.t_cap, cfg.db_min_samples), lds2 = two ? dbscan_lds_bytes(2, UM, cfg.t_cap, cfg.db_min_samples) : 0;
+    const bool two = kClassUM[1] < um;
+    const int um1 = dbscan_class_um(1, um), cl1 = dbscan_class_cl(1, um, cfg.t_cap, cfg.db_min_samples);
+    const int um2 = dbscan_class_um(2, um), cl2 = dbscan_class_cl(2, um, cfg.t_cap, cfg.db_min_samples);
+    const size_t lds1 = dbscan_lds_bytes(1, um, cfg.t_cap, cfg.db_min_samples), lds2 = two ? dbscan_lds_bytes(2, um, cfg.t_cap, cfg.db_min_samples) : 0;
+    if (um <= kBigThreads && um < UM) {  // start-up, one point per thread everywhere: the two-workgroups-per-CU build
+        const size_t lds = db_lds_layout<false>(um1, cl1, true, nullptr, nullptr);
+        int g = 256 * ((160u * 1024u) / lds >= 2 ? 2 : 1);
+        if (g > S) g = S;
+        mmw_launch(k_dbscan_startup, dim3(g), dim3(kBigThreads), lds, stream, cfg, st, um1, cl1, UM, parity, labels, db_n);
+        return;
+    }
     const size_t lds = lds1 > lds2 ? lds1 : lds2;
     int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));  // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
     if (per_cu > 2048 / kBigThreads) per_cu = 2048 / kBigThreads;

@@ -26,7 +26,7 @@ void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, cons
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
 size_t dbscan_only_lds_bytes(int UM);
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples);
-void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
+void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 hipError_t prepare_inner(const DevCfg &cfg);
 size_t inner_lds_demand(const DevCfg &cfg);
 int inner_um(const DevCfg &cfg);
@@ -78,6 +78,7 @@ struct mmw_ctx {
     unsigned long long *d_stats = nullptr;
     int32_t *d_db_list = nullptr, *d_db_count = nullptr, *d_q = nullptr;
     int step_parity = 0;
+    int ring_frames_bound = 0;   // no scene's global ring holds more frames than this (host-side knowledge: steps since the last reset)
     // host-convenience staging (lazy)
     double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;
     int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr;
@@ -359,6 +360,7 @@ int mmw_reset(mmw_ctx *c)
     launch_reset(c->dc, c->st, c->stream);
     HIPCHK(c, hipGetLastError());
     c->dc.var_ring = 0;   // fresh BatchedData objects: default sizes again
+    c->ring_frames_bound = 0;
     return MMW_OK;
 }
 
@@ -405,6 +407,7 @@ int mmw_set_batch_frame(mmw_ctx *c, int32_t scene, const double *rows, int32_t n
     HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     h.g_len = 1;
+    if (c->ring_frames_bound < 1) c->ring_frames_bound = 1;
     for (int k = 0; k < MMW_RING_MAX; k++) h.g_n[k] = 0;
     h.g_n[0] = n;
     double *dst = c->st.g_ring + ((size_t)scene * c->dc.ring + h.g_slot[0]) * (size_t)c->dc.max_pts * 8;
@@ -527,7 +530,10 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_DBSCAN, ep);
-    launch_dbscan_big(c->dc, c->st, c->UM, c->step_parity, db_labels, db_n, c->stream);
+    // a cloud is the unassigned part of the ring's frames: in the first steps after a reset it cannot be larger than the
+    // frames pushed so far, and the launch is carved (LDS per workgroup -> workgroups per CU) for that bound
+    if (c->ring_frames_bound < c->dc.ring) c->ring_frames_bound++;
+    launch_dbscan_big(c->dc, c->st, c->UM, c->ring_frames_bound * c->dc.max_pts, c->step_parity, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
     if (c->pending.size() >= 2048) prof_fold(c);
     c->step_parity ^= 1;

@@ -89,9 +89,10 @@ class MarsCNN(nn.Module):
         self.register_buffer("k_w2", torch.zeros(kt * 16 * 32))
         self.register_buffer("k_b2", torch.zeros(32))
         self.dense1_dhwc = nn.Linear(flat, hidden)
-        # the same matrix split for the fp16 matrix cores: W_hi (K, N) and [W_lo' ; W_hi] (2K, N)
-        self.register_buffer("d1_w_hi", torch.zeros((flat, hidden), dtype=torch.float16))
-        self.register_buffer("d1_w2", torch.zeros((2 * flat, hidden), dtype=torch.float16))
+        # the same matrix split for the fp16 matrix cores: W_hi (K, N) and [W_lo' ; W_hi] (2K, N), both stored transposed
+        # (K contiguous: hipBLASLt's faster operand layout for these shapes, scripts/exp_gemm_layouts.py)
+        self.register_buffer("d1_w_hi_t", torch.zeros((hidden, flat), dtype=torch.float16))
+        self.register_buffer("d1_w2_t", torch.zeros((hidden, 2 * flat), dtype=torch.float16))
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -124,8 +125,8 @@ class MarsCNN(nn.Module):
         w32 = torch.from_numpy(wk.copy()).float()                    # (K, N), what the fp32 GEMM multiplies with
         w_hi = w32.half()
         w_lo = ((w32 - w_hi.float()) * SPLIT_SCALE).half()
-        m.d1_w_hi.copy_(w_hi)
-        m.d1_w2.copy_(torch.cat([w_lo, w_hi], 0))
+        m.d1_w_hi_t.copy_(w_hi.t())
+        m.d1_w2_t.copy_(torch.cat([w_lo, w_hi], 0).t())
         m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
         m.dense1.bias.copy_(torch.from_numpy(b1).float())
         a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
@@ -181,8 +182,8 @@ class MarsCNN(nn.Module):
     def _dense1_split(self, a2: torch.Tensor) -> torch.Tensor:
         """bias + hi.W_hi + 2^-11 [hi | lo'].[W_lo' ; W_hi]: two fp16 GEMMs with fp32 accumulation and output."""
         k = a2.shape[1] // 2
-        g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi, out_dtype=torch.float32)
-        return torch.addmm(g1, a2, self.d1_w2, out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE)
+        g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi_t.t(), out_dtype=torch.float32)
+        return torch.addmm(g1, a2, self.d1_w2_t.t(), out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""

@@ -242,3 +242,40 @@ def test_track_table_carries_the_fade_square_of_the_output_step():
         const.M_X, const.M_Y, const.M_Z, const.V_SCREEN_FADE_SIZE_MAX, const.V_SCREEN_FADE_WEIGHT = old
     assert (tab2[0, 0]["fade_x"], tab2[0, 0]["fade_z"], tab2[0, 0]["fade_size"]) == (np.float32(px), np.float32(pz), np.float32(size))
     sb.close(); sb2.close()
+
+
+@pytest.mark.parametrize("S,N,T,F", [(256, 256, 4, 30), (4096, 512, 8, 12)])
+def test_baseline_configs_at_their_size_vs_oracle(S, N, T, F):
+    """BASELINE.json configs[1] (256 scenes x 256 points x 4 tracks) and configs[2] (4096 x 512 x 8, the bench's
+    workload with its side-stream DBSCAN workers) AT THEIR SIZE: after F frames the state of EVERY scene -- track
+    count / order, x, P, centroid, spread, dispersion, lifetime, point counts, ring lengths -- is bit-equal to the C
+    oracle's (run with OpenMP over the scenes), and so are the association vector and the DBSCAN labels of the last frame."""
+    import bench
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from oracle import c_oracle as co
+    pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=4)
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N, device=0)
+    ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
+    co.batch_run_f32(ob, pts[:F - 1], cnt[:F - 1], dts[:F - 1], 0)
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    o_assoc, o_lab, o_dbn = ob.step(pts[F - 1].astype(np.float64), cnt[F - 1], dts[F - 1])
+    assert np.array_equal(dbn, o_dbn)
+    for s in range(S):
+        c = cnt[F - 1, s]
+        assert np.array_equal(assoc[s, :c], o_assoc[s, :c]), s
+        if dbn[s] >= 0:
+            assert np.array_equal(labels[s, : dbn[s]], o_lab[s, : dbn[s]]), s
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    ln, rn = sb.batch_ring()
+    for s in range(S):
+        want = ob.scenes[s].tracks()
+        assert ntr[s] == len(want), s
+        for name in ("x", "P", "centroid", "min_vals", "max_vals", "spread_est", "group_disp_est", "n_est", "lifetime",
+                     "point_num", "is_static", "ring_len", "ring_n"):
+            assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
+        assert np.array_equal(rn[s, : ln[s]], ob.scenes[s].batch_ring()), s
+    sb.check()
+    sb.close()
