@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (tracker + features + CNN every frame) leg")
     ap.add_argument("--no-e2e-parity", action="store_true", help="skip the configs[3] end-to-end parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")
+    ap.add_argument("--chain-side-stream", type=int, default=0, choices=(-1, 0, 1),
+                    help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1024 scenes), 1 = on, -1 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / shard / gather plumbing only, on the CPU with gloo (tests/test_dist_gloo.py): no GPU work, no metric")
     ap.add_argument("--gen-workers", type=int, default=-1,
@@ -309,7 +311,7 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
     n_ranks_seen = dist.get_world_size() if world > 1 else 1
-    sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks), S, N, device=local_rank)
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream), S, N, device=local_rank)
     # one real stream for torch and the context: uploads, the CNN of the posture leg and the mmw_* calls on device
     # tensors are then ordered by the stream itself (torch's default stream would read as "context's own stream")
     side = torch.cuda.Stream(device=dev)
@@ -409,6 +411,7 @@ def main():
     el = max_over_ranks(el)
     sb.check()
     stats = sb.stats()
+    side_workers = {0: "off", 1: "on", 2: "unchecked"}[sb.side_workers()]   # the DBSCAN chain workers on their side streams
     prof = {k: sb.profile_get(k) for k in (_lib.K_TRACK, _lib.K_DBSCAN, _lib.K_TABLE, _lib.K_PREDICT, _lib.K_POST)}
     gathered_rows = int(gathered.shape[0])
 
@@ -526,6 +529,7 @@ def main():
             "work": {"dbscan_calls_per_step": round(float(stats[3]) / K, 1), "mean_U": round(mean_U, 1),
                      "gate_evals_per_step": round(gate_evals / K, 1), "tracks_per_scene": round(mean_T, 2),
                      "clusters_found_per_step": round(float(stats[7]) / K, 2)},
+            "side_workers": side_workers,
             "host": {"cores": cores, "logical_cpus": os.cpu_count(), "gen_s": round(t_gen, 1),
                      "note": "cores = min(logical CPUs, affinity mask, cgroup CPU quota): what the CPU baselines can really use"},
         }

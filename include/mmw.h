@@ -312,10 +312,15 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
  * [6] gate evaluations (points x tracks)  [7] clusters found.  Definitions: DESIGN.md §4. */
 int mmw_stats_get(mmw_ctx *ctx, uint64_t *out /*[8]*/);
 int mmw_stats_reset(mmw_ctx *ctx);
+/* Are the chain workers in use?  0 = no (not configured, seek_inner, or the side streams turned out to share a hardware
+ * queue with the context's stream: checked by the first mmw_step after mmw_create / mmw_set_stream /
+ * mmw_set_chain_side_stream), 1 = yes, 2 = configured, not checked yet (no step since). */
+int mmw_side_workers(mmw_ctx *ctx);
 /* Diagnostic: the queue of scenes whose small-cloud DBSCAN k_track could not rule out (k_dbscan.hip), per step parity p:
  * [8p] pushed, [8p+1] claimed, [8p+2] finished this step; [3] last step whose k_post has begun, [4] waits given up (also
- * reported by mmw_check).  Sync; does not wait for the context's stream. */
-int mmw_diag_queue(mmw_ctx *ctx, int32_t *out /*[16]*/);
+ * reported by mmw_check); [16 + 8p ...] the same three words for the queue of the clouds of more than 256 points.
+ * Sync; does not wait for the context's stream. */
+int mmw_diag_queue(mmw_ctx *ctx, int32_t *out /*[32]*/);
 /* [0..7] as mmw_stats_get; [8..29] per-phase cycle sums, non-zero only in the diagnostic build
  * (make -C mmwave_msc_amd/csrc STAMPS=1), see scripts/phase_stamps.py; [30] k_features algorithmic bytes (ring rows
  * read + fp32 tensors written)  [31] feature tensors written. */

@@ -113,6 +113,11 @@ class SceneBatch:
         """Small-cloud DBSCAN workers beside the association kernel (second stream) on / off, from the next step on."""
         self._chk(self.L.mmw_set_chain_side_stream(self.h, 1 if on else 0))
 
+    def side_workers(self) -> int:
+        """mmw_side_workers: 0 = the DBSCAN chain workers are not in use (not configured, or their streams share a hardware
+        queue with the context's stream), 1 = in use, 2 = configured but no step has checked the streams yet."""
+        return int(self.L.mmw_side_workers(self.h))
+
     def synchronize(self):
         self._chk(self.L.mmw_synchronize(self.h))
 

@@ -23,6 +23,7 @@
 //   class 1: U <= 768   256 threads
 //   class 2: U <= 1920  256 threads
 // k_track appends every scene that must cluster to the work list of its class.
+#include <cstdlib>
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 #include "mmw_cloud.hpp"
@@ -1101,12 +1102,14 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
     }
 }
 
-// The chain workers: claim scenes from the queue over list 3 (k_track pushes them while it runs) and do
-// apply_DBscan + _add_tracks for each: the exact pair count of the screen first, the BallTree only if a core point is
-// still possible.  Run by the blocks of k_chain (a second stream, BESIDE k_track: a ~60 us BallTree chain then sits in
-// k_track's shadow instead of behind the Kalman update) and by the worker blocks of k_post (after k_track: whatever is
-// left; correctness never depends on k_chain having run).  `epoch` = this step's number: k_post raises q[kQStop] to it when
-// it starts, i.e. when no more pushes can come.  Every wait is bounded.
+// The two queues k_track fills WHILE IT RUNS (q[8p + ...] over list 0: the clouds of <= 256 points that can hold a
+// cluster; q[kQBig + 8p + ...] over list 1: the clouds of more than 256 points) and their consumers.  An item is
+// apply_DBscan + _add_tracks of one scene: 40-90 us of BallTree chain for a small cloud (after the exact pair count of the
+// screen), 100-250 us for a large one.  The workgroups of k_chain take them on a second stream BESIDE k_track and k_post, so
+// a chain sits in the shadow of the bulk kernels instead of behind them; the worker blocks of k_post (small) and
+// k_dbscan_big (large) follow on the context's stream, take whatever is left and wait for the claimed items to finish --
+// correctness never depends on k_chain having run.  `epoch` = this step's number: k_post raises q[kQStop] to it when it
+// starts, i.e. when no more pushes can come.  Every wait is bounded.
 constexpr int kChainBlocks = 8;
 constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: ~80 ms
 // Polls are RELAXED device-scope atomic loads (served by the L2, no side effects): an ACQUIRE load invalidates the caches of
@@ -1115,12 +1118,11 @@ constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: ~80 ms
 __device__ __forceinline__ int q_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void q_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
-// FROM_POST: the caller is k_post (the step's pushes are complete): tickets are taken with one atomicAdd -- a ticket past
-// the count ends the block, and the counters are reset before their parity is used again.  k_chain claims with a
-// compare-and-swap only when an entry is there, so a worker that gives up (bounded wait) never holds a ticket.
-template <bool FROM_POST>
+// The small queue from k_post (the step's pushes are complete): tickets are taken with one atomicAdd -- a ticket past the
+// count ends the block, and the counters are reset before their parity is used again.  (k_chain claims with a
+// compare-and-swap only when an entry is there, so a worker that gives up -- bounded wait -- never holds a ticket.)
 __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
-                                                  int epoch, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+                                                  int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
     DbLds L;
     db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
@@ -1138,22 +1140,9 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
         if (threadIdx.x == 0) {
             if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
             int s = -1, h = -1;
-            if (FROM_POST) {
-                h = atomicAdd(&q[kQHead], 1);
-                if (h >= q_load(&q[kQCount])) h = -1;
-            } else {
-                for (int spins = 0; spins < kSpinLimit; spins++) {
-                    const int hh = q_load(&q[kQHead]), c = q_load(&q[kQCount]);
-                    if (hh < c) {
-                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh; break; }
-                        continue;
-                    }
-                    if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and the queue is empty: done
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
+            h = atomicAdd(&q[kQHead], 1);
+            if (h >= q_load(&q[kQCount])) h = -1;
             if (h >= 0) {
-                // the entry follows its count by a few instructions in the pushing workgroup
                 int32_t *e = ring + h;
                 int v = 0;
                 for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
@@ -1183,13 +1172,6 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
     }
 }
 
-__global__ __launch_bounds__(256) void k_chain(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int epoch,
-                                               int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    chain_worker_loop<false>(cfg, st, lds_raw, UMc, CL, UM_out, parity, epoch, labels_out, db_n_out);
-}
-
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
 //   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
 //                    <= 256 points k_track's cell count could not rule out): the exact pair count, then for
@@ -1210,6 +1192,8 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
         if ((int)blockIdx.x == G0 - 1) {
             // (the worker least likely to have a scene) next frame's schedule for k_track: scenes by descending
             // track count -- a counting sort over the scene headers; the order inside a count is irrelevant.
+            // (Scenes without tracks FIRST -- they are the ones that cluster their whole ring, 100-250 us on a chain
+            // worker -- was tried: no measurable gain in either window, and they are the filler k_track's tail wants.)
             // The key is n_upd, which nothing in this launch writes: n_tracks may be raised by a spawning worker
             // between the two passes, and a scene counted in one bin but scattered into another would break the
             // permutation.
@@ -1265,7 +1249,7 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
                 __syncthreads();  // LDS is reused by the next scene
             }
         }
-        chain_worker_loop<true>(cfg, st, lds_raw, UMc, CL, UM_out, parity, epoch, labels_out, db_n_out);
+        chain_worker_loop(cfg, st, lds_raw, UMc, CL, UM_out, parity, labels_out, db_n_out);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             // the launch must not end before every claimed scene is finished (k_chain may still hold one): the next
             // launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
@@ -1291,47 +1275,178 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, scratch);
 }
 
-// Work lists 1 and 2 (clouds of more than 256 points: the start-up frames of a scene) in one launch: blocks
-// [0, g1) take list 1 with the class-1 LDS carve-up, the others list 2.  In the steady state both lists
-// are empty and this is one small wave of workgroups that leave at once.
+// The clouds of more than 256 points (a scene without tracks clusters its whole ring: the start-up frames, and every scene
+// whose tracks have all expired): 100-250 us of BallTree chain each on a 512-thread workgroup.  They sit in a queue k_track
+// fills while it runs (q[kQBig + ...], ring = list 1).  Consumers:
+//   k_chain_big       a few workgroups on a side stream, BESIDE k_track and k_post (claims by compare-and-swap, leaves
+//                     when k_post has begun and the queue is empty);
+//   k_dbscan_big      behind k_post on the context's stream: takes what is left (tickets by atomicAdd: the pushes are
+//                     complete) and does not end before every claimed cloud is finished;
+//   k_dbscan_startup  the same for the first frames after a reset, when every cloud fits one point per thread, under a
+//                     register budget that lets two workgroups share a CU.
+// Correctness never depends on k_chain_big having run.
 constexpr int kBigThreads = 512;
-__global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState st, int g1, int UMc1, int CL1, int UMc2, int CL2, int UM_out,
-                                                    int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+template <bool AFTER_TRACK, bool TPP_ONLY>
+__device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
+                                                int epoch, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const bool first = (int)blockIdx.x < g1;
-    const int cls = first ? 1 : 2, UMc = first ? UMc1 : UMc2, CL = first ? CL1 : CL2;
-    const int b0 = first ? blockIdx.x : blockIdx.x - g1, nb = first ? g1 : (int)gridDim.x - g1;
     DbLds L;
-    const int count = st.db_count[parity * 4 + cls];
-    for (int w = b0; w < count; w += nb) {
-        const int s = st.db_list[(size_t)cls * cfg.n_scenes + w];
+    // the ticket word sits behind the BallTree carve-up (big_lds_bytes reserves it)
+    const size_t a = db_lds_layout<false>(UMc, CL, true, nullptr, nullptr), b = TPP_ONLY ? 0 : db_lds_layout<false>(UMc, CL, false, nullptr, nullptr);
+    int *ticket = reinterpret_cast<int *>(lds_raw + db_align16(a > b ? a : b));
+    int32_t *q = st.q + kQBig + parity * 8;
+    int32_t *ring = st.db_list + cfg.n_scenes;  // list 1
+    bool have = false;
+    for (;;) {
+        __syncthreads();  // every thread is done with the previous cloud: its stores are issued, LDS is free again
+        if (threadIdx.x == 0) {
+            if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
+            int s = -1, h = -1;
+            if (AFTER_TRACK) {
+                if (q_load(&q[kQHead]) < q_load(&q[kQCount])) {  // (an empty queue costs two loads, no atomic)
+                    h = atomicAdd(&q[kQHead], 1);
+                    if (h >= q_load(&q[kQCount])) h = -1;
+                }
+            } else {
+                for (int spins = 0; spins < kSpinLimit; spins++) {
+                    const int hh = q_load(&q[kQHead]), c = q_load(&q[kQCount]);
+                    if (hh < c) {
+                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh; break; }
+                        continue;
+                    }
+                    if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and the queue is empty: done
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            if (h >= 0) {
+                int32_t *e = ring + h;
+                int v = 0;
+                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&q[kQDone], 1); }
+                else {
+                    __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q_acquire();  // what the pushing workgroup stored for the scene is visible from here on
+                    s = v - 1;
+                }
+            }
+            *ticket = s;
+        }
+        __syncthreads();
+        const int s = *ticket;
+        if (s < 0) return;
+        have = true;
         if (cfg.seek_inner && !st.hdr[s].need_db) continue;  // cancelled by k_inner (uniform)
         // a cloud that fits one point per thread takes the thread-per-point build of the small class (registers
         // hold the 8 columns, one bitonic sort per level): 3-4x less tree-build time than the strided build
-        const bool tpp = st.hdr[s].db_u <= kBigThreads;  // uniform
+        const bool tpp = TPP_ONLY || st.hdr[s].db_u <= kBigThreads;  // uniform
         db_lds_layout<true>(UMc, CL, tpp, lds_raw, &L);
         if (tpp) spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
-        else spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
-        __syncthreads();  // LDS is reused by the next scene
+        else if constexpr (!TPP_ONLY) spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
     }
 }
 
-// The start-up frames: every cloud of work list 1 fits one point per thread (the launcher knows from the ring bound).  Same
-// code as the thread-per-point branch above under a register budget that lets two workgroups share a CU.
+// the launch must not end before every claimed cloud is finished (a side-stream worker may still hold one): the next
+// launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
+__device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
+{
+    const int32_t *qp = st.q + kQBig + parity * 8;
+    const int want = q_load(&qp[kQCount]);
+    long long spins = 0;
+    while (q_load(&qp[kQDone]) < want && spins < (1LL << 23)) { __builtin_amdgcn_s_sleep(8); spins++; }
+    if (q_load(&qp[kQDone]) < want) atomicAdd(&st.q[kQTimeout], 1);
+    q_acquire();
+}
+
+// The chain workers of the side stream: 512-thread workgroups that serve BOTH queues while k_track and k_post run -- the
+// large clouds first (the longer chains), then the small ones (pair-count screen, then the BallTree on the thread-per-point
+// build).  One kernel, one stream: every further stream with a spinning kernel is one more hardware queue the context's
+// stream must not share (see probe_side_stream in mmw_api.hip).
+__global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity, int epoch,
+                                               int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    DbLds L;
+    const size_t la = db_lds_layout<false>(UMc, CL, true, nullptr, nullptr), lb = db_lds_layout<false>(UMc, CL, false, nullptr, nullptr);
+    char *scr = lds_raw + db_align16(la > lb ? la : lb);  // screen scratch + ticket behind the BallTree carve-up (chain_lds_bytes)
+    float4 *P4 = reinterpret_cast<float4 *>(scr);
+    int *cnt = reinterpret_cast<int *>(scr + 4096), *flag = cnt + 256;
+    unsigned long long *mm = reinterpret_cast<unsigned long long *>(flag + 2);
+    int *ticket = flag + 8;  // [2]: scene, queue
+    int32_t *qs = st.q + parity * 8, *qb = st.q + kQBig + parity * 8;
+    int have = 0;  // queue of the item this workgroup is finishing (1 small, 2 large; uniform)
+    for (;;) {
+        __syncthreads();  // every thread is done with the previous cloud: its stores are issued, LDS is free again
+        if (threadIdx.x == 0) {
+            if (have) { __threadfence(); atomicAdd(&(have == 2 ? qb : qs)[kQDone], 1); }
+            int s = -1, h = -1, kind = 0;
+            for (int spins = 0; spins < kSpinLimit; spins++) {
+                const int hb = q_load(&qb[kQHead]), cb = q_load(&qb[kQCount]);
+                if (hb < cb) {
+                    if (atomicCAS(&qb[kQHead], hb, hb + 1) == hb) { h = hb; kind = 2; break; }
+                    continue;
+                }
+                const int hs = q_load(&qs[kQHead]), cs = q_load(&qs[kQCount]);
+                if (hs < cs) {
+                    if (atomicCAS(&qs[kQHead], hs, hs + 1) == hs) { h = hs; kind = 1; break; }
+                    continue;
+                }
+                if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and both queues are empty: done
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (h >= 0) {
+                // the entry follows its count by a few instructions in the pushing workgroup
+                int32_t *e = st.db_list + (kind == 2 ? cfg.n_scenes : 0) + h;
+                int v = 0;
+                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&(kind == 2 ? qb : qs)[kQDone], 1); }
+                else {
+                    __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q_acquire();  // what the pushing workgroup stored for the scene is visible from here on
+                    s = v - 1;
+                }
+            }
+            ticket[0] = s;
+            ticket[1] = kind;
+        }
+        __syncthreads();
+        const int s = ticket[0];  // (rewritten only behind the barrier at the top of the next round)
+        if (s < 0) return;
+        have = ticket[1];
+        SceneHdr *hdr = st.hdr + s;
+        const int U = hdr->db_u;
+        if (have == 2) {
+            const bool tpp = U <= kBigThreads;  // uniform
+            db_lds_layout<true>(UMc, CL, tpp, lds_raw, &L);
+            if (tpp) spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+            else spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+        } else {
+            db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
+            if (cloud_pairs_prove_no_core<kBigThreads>(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
+                cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
+            else
+                spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity,
+                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    // (k_track is complete: the count is final and a plain load.  No large cloud this step -- nearly every step of a
+    // tracked scene set -- and the whole launch leaves on that one word)
+    if (st.q[kQBig + parity * 8 + kQCount] == 0) return;
+    big_worker_loop<true, false>(cfg, st, lds_raw, UMc, CL, UM_out, parity, 0, labels_out, db_n_out);
+    if (blockIdx.x == 0 && threadIdx.x == 0) big_wait_done(st, parity);
+}
+
 __global__ __launch_bounds__(kBigThreads, 4) void k_dbscan_startup(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity,
                                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    DbLds L;
-    db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
-    const int count = st.db_count[parity * 4 + 1];
-    for (int w = blockIdx.x; w < count; w += gridDim.x) {
-        const int s = st.db_list[(size_t)cfg.n_scenes + w];
-        if (cfg.seek_inner && !st.hdr[s].need_db) continue;
-        spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
-        __syncthreads();
-    }
+    if (st.q[kQBig + parity * 8 + kQCount] == 0) return;
+    big_worker_loop<true, true>(cfg, st, lds_raw, UMc, CL, UM_out, parity, 0, labels_out, db_n_out);
+    if (blockIdx.x == 0 && threadIdx.x == 0) big_wait_done(st, parity);
 }
 
 // Utils.apply_DBscan on caller-provided clouds: pts[S][max_n][8]
@@ -1382,17 +1497,45 @@ static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
     return upd > db ? upd : db;
 }
 
+// capacity of the large-cloud kernels this step: no cloud has more than `u_bound` points (the caller knows how many frames the
+// rings can hold so soon after a reset), none more than UM, and the BallTree emulation holds 1920
+static int big_um(int UM, int u_bound)
+{
+    int um = u_bound < UM ? u_bound : UM;
+    return um < kClassUM[2] ? um : kClassUM[2];
+}
+static int big_cl(int um, int t_cap, int min_samples)
+{
+    const int cl = um / (min_samples > 0 ? min_samples : 1) + 1;
+    return cl < t_cap ? cl : t_cap;
+}
+static size_t big_lds_bytes(int um, int cl, bool tpp_only)
+{
+    const size_t a = db_lds_layout<false>(um, cl, true, nullptr, nullptr), b = tpp_only ? 0 : db_lds_layout<false>(um, cl, false, nullptr, nullptr);
+    return db_align16(a > b ? a : b) + 16;  // + the ticket word
+}
+// k_chain: the capacity of the large clouds (at least one slot per thread), + the pair-count scratch and the ticket
+static int chain_um(int UM, int u_bound)
+{
+    const int um = big_um(UM, u_bound);
+    return um < kBigThreads ? kBigThreads : um;
+}
+static size_t chain_lds_bytes(int um, int t_cap, int min_samples)
+{
+    return big_lds_bytes(um, big_cl(um, t_cap, min_samples), false) + 4096 + (256 + 2) * 4 + 3 * 8 + 16 + 64;
+}
+
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
 {
     hipError_t e = hipFuncSetAttribute((const void *)k_post<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_post<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
-    if (e != hipSuccess) return e;
-    size_t big = dbscan_lds_bytes(1, UM, t_cap, min_samples);
-    if (dbscan_lds_bytes(2, UM, t_cap, min_samples) > big) big = dbscan_lds_bytes(2, UM, t_cap, min_samples);
+    const int bum = big_um(UM, UM);
+    const size_t big = big_lds_bytes(bum, big_cl(bum, t_cap, min_samples), false);
     e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(chain_um(UM, UM), t_cap, min_samples));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_dbscan_startup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
@@ -1435,41 +1578,32 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
     else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, epoch, labels, db_n);
 }
 
-// The chain workers beside k_track (a second stream; see chain_worker_loop)
-void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side)
+// The chain workers beside k_track and k_post (a second stream; see k_chain)
+void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side)
 {
-    const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
-    const size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
-    hipLaunchKernelGGL(k_chain, dim3(kChainBlocks), dim3(256), lds, side, cfg, st, umc, cl, UM, parity, epoch, labels, db_n);
+    static const int want = getenv("MMW_CHAIN_BLOCKS") ? atoi(getenv("MMW_CHAIN_BLOCKS")) : kChainBlocks;  // (diagnostic knob: 4 .. 12 trade 1 % between the 40- and the 160-frame window)
+    const int um = chain_um(UM, u_bound), cl = big_cl(um, cfg.t_cap, cfg.db_min_samples);
+    const int g = want < cfg.n_scenes ? want : cfg.n_scenes;
+    hipLaunchKernelGGL(k_chain, dim3(g > 0 ? g : 1), dim3(kBigThreads), chain_lds_bytes(um, cfg.t_cap, cfg.db_min_samples), side, cfg, st, um, cl, UM,
+                       parity, epoch, labels, db_n);
 }
 
-// The larger clouds (work lists 1 and 2; the start-up frames of a scene): k_dbscan_big.
+// The larger clouds, what the side-stream workers have not taken: k_dbscan_big (k_dbscan_startup in the first frames
+// after a reset: 512-point clouds at most, two workgroups per CU -- 3.0 instead of 4.0 ms for frame 0 of 4096 scenes).
 void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
-    // `u_bound`: no cloud of this step has more points (the caller knows how many frames the rings can hold so soon after
-    // a reset).  The class capacities -- and with them the LDS per workgroup -- shrink to it: the start-up frame of 4096
-    // scenes (512-point clouds, class 1 only) runs three workgroups per CU instead of the one the 1536-point carve-up allows.
-    const int um = u_bound < UM ? u_bound : UM;
+    const int um = big_um(UM, u_bound);
     if (kClassUM[0] >= um) return;  // no cloud can exceed the small class
-    const int S = cfg.n_scenes;
-    const bool two = kClassUM[1] < um;
-    const int um1 = dbscan_class_um(1, um), cl1 = dbscan_class_cl(1, um, cfg.t_cap, cfg.db_min_samples);
-    const int um2 = dbscan_class_um(2, um), cl2 = dbscan_class_cl(2, um, cfg.t_cap, cfg.db_min_samples);
-    const size_t lds1 = dbscan_lds_bytes(1, um, cfg.t_cap, cfg.db_min_samples), lds2 = two ? dbscan_lds_bytes(2, um, cfg.t_cap, cfg.db_min_samples) : 0;
-    if (um <= kBigThreads && um < UM) {  // start-up, one point per thread everywhere: the two-workgroups-per-CU build
-        const size_t lds = db_lds_layout<false>(um1, cl1, true, nullptr, nullptr);
+    const int S = cfg.n_scenes, cl = big_cl(um, cfg.t_cap, cfg.db_min_samples);
+    if (um <= kBigThreads && um < UM) {
+        const size_t lds = big_lds_bytes(um, cl, true);
         int g = 256 * ((160u * 1024u) / lds >= 2 ? 2 : 1);
         if (g > S) g = S;
-        mmw_launch(k_dbscan_startup, dim3(g), dim3(kBigThreads), lds, stream, cfg, st, um1, cl1, UM, parity, labels, db_n);
+        mmw_launch(k_dbscan_startup, dim3(g), dim3(kBigThreads), lds, stream, cfg, st, um, cl, UM, parity, labels, db_n);
         return;
     }
-    const size_t lds = lds1 > lds2 ? lds1 : lds2;
-    int per_cu = (int)((160u * 1024u) / (lds ? lds : 1));  // resident workgroups per CU: ~160 KiB of LDS, 2048 threads
-    if (per_cu > 2048 / kBigThreads) per_cu = 2048 / kBigThreads;
-    if (per_cu < 1) per_cu = 1;
-    int g = 256 * per_cu;
-    if (g > S) g = S;
-    mmw_launch(k_dbscan_big, dim3(two ? 2 * g : g), dim3(kBigThreads), lds, stream, cfg, st, g, um1, cl1, um2, cl2, UM, parity, labels, db_n);
+    const int g = S < 256 ? S : 256;  // 176 VGPRs: one 512-thread workgroup per CU
+    mmw_launch(k_dbscan_big, dim3(g), dim3(kBigThreads), big_lds_bytes(um, cl, false), stream, cfg, st, um, cl, UM, parity, labels, db_n);
 }
 
 void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,

@@ -409,4 +409,21 @@ void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st)
     hipLaunchKernelGGL(k_reset, dim3((cfg.n_scenes + 255) / 256 > 0 ? (cfg.n_scenes + 255) / 256 : 1), dim3(256), 0, st, cfg, s);
 }
 
+// Do kernels of stream B run while a kernel of stream A is spinning?  Streams are multiplexed onto a few hardware queues, and
+// two streams that share one execute in order: a chain worker (side stream) that polls for what k_track (context's stream)
+// publishes would then hold k_track back until its bounded wait runs out.  mmw_api.hip probes once per stream set-up:
+// waiters on the side streams, one setter on the context's stream.
+__global__ void k_probe_wait(int32_t *w, int slot, int polls)
+{
+    int seen = 0;
+    for (int i = 0; i < polls && !seen; i++) {
+        seen = __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!seen) __builtin_amdgcn_s_sleep(8);
+    }
+    w[1 + slot] = seen;
+}
+__global__ void k_probe_set(int32_t *w) { __hip_atomic_store(&w[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+void launch_probe_wait(int32_t *w, int slot, int polls, hipStream_t st) { hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, st, w, slot, polls); }
+void launch_probe_set(int32_t *w, hipStream_t st) { hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, st, w); }
+
 }  // namespace mmw

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;  // ... and its queue counters (kQCount, kQHead, kQDone)
+    if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = 0;  // ... and those of the large clouds' queue
     if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
     if (s == 0 && tid == kThreads - 1) st.spc_count[parity ^ 1] = 0;
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
@@ -759,24 +760,22 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
             listed = !cloud_cells_prove_no_core_rows(cfg, src, Udb, mm, &L.misc[12], grid);
         }
         if (listed) {
-            // Work lists: 3 = clouds <= 256 points (k_post), 1 and 2 = larger ones (k_dbscan_big), read after this launch.
-            // List 0 is a QUEUE the chain workers claim from WHILE this launch is running (k_chain beside it; k_post's worker
-            // blocks take what is left): the small clouds that can hold a new cluster (more points than a ring of clutter:
-            // kEarlyU), i.e. the ones whose DBSCAN may be a ~60 us BallTree chain.  Everything this workgroup has stored for
-            // the scene must be visible device-wide before the queue entry is -- one full barrier + fence, paid by those
-            // scenes only.
-            const int cls = Udb <= 256 ? (Udb >= kEarlyU && cfg.side_worker ? 0 : 3) : (Udb <= 768 ? 1 : 2);  // uniform
-            if (cls == 0) __syncthreads();
+            // Work list 3 = clouds <= 256 points, read by k_post after this launch.  The other two are QUEUES consumers claim
+            // from, also WHILE this launch is running (chain workers on side streams; the kernels that follow on this stream take
+            // what is left): queue 0 = the small clouds that can hold a new cluster (more points than a ring of clutter: kEarlyU),
+            // i.e. the ones whose DBSCAN may be a ~60 us BallTree chain; queue 1 = the clouds of more than 256 points
+            // (100-250 us each).  Everything this workgroup has stored for the scene must be visible device-wide before the
+            // queue entry is -- one workgroup barrier + a release store, paid by those scenes only.
+            const int cls = Udb <= 256 ? (Udb >= kEarlyU && cfg.side_worker ? 0 : 3) : 1;  // uniform
+            if (cls != 3) __syncthreads();
             if (tid == 0) {
-                if (cls == 0) {
-                    // (the RELEASE of the entry's store is the only fence: it follows the workgroup barrier, so it covers what the
-                    //  other waves stored; a full __threadfence() here would also invalidate this CU's caches)
-                    const int pos = atomicAdd(&st.q[parity * 8 + kQCount], 1);  // (< n_scenes: one push per scene and step)
-                    __hip_atomic_store(&st.db_list[pos], s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    const int pos = atomicAdd(&st.db_count[parity * 4 + cls], 1);
-                    st.db_list[(size_t)cls * cfg.n_scenes + pos] = s;
-                }
+                // (queues: the RELEASE of the entry's store is the only fence: it follows the workgroup barrier, so it covers
+                //  what the other waves stored; a full __threadfence() here would also invalidate this CU's caches)
+                int32_t *cnt = cls == 3 ? st.db_count + parity * 4 + 3 : st.q + cls * kQBig + parity * 8 + kQCount;
+                const int pos = atomicAdd(cnt, 1);  // (< n_scenes: one push per scene and step)
+                int32_t *e = st.db_list + (size_t)cls * cfg.n_scenes + pos;
+                if (cls == 3) *e = s;
+                else __hip_atomic_store(e, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             cloud_finish_empty(st, hdr, s, Udb, UM_out, db_labels_out, db_n_out);

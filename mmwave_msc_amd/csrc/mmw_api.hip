@@ -20,7 +20,7 @@ hipError_t prepare_track(const DevCfg &cfg);
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream);
 void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n,
                  hipStream_t stream);
-void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side);
+void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
@@ -44,6 +44,8 @@ void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const 
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
 void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st);
+void launch_probe_wait(int32_t *w, int slot, int polls, hipStream_t st);
+void launch_probe_set(int32_t *w, hipStream_t st);
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
@@ -67,6 +69,9 @@ struct mmw_ctx {
     hipStream_t own_stream, stream;
     hipStream_t side_stream = nullptr;   // k_chain beside k_track (contexts with dc.side_worker)
     hipEvent_t side_gate = nullptr;      // recorded on the context's stream at the head of a step: k_chain does not start before it
+    int side_wanted = 0;                 // what the configuration / mmw_set_chain_side_stream asked for
+    int side_probed = 0;                 // the side streams have been checked against the current context stream (probe_side_streams)
+    int32_t *d_probe = nullptr;          // [4] flag + results of that check
     int epoch = 0;                       // step number (queue protocol of list 3, k_dbscan.hip)
     std::string err;
     // internal scratch
@@ -199,6 +204,43 @@ int mmw_config_default(mmw_config *c)
 
 const char *mmw_last_error(const mmw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
+// The chain workers' stream.  It must not share a hardware queue with the context's stream (the HIP runtime multiplexes
+// streams onto a few queues -- GPU_MAX_HW_QUEUES, 4 by default -- round-robin at creation): probe_side_streams checks that
+// and re-creates a stream that does.  (A highest-priority stream gets a queue of another pool, but the context's own
+// launches then start ~8 us later per step: measured, not used.)
+static hipError_t create_side_streams(mmw_ctx *c)
+{
+    hipError_t e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->side_gate, hipEventDisableTiming);
+    return e;
+}
+
+// 1 = a kernel on the context's stream runs while a kernel on `side` spins, 0 = it does not (shared hardware queue: a worker
+// polling for k_track's pushes would keep k_track from starting until its bounded wait runs out), -1 = HIP error.
+static int probe_one(mmw_ctx *c, hipStream_t side, hipStream_t other)
+{
+    const int polls = 1 << 12;   // a few ms at most; ~20 us when the streams are independent
+    if (hipMemsetAsync(c->d_probe, 0, 4 * sizeof(int32_t), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    launch_probe_wait(c->d_probe, 0, polls, side);
+    launch_probe_set(c->d_probe, other);
+    if (hipStreamSynchronize(side) != hipSuccess || hipStreamSynchronize(other) != hipSuccess) return -1;
+    int32_t w[4] = {0, 0, 0, 0};
+    if (hipMemcpy(w, c->d_probe, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return w[1] ? 1 : 0;
+}
+static int probe_side_streams(mmw_ctx *c)
+{
+    int ok = probe_one(c, c->side_stream, c->stream);
+    for (int attempt = 0; ok == 0 && attempt < 6; attempt++) {  // the next stream lands on the next hardware queue
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) return -1;
+        hipStreamDestroy(c->side_stream);
+        c->side_stream = fresh;
+        ok = probe_one(c, fresh, c->stream);
+    }
+    return ok;
+}
+
 int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t device, mmw_ctx **out)
 {
     if (!cfg || !out) return fail(nullptr, MMW_E_ARG, "mmw_create: null argument");
@@ -282,7 +324,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_stats, ((size_t)kStatSlots * kStatWords + 128) * sizeof(unsigned long long));  // + probe words of the diagnostic build
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
-    ALLOC(c->d_q, 16 * sizeof(int32_t));
+    ALLOC(c->d_q, kQWords * sizeof(int32_t));
+    ALLOC(c->d_probe, 4 * sizeof(int32_t));
     ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
     ALLOC(c->st.perm, 2 * S * sizeof(int32_t));
     ALLOC(c->st.upd_count, 2 * (size_t)(cap + 1) * sizeof(int32_t));
@@ -304,7 +347,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->d_q, 0, 16 * sizeof(int32_t)) != hipSuccess || hipMemset(c->d_db_list, 0, 4 * S * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(c->d_q, 0, kQWords * sizeof(int32_t)) != hipSuccess || hipMemset(c->d_db_list, 0, 4 * S * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.upd_count, 0, 2 * (size_t)(cap + 1) * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.spc_count, 0, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
@@ -315,8 +358,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         if (hipEventCreateWithFlags(&c->feat_ev[k], hipEventDisableTiming) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipEventCreate failed"); }
     }
     c->stream = c->own_stream;
-    if (d.side_worker && (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-                          hipEventCreateWithFlags(&c->side_gate, hipEventDisableTiming) != hipSuccess)) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
+    c->side_wanted = d.side_worker;
+    if (d.side_worker && create_side_streams(c) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     size_t lds_b = dbscan_only_lds_bytes(c->UM);
     for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
     const size_t lds_a = track_lds_bytes(d);
@@ -341,7 +384,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
                     c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
@@ -422,11 +465,9 @@ int mmw_set_chain_side_stream(mmw_ctx *c, int32_t on)
     if (!c) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (on && c->dc.seek_inner) return fail(c, MMW_E_ARG, "mmw_set_chain_side_stream: not with seek_inner (k_inner may cancel queued scenes)");
-    if (on && !c->side_stream) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->side_gate, hipEventDisableTiming));
-    }
-    c->dc.side_worker = on ? 1 : 0;   // takes effect with the next mmw_step (the queue is empty between steps)
+    if (on && !c->side_stream) HIPCHK(c, create_side_streams(c));
+    c->dc.side_worker = c->side_wanted = on ? 1 : 0;   // takes effect with the next mmw_step (the queues are empty between steps)
+    c->side_probed = 0;
     return MMW_OK;
 }
 
@@ -436,6 +477,8 @@ int mmw_set_stream(mmw_ctx *c, void *s)
     HIPCHK(c, hipSetDevice(c->device));
     hipStreamSynchronize(c->stream);
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->dc.side_worker = c->side_wanted;   // (checked against the new stream by the next mmw_step)
+    c->side_probed = 0;
     return MMW_OK;
 }
 
@@ -508,15 +551,26 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
     c->epoch++;
+    // a cloud is the unassigned part of the ring's frames: in the first steps after a reset it cannot be larger than the
+    // frames pushed so far, and the large-cloud launches are carved (LDS per workgroup -> workgroups per CU) for that bound
+    if (c->ring_frames_bound < c->dc.ring) c->ring_frames_bound++;
+    const int u_bound = c->ring_frames_bound * c->dc.max_pts;
     // the chain workers of this step wait on the side stream for what k_track queues (nothing orders them with the
     // context's stream but the queue itself: they only touch scenes k_track has published)
     // They must not start long before k_track does -- a caller may have queued other work on the context's stream (the CNN
     // of the previous frame), beside which eight polling workgroups are a nuisance --: the side stream waits for an event
     // recorded here, at the head of the step.
+    if (c->dc.side_worker && !c->side_probed) {
+        // first step on this stream set-up: the workers are only used if they really run BESIDE the context's stream
+        const int ok = probe_side_streams(c);
+        if (ok < 0) return fail(c, MMW_E_HIP, "side-stream probe failed: %s", hipGetErrorString(hipGetLastError()));
+        c->side_probed = 1;
+        if (!ok) c->dc.side_worker = 0;
+    }
     if (c->dc.side_worker) {
         HIPCHK(c, hipEventRecord(c->side_gate, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_gate, 0));
-        launch_chain(c->dc, c->st, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
+        launch_chain(c->dc, c->st, c->UM, u_bound, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
     }
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
     prof_arm(c, MMW_K_PREDICT, ep);
@@ -530,10 +584,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_DBSCAN, ep);
-    // a cloud is the unassigned part of the ring's frames: in the first steps after a reset it cannot be larger than the
-    // frames pushed so far, and the launch is carved (LDS per workgroup -> workgroups per CU) for that bound
-    if (c->ring_frames_bound < c->dc.ring) c->ring_frames_bound++;
-    launch_dbscan_big(c->dc, c->st, c->UM, c->ring_frames_bound * c->dc.max_pts, c->step_parity, db_labels, db_n, c->stream);
+    launch_dbscan_big(c->dc, c->st, c->UM, u_bound, c->step_parity, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
     if (c->pending.size() >= 2048) prof_fold(c);
     c->step_parity ^= 1;
@@ -896,11 +947,16 @@ int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[128]*/)
     return MMW_OK;
 }
 #endif
-int mmw_diag_queue(mmw_ctx *c, int32_t *out /*[16]*/)
+int mmw_side_workers(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    return c->dc.side_worker ? (c->side_probed ? 1 : 2) : 0;
+}
+int mmw_diag_queue(mmw_ctx *c, int32_t *out /*[32]*/)
 {
     if (!c || !out) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(out, c->d_q, 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->d_q, kQWords * sizeof(int32_t), hipMemcpyDeviceToHost));
     return MMW_OK;
 }
 int mmw_stats_reset(mmw_ctx *c)

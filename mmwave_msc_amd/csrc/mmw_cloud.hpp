@@ -208,7 +208,9 @@ __device__ __forceinline__ bool cloud_cells_prove_no_core_rows(const DevCfg &cfg
 }
 
 // Stage 2, O(U^2): the exact superset count over all pairs, for the clouds stage 1 left undecided (k_post),
-// read from the scene's global ring.  P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.
+// read from the scene's global ring.  P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.  NT = threads of
+// the workgroup (256 in k_post, 512 in k_chain); the count -- and with it the answer -- does not depend on it.
+template <int NT = 256>
 __device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
                                                           unsigned long long *mm, int *flag)
 {
@@ -249,9 +251,9 @@ __device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, con
     // tasks (point p, slice `part` of the partners), about four per thread
     int parts = 1024 / U;
     parts = parts < 1 ? 1 : (parts > 16 ? 16 : parts);
-    const int q256 = 256 / U, r256 = 256 - q256 * U, ntask = U * parts;
+    const int q256 = NT / U, r256 = NT - q256 * U, ntask = U * parts;
     int part = tid / U, p = tid - part * U;
-    for (int t = tid; t < ntask; t += 256) {
+    for (int t = tid; t < ntask; t += NT) {
         const float4 a = P4[p];
         int c = 0;
 #pragma unroll 4

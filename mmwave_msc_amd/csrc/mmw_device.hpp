@@ -94,11 +94,12 @@ struct DevState {
     double *g_ring;       // [S][ring][max_pts][8]
     const float *default_posture;  // [57]
     unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
-    int32_t *db_list;              // [4][S] scenes whose apply_DBscan the cell count could not finish this step: list 3 = clouds <= 256 points (k_post), 1 and 2 = larger ones (k_dbscan_big); filled by k_track
-    int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity (lists 1 and 2; list 3 is the queue below)
-    int32_t *q;                    // [16] the early queue = list 0 (n_scenes entries, 0 = empty, else scene + 1), per step parity p at
+    int32_t *db_list;              // [4][S] scenes whose apply_DBscan the cell count could not finish this step, filled by k_track: list 3 = clouds <= 256 points (k_post); rows 0 and 1 are the rings of the two queues below
+    int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity (list 3)
+    int32_t *q;                    // [kQWords] the early queue = list 0 (n_scenes entries, 0 = empty, else scene + 1), per step parity p at
                                    // q[8p + ...]: kQCount pushes, kQHead claims, kQDone finished items of the step (reset a step ahead by
-                                   // k_track); shared: q[kQStop] = last step whose k_post has begun (monotonic), q[kQTimeout]
+                                   // k_track); shared: q[kQStop] = last step whose k_post has begun (monotonic), q[kQTimeout];
+                                   // the same three words at q[kQBig + 8p + ...] for the queue of the larger clouds (ring = list 1)
     int32_t *perm;                 // [2][S] by step parity: scene handled by unit b of k_predict / k_track / k_post, heaviest scenes (most tracks) first; k_post builds the next step's
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
     int32_t *upd_count;            // [2][t_cap+1] by step parity: scenes that hold t tracks to update this frame (k_track -> k_post)
@@ -109,6 +110,8 @@ struct DevState {
     int32_t inner_cap;             // label words per scene
 };
 constexpr int kQCount = 0, kQHead = 1, kQDone = 2, kQStop = 3, kQTimeout = 4;
+constexpr int kQBig = 16;   // q[kQBig + 8p + kQCount/kQHead/kQDone]: the queue of the clouds of more than 256 points
+constexpr int kQWords = 32;
 constexpr int kEarlyU = 0;     // clouds of at least this many points go to the early queue (k_track.hip); a threshold above the clutter level (180) measured slower
 constexpr int kInnerHdr = 2 + 16;  // calls, labels stored, rows of the first 16 calls
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment: layouts / fusions of the split Dense-1 GEMMs (M = 18304, N = 1536, K = 6144, fp16 in, fp32 out)."""
-import time, torch
+import os, time, torch
 dev = torch.device("cuda:0")
 M, N, K = 18304, 1536, 6144
 S = 2048.0
@@ -36,3 +36,26 @@ for name, f in (("two GEMMs, W [K,N]", two_nn), ("two GEMMs, W^T [N,K]", two_nt)
     out = f()
     err = float((out[:256].double() - ref).abs().max())
     print(f"{name:28s} {tm(f):.3f} ms   max err vs fp64 {err:.2e}")
+
+print("preferred BLAS library by default:", torch.backends.cuda.preferred_blas_library())
+for lib in ("cublas", "cublaslt", "ck"):
+    try:
+        torch.backends.cuda.preferred_blas_library(lib)
+        for name, f in (("two GEMMs, W [K,N]", two_nn), ("two GEMMs, W^T [N,K]", two_nt)):
+            out = f()
+            err = float((out[:256].double() - ref).abs().max())
+            print(f"{lib:9s} {name:28s} {tm(f):.3f} ms   max err vs fp64 {err:.2e}")
+    except Exception as e:
+        print(lib, "failed:", str(e)[:200])
+torch.backends.cuda.preferred_blas_library("default")
+
+# the same with PyTorch's TunableOp picking among the hipBLASLt / rocBLAS solutions
+import torch.cuda.tunable as tun
+tun.enable(True); tun.tuning_enable(True); tun.set_max_tuning_duration(int(os.environ.get('TUNE_MS', '3000'))); tun.set_max_tuning_iterations(100)
+tun.set_filename("gpurun_out/tunableop_dense1.csv")
+t0 = time.perf_counter()
+for name, f in (("two GEMMs, W [K,N]", two_nn), ("two GEMMs, W^T [N,K]", two_nt)):
+    out = f()
+    err = float((out[:256].double() - ref).abs().max())
+    print(f"tuned {name:28s} {tm(f):.3f} ms   max err vs fp64 {err:.2e}   (tuning so far {time.perf_counter() - t0:.0f} s)")
+for r in tun.get_results(): print(r)

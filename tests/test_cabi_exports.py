@@ -78,8 +78,21 @@ def test_step_kernels_compile_without_scratch():
     rep = out.stderr
     names = re.findall(r"Function Name: (\S*k_track\S*)", rep)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", rep)]
-    assert len(names) >= 6 and len(scratch) >= 6, rep[-2000:]
-    # k_track<PPT, INNER>: the default instantiations (INNER = false, mangled "Lb0E") are the tuned hot path; the
-    # seek_inner ones (optional, Tracking.py:656 active) may keep an SGPR-spill stack slot the compiler never touches
-    default = [(n, v) for n, v in zip(names, scratch) if "Lb0E" in n]
-    assert len(default) == 3 and all(v == 0 for _, v in default), list(zip(names, scratch))
+    vspill = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", rep)]
+    assert len(names) >= 6 and len(scratch) >= 6 and len(vspill) >= 6, rep[-2000:]
+    # no vector register is spilled in any instantiation
+    assert all(v == 0 for v in vspill[: len(names)]), list(zip(names, vspill))
+    # k_track<PPT, INNER>: the instantiations of the benchmarked configurations (PPT 1 and 2, INNER = false, mangled
+    # "Lb0E") have no stack at all
+    hot = [(n, v) for n, v in zip(names, scratch) if "Lb0E" in n and ("ILi1E" in n or "ILi2E" in n)]
+    assert len(hot) == 2 and all(v == 0 for _, v in hot), list(zip(names, scratch))
+    # the others (PPT 4: frames of up to 1024 points; seek_inner, Tracking.py:656 active) may keep an SGPR-spill stack slot
+    # the compiler reserves but never touches: the ISA of such a kernel must not hold a single scratch access
+    slotted = [n for n, v in zip(names, scratch) if v != 0]
+    if slotted:
+        asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                              "--cuda-device-only", "-S", "-c", src, "-o", "-"], capture_output=True, text=True, timeout=600).stdout
+        for n in slotted:
+            body = asm[asm.index("\n" + n + ":"):]
+            body = body[: body.index("s_endpgm")]
+            assert not re.search(r"\bscratch_|buffer_(load|store)\S* .*offen", body), n

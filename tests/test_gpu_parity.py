@@ -403,3 +403,59 @@ def test_seek_inner_many_scenes_vs_oracle():
     assert split >= 4, "no inner split happened: the scenario does not exercise the spawn"
     sb.check()
     sb.close()
+
+
+def test_side_workers_are_probed_and_switchable():
+    """The DBSCAN chain workers run on a side stream only after the first step has checked that this stream does not
+    share a hardware queue with the context's stream (mmw_side_workers: 2 = unchecked, 1 = in use, 0 = off); large and
+    small clouds give the oracle's labels with the workers on and off."""
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    S, N, F = 24, 256, 8
+    pts = np.zeros((F, S, N, 8), np.float32)
+    cnt = np.zeros((F, S), np.int32)
+    dts = np.zeros((F, S))
+    for s in range(S):   # every third scene is clutter only: it clusters its whole ring (up to 768 points) every frame
+        p, c, d = make_batch([5200 + s], F, N, s % 3)
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    results = []
+    for on in (1, -1):
+        sb = _mk(S, N, tr_max_tracks=2, chain_side_stream=on)
+        assert sb.side_workers() == (2 if on == 1 else 0)
+        out = []
+        for f in range(F):
+            if on == 1 and f == 4:
+                sb.set_chain_side_stream(False)
+                assert sb.side_workers() == 0
+            if on == 1 and f == 6:
+                sb.set_chain_side_stream(True)
+                assert sb.side_workers() == 2
+            assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+            if on == 1 and f == 0:
+                assert sb.side_workers() in (0, 1)   # checked by the first step
+            out.append((assoc.copy(), labels.copy(), dbn.copy()))
+        sb.check()
+        results.append((out, sb.tracks(cap=8).copy(), sb.num_tracks().copy()))
+        sb.close()
+    for (a0, l0, d0), (a1, l1, d1) in zip(results[0][0], results[1][0]):
+        assert np.array_equal(a0, a1) and np.array_equal(d0, d1)
+        for s in range(S):
+            assert np.array_equal(l0[s, : max(d0[s], 0)], l1[s, : max(d1[s], 0)]), s
+    assert np.array_equal(results[0][2], results[1][2])
+    for s in range(S):
+        k = int(results[0][2][s])
+        for name in ("x", "P", "centroid", "min_vals", "max_vals", "spread_est", "group_disp_est", "n_est", "lifetime",
+                     "point_num", "is_static", "ring_len", "ring_n", "uid"):
+            assert np.array_equal(results[0][1][s, :k][name], results[1][1][s, :k][name]), (s, name)
+    # ... and both equal the oracle (large clouds occur: frame 0 clusters 256 points, frames 1-2 up to 768)
+    ob = co.OracleBatch(co.default_config(tr_max_tracks=2), S, N)
+    saw_big = False
+    for f in range(F):
+        oa, ol, od = ob.step(pts[f].astype(np.float64), cnt[f], dts[f])
+        a, l, d = results[0][0][f]
+        assert np.array_equal(d, od) and np.array_equal(a, oa)
+        for s in range(S):
+            if od[s] > 0:
+                assert np.array_equal(l[s, : od[s]], ol[s, : od[s]]), (f, s)
+                saw_big |= od[s] > 256
+    assert saw_big
