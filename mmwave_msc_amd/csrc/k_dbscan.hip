@@ -72,6 +72,8 @@ struct DbLds {
     int *cl_n, *cl_off;            // [CL+2]
     double *ccen;                  // [CL+1][6]
     double *fst;                   // [kFrontChunk][4] frontier staging of the labelling: mask bits, x, y, z
+    unsigned long long *adj;       // [min(UM, kAdjMax)][W] + [4][8]: the eps-neighbourhoods of clouds of <= kAdjMax points as bit rows
+                                   // (tree positions), then the frontier / reached / labelled / core sets of the labelling
 };
 
 __host__ __device__ inline size_t db_align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -93,6 +95,32 @@ constexpr int kMmCopies = 8;
 // (the 512-thread build of k_dbscan_big takes four: with eight its carve-up would cost a workgroup per CU)
 __host__ __device__ inline int db_mm_copies(int UM) { return UM > 256 ? 4 : kMmCopies; }
 constexpr int kFrontChunk = 32;
+// Clouds of up to kAdjMax points keep their neighbourhoods as bit rows (query_radius writes them, dbscan_inner then works on
+// bits alone): 32 KiB at 512 points, 8 KiB at 256.
+constexpr int kAdjMax = 512;
+// (the carve-up of the largest capacities, 1537 .. 1920 points, has room for 256-point rows only: 160 KiB of LDS)
+__host__ __device__ inline int db_adj_cap(int UM) { return UM > 1536 ? 256 : (UM < kAdjMax ? UM : kAdjMax); }
+// (rows are ((U + 63) / 64) | 1 words apart: an odd stride keeps the lanes of a wave, one row each, on different banks)
+__host__ __device__ inline int db_adj_words(int UM)
+{
+    const int cap = db_adj_cap(UM);
+    return cap * (((cap + 63) / 64) | 1) + 32;
+}
+
+// Transpose a 64 x 64 bit tile held one row per lane (bit c of lane i's word <-> bit i of lane c's word): six rounds of
+// swapping the off-diagonal blocks with the partner lane.
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, int lane)
+{
+    unsigned long long m = 0x00000000FFFFFFFFULL;
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)x, j), hi = __shfl_xor((unsigned)(x >> 32), j);
+        const unsigned long long y = ((unsigned long long)hi << 32) | lo;
+        x = (lane & j) == 0 ? (x & m) | ((y & m) << j) : (x & ~m) | ((y & ~m) >> j);
+        m ^= m << (j >> 1);
+    }
+    return x;
+}
 
 template <bool WRITE>
 __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool all8, char *base, DbLds *L)
@@ -133,6 +161,7 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(cl_off, int, CL + 2)
     CARVE(ccen, double, (CL + 1) * 6)
     CARVE(fst, double, kFrontChunk * 4)
+    CARVE(adj, unsigned long long, db_adj_words(UM))
 #undef CARVE
     return off;
 }
@@ -213,7 +242,6 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
 
     // ---- stage x,y,z in LDS (by point index); identity order.  ALL8 (U <= NT): thread i owns
     //      point i and keeps all 8 of its columns in registers for the whole tree build ----
-    (void)UMc;
     double f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0;
     int mypos = tid;  // ALL8: tree position of point `tid`
     if (ALL8) {
@@ -662,10 +690,17 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     // TEST leaf; counts meet in an LDS counter.  Otherwise one thread per query.
     const int qparts = ALL8 ? (NT / U > 0 ? NT / U : 1) : 1;
     int *qcount = L.front;
-    if (ALL8 && qparts > 1) {
+    // Clouds of <= kAdjMax points also record WHICH points are within eps: row p of L.adj, one bit per tree position, set
+    // exactly where the labelling below would find "q in query_radius(p)" (a node taken whole: its range; a tested leaf:
+    // the points that passed).  dbscan_inner then never touches a coordinate again.
+    const bool use_adj = U <= db_adj_cap(UMc);  // uniform
+    const int W = (U + 63) >> 6, WS = W | 1;
+    unsigned long long *adj = L.adj;
+    if (use_adj)
+        for (int e = tid; e < U * WS + 32; e += NT) adj[e] = 0ULL;
+    if (ALL8 && qparts > 1)
         for (int p = tid; p < U; p += NT) qcount[p] = 0;
-        __syncthreads();
-    }
+    if (use_adj || (ALL8 && qparts > 1)) __syncthreads();
     for (int t = tid; t < (ALL8 ? U * qparts : U); t += NT) {
         const int qpart = ALL8 ? t / U : 0;
         const int p = ALL8 ? t - qpart * U : t;
@@ -690,9 +725,30 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 const unsigned long long sel = span == 32 ? ~0ULL : ((1ULL << (2 * span)) - 1ULL);
                 m |= (pat & sel) << (2 * fl);
                 const int s = L.nstart[node], e = L.nend[node];
-                if (state == 1) count += (qpart == 0) ? e - s : 0;
-                else
-                {
+                if (state == 1) {
+                    if (qpart == 0) {
+                        count += e - s;
+                        if (use_adj)
+                            for (int w = s >> 6; w <= (e - 1) >> 6; w++) {
+                                const int lo = (s > w * 64 ? s : w * 64) - w * 64, hi = (e < w * 64 + 64 ? e : w * 64 + 64) - w * 64;
+                                const unsigned long long bits = (hi == 64 ? ~0ULL : ((1ULL << hi) - 1ULL)) & ~((1ULL << lo) - 1ULL);
+                                atomicOr(&adj[p * WS + w], bits);
+                            }
+                    }
+                } else if (use_adj) {
+                    // (a leaf holds at most 2 * leaf_size = 60 points: one word of bits relative to its start, two row words)
+                    unsigned long long bits = 0ULL;
+#pragma unroll 4
+                    for (int q = s + qpart; q < e; q += qparts) {
+                        const unsigned long long in = alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1ULL : 0ULL;
+                        bits |= in << (q - s);
+                    }
+                    count += __popcll(bits);
+                    const int w0 = s >> 6, lo = s & 63;
+                    const unsigned long long b0 = bits << lo, b1 = lo ? bits >> (64 - lo) : 0ULL;
+                    if (b0) atomicOr(&adj[p * WS + w0], b0);
+                    if (b1) atomicOr(&adj[p * WS + w0 + 1], b1);
+                } else {
 #pragma unroll 4
                     for (int q = s + qpart; q < e; q += qparts)
                         count += alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1 : 0;
@@ -718,6 +774,73 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     //      point index; frontier expansion instead of the DFS stack (same labels) ----
     int n_clusters = 0;
     int *front = L.front, *next = L.next;
+    if (use_adj) {
+        // Bit-set form.  The rows are transposed first (row q then says WHO has q in its neighbourhood: the distance itself
+        // is symmetric, bit for bit, but the rows are not -- the tree takes whole nodes by a bound that is no true triangle
+        // inequality for this weighted distance -- so a cluster is what its seed reaches along rows of cores, in seed
+        // order, exactly dbscan_inner's; a union-find would not do).  One round of the expansion is then,
+        // per unlabelled point, a few ANDs of its row with the frontier set F and a ballot: no atomics, one barrier.
+        unsigned long long *F0 = adj + U * WS, *F1 = F0 + 8;
+        {
+            const int wave = tid >> 6, nw = NT >> 6;
+            int pair = 0;
+            for (int a = 0; a < W; a++)
+                for (int b = a; b < W; b++, pair++) {
+                    if (pair % nw != wave) continue;  // (uniform per wave)
+                    const int ra = a * 64 + lane, rb = b * 64 + lane;
+                    unsigned long long x = ra < U ? adj[ra * WS + b] : 0ULL;             // tile (a, b)
+                    unsigned long long y = (a != b && rb < U) ? adj[rb * WS + a] : 0ULL;  // tile (b, a)
+                    x = transpose64(x, lane);
+                    if (a != b) y = transpose64(y, lane);
+                    if (a == b) { if (ra < U) adj[ra * WS + a] = x; }
+                    else {
+                        if (rb < U) adj[rb * WS + a] = x;
+                        if (ra < U) adj[ra * WS + b] = y;
+                    }
+                }
+        }
+        __syncthreads();
+        for (;;) {
+            if (tid == 0) L.misc[0] = 0x7fffffff;
+            __syncthreads();
+            {
+                int best = 0x7fffffff;
+                for (int p = tid; p < U; p += NT)
+                    if (L.core[p] && L.lab[p] < 0) { const int k = idx[p] * 4096 + p; best = k < best ? k : best; }
+                for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(best, o); best = t < best ? t : best; }
+                if (lane == 0 && best != 0x7fffffff) atomicMin(&L.misc[0], best);
+            }
+            __syncthreads();
+            const int seedkey = L.misc[0];
+            if (seedkey == 0x7fffffff) break;
+            __syncthreads();
+            const int sp = seedkey & 4095;
+            if (tid < 8) F0[tid] = (sp >> 6) == tid ? 1ULL << (sp & 63) : 0ULL;
+            if (tid == 0) L.lab[sp] = n_clusters;
+            __syncthreads();
+            unsigned long long *Fc = F0, *Fn = F1;
+            for (;;) {
+                for (int p0 = 0; p0 < U; p0 += NT) {
+                    const int p = p0 + tid;
+                    bool hit = false;
+                    if (p < U && L.lab[p] < 0) {
+                        unsigned long long acc = 0ULL;
+                        for (int w = 0; w < W; w++) acc |= adj[p * WS + w] & Fc[w];
+                        hit = acc != 0ULL;
+                    }
+                    if (hit) L.lab[p] = n_clusters;
+                    const unsigned long long hb = __ballot(hit && L.core[p]);
+                    if (lane == 0 && p < U) Fn[p >> 6] = hb;  // (whole words: a wave's points share one)
+                }
+                __syncthreads();
+                unsigned long long any = 0ULL;
+                for (int w = 0; w < W; w++) any |= Fn[w];  // (uniform: the same LDS words for every thread)
+                if (!any) break;
+                { unsigned long long *t = Fc; Fc = Fn; Fn = t; }
+            }
+            n_clusters++;
+        }
+    } else
     for (;;) {
         if (tid == 0) L.misc[0] = 0x7fffffff;
         __syncthreads();
