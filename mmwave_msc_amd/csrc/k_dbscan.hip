@@ -686,9 +686,16 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     DSTAMP(2);
     // ---- BallTree.query_radius(X, eps) for every point (_binary_tree.pxi.tp:1903-1980) ----
     const int lbits = n_levels - 1;
-    // ALL8: spare threads share a query -- slice `qpart` of `qparts` takes every qparts-th candidate of a
-    // TEST leaf; counts meet in an LDS counter.  Otherwise one thread per query.
-    const int qparts = ALL8 ? (NT / U > 0 ? NT / U : 1) : 1;
+    // A WAVE walks the tree as one: its 64 queries are neighbours in the tree (one or two leaves), so the nodes any of them
+    // needs are nearly the nodes each of them needs -- and with node and level uniform every branch below is taken by
+    // the whole wave, the candidates of a leaf are read once (one LDS broadcast per coordinate) and the distance block runs
+    // on full lanes.  (One thread walking alone per query left the SIMDs ~25 % busy: every lane at its own node.)  Per lane:
+    // `alive` bit l = "the walk reached this level's node through DESCEND states of mine".  The per-lane visit order is the
+    // order of the private walk, so masks, counts and rows are the same.
+    // Spare waves (thread-per-point build, U <= NT / 2) share the queries: slice `qpart` of `qparts` takes every qparts-th
+    // candidate of a TEST leaf; counts meet in an LDS counter.
+    const int Wq = (U + 63) >> 6;  // waves that hold one query each per lane
+    const int qparts = ALL8 ? ((NT >> 6) / Wq > 0 ? (NT >> 6) / Wq : 1) : 1;
     int *qcount = L.front;
     // Clouds of <= kAdjMax points also record WHICH points are within eps: row p of L.adj, one bit per tree position, set
     // exactly where the labelling below would find "q in query_radius(p)" (a node taken whole: its range; a tested leaf:
@@ -701,41 +708,48 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     if (ALL8 && qparts > 1)
         for (int p = tid; p < U; p += NT) qcount[p] = 0;
     if (use_adj || (ALL8 && qparts > 1)) __syncthreads();
-    for (int t = tid; t < (ALL8 ? U * qparts : U); t += NT) {
-        const int qpart = ALL8 ? t / U : 0;
-        const int p = ALL8 ? t - qpart * U : t;
-        const double px = L.X[p], py = L.Y[p], pz = L.Z[p];
-        unsigned long long m = 0;
-        int count = 0, node = 0, level = 0;
-        for (;;) {
-            const double d = alt_dist(px, py, pz, L.ncen[node * 3], L.ncen[node * 3 + 1], L.ncen[node * 3 + 2], rw, zw);
-            const double rad = __longlong_as_double((long long)L.nrad[node]);
-            const double t = d - rad;
-            const double lb = t > 0 ? t : 0, ub = d + rad;
-            int state;  // 0 prune, 1 all, 2 leaf test, 3 descend
-            if (lb > eps) state = 0;
-            else if (ub <= eps) state = 1;
-            else if (level == lbits) state = 2;
-            else state = 3;
-            if (state == 3) { node = 2 * node + 1; level++; continue; }
-            if (state != 0) {
-                const int span = 1 << (lbits - level);
-                const int fl = (node + 1 - (1 << level)) * span;
-                const unsigned long long pat = state == 1 ? 0x5555555555555555ULL : 0xAAAAAAAAAAAAAAAAULL;
-                const unsigned long long sel = span == 32 ? ~0ULL : ((1ULL << (2 * span)) - 1ULL);
-                m |= (pat & sel) << (2 * fl);
+    {
+        const int wv = tid >> 6;
+        const int qpart = ALL8 ? wv / Wq : 0;                     // (uniform per wave)
+        const int pbase = ALL8 ? (wv - qpart * Wq) * 64 : wv * 64;
+        const int pstep = ALL8 ? U : NT;                           // (thread-per-point build: one batch)
+        for (int pb = pbase; pb < U && qpart < qparts; pb += pstep) {
+            const int p = pb + lane;
+            const bool act = p < U;
+            const double px = L.X[act ? p : 0], py = L.Y[act ? p : 0], pz = L.Z[act ? p : 0];
+            unsigned long long m = 0;
+            int count = 0, node = 0, level = 0;  // node, level: uniform
+            unsigned alive = 1u;
+            for (;;) {
+                int state = 0;  // 0 prune (or not mine), 1 all, 2 leaf test, 3 descend
+                if (act && ((alive >> level) & 1u)) {
+                    const double d = alt_dist(px, py, pz, L.ncen[node * 3], L.ncen[node * 3 + 1], L.ncen[node * 3 + 2], rw, zw);
+                    const double rad = __longlong_as_double((long long)L.nrad[node]);
+                    const double t = d - rad;
+                    const double lb = t > 0 ? t : 0, ub = d + rad;
+                    if (lb > eps) state = 0;
+                    else if (ub <= eps) state = 1;
+                    else if (level == lbits) state = 2;
+                    else state = 3;
+                }
                 const int s = L.nstart[node], e = L.nend[node];
-                if (state == 1) {
-                    if (qpart == 0) {
-                        count += e - s;
-                        if (use_adj)
-                            for (int w = s >> 6; w <= (e - 1) >> 6; w++) {
-                                const int lo = (s > w * 64 ? s : w * 64) - w * 64, hi = (e < w * 64 + 64 ? e : w * 64 + 64) - w * 64;
-                                const unsigned long long bits = (hi == 64 ? ~0ULL : ((1ULL << hi) - 1ULL)) & ~((1ULL << lo) - 1ULL);
-                                atomicOr(&adj[p * WS + w], bits);
-                            }
-                    }
-                } else if (use_adj) {
+                if (state == 1 || state == 2) {
+                    const int span = 1 << (lbits - level);
+                    const int fl = (node + 1 - (1 << level)) * span;
+                    const unsigned long long pat = state == 1 ? 0x5555555555555555ULL : 0xAAAAAAAAAAAAAAAAULL;
+                    const unsigned long long sel = span == 32 ? ~0ULL : ((1ULL << (2 * span)) - 1ULL);
+                    m |= (pat & sel) << (2 * fl);
+                }
+                if (state == 1 && qpart == 0) {
+                    count += e - s;
+                    if (use_adj)
+                        for (int w = s >> 6; w <= (e - 1) >> 6; w++) {
+                            const int lo = (s > w * 64 ? s : w * 64) - w * 64, hi = (e < w * 64 + 64 ? e : w * 64 + 64) - w * 64;
+                            const unsigned long long bits = (hi == 64 ? ~0ULL : ((1ULL << hi) - 1ULL)) & ~((1ULL << lo) - 1ULL);
+                            atomicOr(&adj[p * WS + w], bits);
+                        }
+                }
+                if (level == lbits && __any(state == 2)) {
                     // (a leaf holds at most 2 * leaf_size = 60 points: one word of bits relative to its start, two row words)
                     unsigned long long bits = 0ULL;
 #pragma unroll 4
@@ -743,25 +757,33 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                         const unsigned long long in = alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1ULL : 0ULL;
                         bits |= in << (q - s);
                     }
-                    count += __popcll(bits);
-                    const int w0 = s >> 6, lo = s & 63;
-                    const unsigned long long b0 = bits << lo, b1 = lo ? bits >> (64 - lo) : 0ULL;
-                    if (b0) atomicOr(&adj[p * WS + w0], b0);
-                    if (b1) atomicOr(&adj[p * WS + w0 + 1], b1);
-                } else {
-#pragma unroll 4
-                    for (int q = s + qpart; q < e; q += qparts)
-                        count += alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1 : 0;
+                    if (state == 2) {
+                        count += __popcll(bits);
+                        if (use_adj) {
+                            const int w0 = s >> 6, lo = s & 63;
+                            const unsigned long long b0 = bits << lo, b1 = lo ? bits >> (64 - lo) : 0ULL;
+                            if (b0) atomicOr(&adj[p * WS + w0], b0);
+                            if (b1) atomicOr(&adj[p * WS + w0 + 1], b1);
+                        }
+                    }
                 }
+                if (__any(state == 3)) {
+                    alive = (alive & ~(2u << level)) | (state == 3 ? 2u << level : 0u);
+                    node = 2 * node + 1;
+                    level++;
+                    continue;
+                }
+                while (node != 0 && (node & 1) == 0) { node = (node - 1) >> 1; level--; }  // climb while right child
+                if (node == 0) break;
+                node++;  // left child -> its sibling
             }
-            while (node != 0 && (node & 1) == 0) { node = (node - 1) >> 1; level--; }  // climb while right child
-            if (node == 0) break;
-            node++;  // left child -> its sibling
+            if (act) {
+                // the key[] buffer is dead after the build: it now holds the masks
+                if (qpart == 0) L.mask[p] = m;
+                if (qparts > 1) atomicAdd(&qcount[p], count);
+                else L.core[p] = count >= min_samples ? 1 : 0;
+            }
         }
-        // the key[] buffer is dead after the build: it now holds the masks
-        if (qpart == 0) L.mask[p] = m;
-        if (qparts > 1) atomicAdd(&qcount[p], count);
-        else L.core[p] = count >= min_samples ? 1 : 0;
     }
     __syncthreads();
     if (qparts > 1) {
