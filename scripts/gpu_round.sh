@@ -14,6 +14,8 @@ for st in $STAGES; do
       timeout 1500 python bench.py 2>&1 | tail -2 | tee gpurun_out/bench_default.json ;;
     bench256)
       timeout 900 python bench.py --scenes 256 --pts 256 --tracks 4 --c-scenes 256 --no-e2e --no-e2e-parity 2>&1 | tail -2 | tee gpurun_out/bench_256.json ;;
+    bench160)
+      timeout 900 python bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --steps 150 --warmup 10 2>&1 | tail -1 | tee gpurun_out/bench_160frames.json ;;
     prof)
       rm -rf gpurun_out/prof
       (cd /tmp && timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --gen-workers 1 --steps 40 --warmup 10 > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1)
