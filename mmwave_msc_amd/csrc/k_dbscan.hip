@@ -1256,7 +1256,11 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
 // correctness never depends on k_chain having run.  `epoch` = this step's number: k_post raises q[kQStop] to it when it
 // starts, i.e. when no more pushes can come.  Every wait is bounded.
 constexpr int kChainBlocks = 8;
-constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: ~80 ms
+constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: ~80 ms (waits that MUST succeed: an entry behind its count, the end of a claimed item)
+// ... and how long a side-stream worker polls EMPTY queues before it leaves (~3 ms; k_post / k_dbscan_big take whatever comes
+// later).  Short on purpose: should the context's stream ever sit behind a polling worker in one hardware queue -- two
+// contexts whose streams share queues crosswise can do that, the probe only sees its own pair -- the damage is these 3 ms.
+constexpr int kIdleLimit = 1 << 12;
 // Polls are RELAXED device-scope atomic loads (served by the L2, no side effects): an ACQUIRE load invalidates the caches of
 // the polling CU -- and the non-coherent lines of its XCD's L2 -- every time, and 64 pollers doing that made k_track, which
 // runs beside them, 50 % slower.  One acquire fence follows a successful claim instead.
@@ -1524,7 +1528,7 @@ __global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, 
         if (threadIdx.x == 0) {
             if (have) { __threadfence(); atomicAdd(&(have == 2 ? qb : qs)[kQDone], 1); }
             int s = -1, h = -1, kind = 0;
-            for (int spins = 0; spins < kSpinLimit; spins++) {
+            for (int spins = 0; spins < kIdleLimit + cfg.n_scenes; spins++) {  // (k_track's first push comes later in a larger context)
                 const int hb = q_load(&qb[kQHead]), cb = q_load(&qb[kQCount]);
                 if (hb < cb) {
                     if (atomicCAS(&qb[kQHead], hb, hb + 1) == hb) { h = hb; kind = 2; break; }
