@@ -1321,6 +1321,91 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
     }
 }
 
+// The clouds of more than 256 points (a scene without tracks clusters its whole ring: the start-up frames, and every scene
+// whose tracks have all expired): 100-250 us of BallTree chain each on a 512-thread workgroup.  They sit in a queue k_track
+// fills while it runs (q[kQBig + ...], ring = list 1).  Consumers:
+//   k_chain_big       a few workgroups on a side stream, BESIDE k_track and k_post (claims by compare-and-swap, leaves
+//                     when k_post has begun and the queue is empty);
+//   k_dbscan_big      behind k_post on the context's stream: takes what is left (tickets by atomicAdd: the pushes are
+//                     complete) and does not end before every claimed cloud is finished;
+//   k_dbscan_startup  the same for the first frames after a reset, when every cloud fits one point per thread, under a
+//                     register budget that lets two workgroups share a CU;
+//   k_post            in contexts of <= kBigInPostScenes scenes, whose step is launch latency: its worker blocks take the
+//                     large clouds too (256 threads, strided build -- rare there) and k_dbscan_big is not launched.
+// Correctness never depends on k_chain_big having run.
+constexpr int kBigThreads = 512;
+constexpr int kBigInPostScenes = 512;
+template <int NT, bool AFTER_TRACK, bool TPP_ONLY>
+__device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
+                                                int epoch, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    DbLds L;
+    // the ticket word sits behind the BallTree carve-up (big_lds_bytes reserves it)
+    const size_t a = db_lds_layout<false>(UMc, CL, true, nullptr, nullptr), b = TPP_ONLY ? 0 : db_lds_layout<false>(UMc, CL, false, nullptr, nullptr);
+    int *ticket = reinterpret_cast<int *>(lds_raw + db_align16(a > b ? a : b));
+    int32_t *q = st.q + kQBig + parity * 8;
+    int32_t *ring = st.db_list + cfg.n_scenes;  // list 1
+    bool have = false;
+    for (;;) {
+        __syncthreads();  // every thread is done with the previous cloud: its stores are issued, LDS is free again
+        if (threadIdx.x == 0) {
+            if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
+            int s = -1, h = -1;
+            if (AFTER_TRACK) {
+                if (q_load(&q[kQHead]) < q_load(&q[kQCount])) {  // (an empty queue costs two loads, no atomic)
+                    h = atomicAdd(&q[kQHead], 1);
+                    if (h >= q_load(&q[kQCount])) h = -1;
+                }
+            } else {
+                for (int spins = 0; spins < kSpinLimit; spins++) {
+                    const int hh = q_load(&q[kQHead]), c = q_load(&q[kQCount]);
+                    if (hh < c) {
+                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh; break; }
+                        continue;
+                    }
+                    if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and the queue is empty: done
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
+            if (h >= 0) {
+                int32_t *e = ring + h;
+                int v = 0;
+                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&q[kQDone], 1); }
+                else {
+                    __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q_acquire();  // what the pushing workgroup stored for the scene is visible from here on
+                    s = v - 1;
+                }
+            }
+            *ticket = s;
+        }
+        __syncthreads();
+        const int s = *ticket;
+        if (s < 0) return;
+        have = true;
+        if (cfg.seek_inner && !st.hdr[s].need_db) continue;  // cancelled by k_inner (uniform)
+        // a cloud that fits one point per thread takes the thread-per-point build of the small class (registers
+        // hold the 8 columns, one bitonic sort per level): 3-4x less tree-build time than the strided build
+        const bool tpp = TPP_ONLY || st.hdr[s].db_u <= NT;  // uniform
+        db_lds_layout<true>(UMc, CL, tpp, lds_raw, &L);
+        if (tpp) spawn_scene<NT, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+        else if constexpr (!TPP_ONLY) spawn_scene<NT, false>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+    }
+}
+
+// the launch must not end before every claimed cloud is finished (a side-stream worker may still hold one): the next
+// launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
+__device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
+{
+    const int32_t *qp = st.q + kQBig + parity * 8;
+    const int want = q_load(&qp[kQCount]);
+    long long spins = 0;
+    while (q_load(&qp[kQDone]) < want && spins < (1LL << 23)) { __builtin_amdgcn_s_sleep(8); spins++; }
+    if (q_load(&qp[kQDone]) < want) atomicAdd(&st.q[kQTimeout], 1);
+    q_acquire();
+}
+
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
 //   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
 //                    <= 256 points k_track's cell count could not rule out): the exact pair count, then for
@@ -1332,7 +1417,7 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
 // clusters, the spawn appends records behind them.
 template <int DX>
 __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
-                                              int UM_out, int parity, int epoch, int32_t *__restrict__ labels_out,
+                                              int UMb, int CLb, int UM_out, int parity, int epoch, int32_t *__restrict__ labels_out,
                                               int32_t *__restrict__ db_n_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -1399,6 +1484,10 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
             }
         }
         chain_worker_loop(cfg, st, lds_raw, UMc, CL, UM_out, parity, labels_out, db_n_out);
+        if (UMb > 0 && st.q[kQBig + parity * 8 + kQCount] != 0) {  // small context: the large clouds here as well (k_track is complete: plain load)
+            big_worker_loop<256, true, false>(cfg, st, lds_raw, UMb, CLb, UM_out, parity, 0, labels_out, db_n_out);
+            if (blockIdx.x == 0 && threadIdx.x == 0) big_wait_done(st, parity);
+        }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             // the launch must not end before every claimed scene is finished (k_chain may still hold one): the next
             // launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
@@ -1422,88 +1511,6 @@ __global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int
     const int us = unit / nq, q = unit - us * nq;
     const int s = st.perm[(size_t)parity * cfg.n_scenes + us];  // this step's schedule (the worker above writes the next one)
     update_tracks_wave<DX>(cfg, st, n_pts, s, q, nq, scratch);
-}
-
-// The clouds of more than 256 points (a scene without tracks clusters its whole ring: the start-up frames, and every scene
-// whose tracks have all expired): 100-250 us of BallTree chain each on a 512-thread workgroup.  They sit in a queue k_track
-// fills while it runs (q[kQBig + ...], ring = list 1).  Consumers:
-//   k_chain_big       a few workgroups on a side stream, BESIDE k_track and k_post (claims by compare-and-swap, leaves
-//                     when k_post has begun and the queue is empty);
-//   k_dbscan_big      behind k_post on the context's stream: takes what is left (tickets by atomicAdd: the pushes are
-//                     complete) and does not end before every claimed cloud is finished;
-//   k_dbscan_startup  the same for the first frames after a reset, when every cloud fits one point per thread, under a
-//                     register budget that lets two workgroups share a CU.
-// Correctness never depends on k_chain_big having run.
-constexpr int kBigThreads = 512;
-template <bool AFTER_TRACK, bool TPP_ONLY>
-__device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
-                                                int epoch, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
-{
-    DbLds L;
-    // the ticket word sits behind the BallTree carve-up (big_lds_bytes reserves it)
-    const size_t a = db_lds_layout<false>(UMc, CL, true, nullptr, nullptr), b = TPP_ONLY ? 0 : db_lds_layout<false>(UMc, CL, false, nullptr, nullptr);
-    int *ticket = reinterpret_cast<int *>(lds_raw + db_align16(a > b ? a : b));
-    int32_t *q = st.q + kQBig + parity * 8;
-    int32_t *ring = st.db_list + cfg.n_scenes;  // list 1
-    bool have = false;
-    for (;;) {
-        __syncthreads();  // every thread is done with the previous cloud: its stores are issued, LDS is free again
-        if (threadIdx.x == 0) {
-            if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
-            int s = -1, h = -1;
-            if (AFTER_TRACK) {
-                if (q_load(&q[kQHead]) < q_load(&q[kQCount])) {  // (an empty queue costs two loads, no atomic)
-                    h = atomicAdd(&q[kQHead], 1);
-                    if (h >= q_load(&q[kQCount])) h = -1;
-                }
-            } else {
-                for (int spins = 0; spins < kSpinLimit; spins++) {
-                    const int hh = q_load(&q[kQHead]), c = q_load(&q[kQCount]);
-                    if (hh < c) {
-                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh; break; }
-                        continue;
-                    }
-                    if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and the queue is empty: done
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-            if (h >= 0) {
-                int32_t *e = ring + h;
-                int v = 0;
-                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
-                if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&q[kQDone], 1); }
-                else {
-                    __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    q_acquire();  // what the pushing workgroup stored for the scene is visible from here on
-                    s = v - 1;
-                }
-            }
-            *ticket = s;
-        }
-        __syncthreads();
-        const int s = *ticket;
-        if (s < 0) return;
-        have = true;
-        if (cfg.seek_inner && !st.hdr[s].need_db) continue;  // cancelled by k_inner (uniform)
-        // a cloud that fits one point per thread takes the thread-per-point build of the small class (registers
-        // hold the 8 columns, one bitonic sort per level): 3-4x less tree-build time than the strided build
-        const bool tpp = TPP_ONLY || st.hdr[s].db_u <= kBigThreads;  // uniform
-        db_lds_layout<true>(UMc, CL, tpp, lds_raw, &L);
-        if (tpp) spawn_scene<kBigThreads, true>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
-        else if constexpr (!TPP_ONLY) spawn_scene<kBigThreads, false>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
-    }
-}
-
-// the launch must not end before every claimed cloud is finished (a side-stream worker may still hold one): the next
-// launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
-__device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
-{
-    const int32_t *qp = st.q + kQBig + parity * 8;
-    const int want = q_load(&qp[kQCount]);
-    long long spins = 0;
-    while (q_load(&qp[kQDone]) < want && spins < (1LL << 23)) { __builtin_amdgcn_s_sleep(8); spins++; }
-    if (q_load(&qp[kQDone]) < want) atomicAdd(&st.q[kQTimeout], 1);
-    q_acquire();
 }
 
 // The chain workers of the side stream: 512-thread workgroups that serve BOTH queues while k_track and k_post run -- the
@@ -1585,7 +1592,7 @@ __global__ __launch_bounds__(kBigThreads) void k_dbscan_big(DevCfg cfg, DevState
     // (k_track is complete: the count is final and a plain load.  No large cloud this step -- nearly every step of a
     // tracked scene set -- and the whole launch leaves on that one word)
     if (st.q[kQBig + parity * 8 + kQCount] == 0) return;
-    big_worker_loop<true, false>(cfg, st, lds_raw, UMc, CL, UM_out, parity, 0, labels_out, db_n_out);
+    big_worker_loop<kBigThreads, true, false>(cfg, st, lds_raw, UMc, CL, UM_out, parity, 0, labels_out, db_n_out);
     if (blockIdx.x == 0 && threadIdx.x == 0) big_wait_done(st, parity);
 }
 
@@ -1594,7 +1601,7 @@ __global__ __launch_bounds__(kBigThreads, 4) void k_dbscan_startup(DevCfg cfg, D
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     if (st.q[kQBig + parity * 8 + kQCount] == 0) return;
-    big_worker_loop<true, true>(cfg, st, lds_raw, UMc, CL, UM_out, parity, 0, labels_out, db_n_out);
+    big_worker_loop<kBigThreads, true, true>(cfg, st, lds_raw, UMc, CL, UM_out, parity, 0, labels_out, db_n_out);
     if (blockIdx.x == 0 && threadIdx.x == 0) big_wait_done(st, parity);
 }
 
@@ -1676,12 +1683,13 @@ static size_t chain_lds_bytes(int um, int t_cap, int min_samples)
 
 hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)k_post<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_post<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post_lds_bytes(UM, t_cap, min_samples));
-    if (e != hipSuccess) return e;
     const int bum = big_um(UM, UM);
     const size_t big = big_lds_bytes(bum, big_cl(bum, t_cap, min_samples), false);
+    const size_t post = post_lds_bytes(UM, t_cap, min_samples) > big ? post_lds_bytes(UM, t_cap, min_samples) : big;  // (small contexts: the large clouds in k_post)
+    hipError_t e = hipFuncSetAttribute((const void *)k_post<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_post<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_lds_bytes(chain_um(UM, UM), t_cap, min_samples));
@@ -1714,17 +1722,29 @@ void launch_inner(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, i
 }
 
 // _update_all + the BallTree DBSCAN of the small clouds (work list 3)
-void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n,
-                 hipStream_t stream)
+void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int u_bound, int parity, int epoch, int32_t *labels,
+                 int32_t *db_n, hipStream_t stream)
 {
     int nq = (cfg.tr_max_tracks + 3) / 4;
     if (nq < 1) nq = 1;
-    const int S = cfg.n_scenes, G0 = S < 256 ? S : 256, units = S * nq;
+    const int S = cfg.n_scenes, units = S * nq;
+    int G0 = S < 256 ? S : 256;
     const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
-    const size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
+    size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
+    // a small context's step is launch latency: its large clouds are taken here too and k_dbscan_big is not launched
+    int umb = 0, clb = 0;
+    if (S <= kBigInPostScenes && big_um(UM, u_bound) > kClassUM[0]) {
+        umb = big_um(UM, u_bound);
+        clb = big_cl(umb, cfg.t_cap, cfg.db_min_samples);
+        const size_t big = big_lds_bytes(umb, clb, false);
+        if (big > lds) lds = big;
+        // (with that much LDS a CU holds one workgroup: workers + update units must stay one wave of workgroups)
+        static const int g0_small = getenv("MMW_POST_WORKERS") ? atoi(getenv("MMW_POST_WORKERS")) : 64;
+        if (G0 > g0_small) G0 = g0_small;
+    }
     const dim3 grid(G0 + (units + 3) / 4);
-    if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, epoch, labels, db_n);
-    else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, UM, parity, epoch, labels, db_n);
+    if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
+    else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
 }
 
 // The chain workers beside k_track and k_post (a second stream; see k_chain)
@@ -1743,6 +1763,7 @@ void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int u_boun
 {
     const int um = big_um(UM, u_bound);
     if (kClassUM[0] >= um) return;  // no cloud can exceed the small class
+    if (cfg.n_scenes <= kBigInPostScenes) return;  // k_post has taken them (launch_post)
     const int S = cfg.n_scenes, cl = big_cl(um, cfg.t_cap, cfg.db_min_samples);
     if (um <= kBigThreads && um < UM) {
         const size_t lds = big_lds_bytes(um, cl, true);

@@ -18,8 +18,8 @@ thread_local LaunchProf g_launch_prof;
 size_t track_lds_bytes(const DevCfg &c);
 hipError_t prepare_track(const DevCfg &cfg);
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream);
-void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int parity, int epoch, int32_t *labels, int32_t *db_n,
-                 hipStream_t stream);
+void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int u_bound, int parity, int epoch, int32_t *labels,
+                 int32_t *db_n, hipStream_t stream);
 void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
@@ -581,7 +581,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     prof_armed_done(c, ep);
     if (c->dc.seek_inner) launch_inner(c->dc, c->st, n_pts, db_n, c->stream);  // Tracking.py:656 active
     prof_arm(c, MMW_K_POST, ep);
-    launch_post(c->dc, c->st, n_pts, c->UM, c->step_parity, c->epoch, db_labels, db_n, c->stream);
+    launch_post(c->dc, c->st, n_pts, c->UM, u_bound, c->step_parity, c->epoch, db_labels, db_n, c->stream);
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_DBSCAN, ep);
     launch_dbscan_big(c->dc, c->st, c->UM, u_bound, c->step_parity, db_labels, db_n, c->stream);
