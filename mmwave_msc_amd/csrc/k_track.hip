@@ -14,6 +14,7 @@
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 #include "mmw_cloud.hpp"
+#include "mmw_kalman.hpp"
 #include "mmw_launch.hpp"
 
 namespace mmw {
@@ -114,6 +115,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
 size_t track_lds_bytes(const DevCfg &c)
 {
     size_t b = track_lds_layout<false>(c, nullptr, nullptr);
+    if (pred_in_track(c) && b < (size_t)16 * kPredScratch * sizeof(double)) b = (size_t)16 * kPredScratch * sizeof(double);  // the predict stage's scratch
 #ifdef MMW_STAMPS
     // diagnostic build only: MMW_DIAG_LDS_EXTRA=<bytes> inflates the allocation to lower the number of
     // resident workgroups per CU (separates latency from contention in the phase stamps)
@@ -188,8 +190,9 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 // reserved for points a configuration can never have.
 // INNER = mmw_config.seek_inner (per-track ring sizes, see k_inner in k_dbscan.hip): a template so that the default
 // instantiation carries none of it.
-template <int PPT, bool INNER>
-__global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+// PRED = _predict_all at the head of this kernel instead of in k_predict (small contexts, mmw_kalman.hpp: pred_in_track).
+template <int PPT, bool INNER, bool PRED = false>
+__global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3)))) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out,
                                                     int32_t *__restrict__ db_labels_out, int UM_out, int parity)
@@ -250,6 +253,28 @@ __global__ __launch_bounds__(kThreads, (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3))) void
 #ifdef MMW_STAMPS
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (PRED) {
+        // _predict_all (Tracking.py:591-596) + the gate matrices, as k_predict does them: a 16-lane group per track, sixteen
+        // tracks per round over the four waves; scratch = the head of this kernel's LDS (nothing else lives there yet).
+        // What the groups store (track records, gate_buf) is read below by every wave of THIS workgroup -- gate_buf through
+        // the SCALAR cache, which has not seen these lines in this launch but may hold a neighbour scene's share of a line:
+        // stores acknowledged by the L2 (vmcnt(0): the vector L1 writes through), workgroup fence + barrier, scalar-cache
+        // invalidate.  (A device-scope fence here writes the L2 back -- the XCDs' L2s are not coherent -- and cost 20 us.)
+        double *Wj = reinterpret_cast<double *>(lds_raw) + (size_t)(wave * 4 + (lane >> 4)) * kPredScratch;
+        int perr = 0;
+        for (int j0 = wave * 4; j0 < T; j0 += 4 * kWaves) {
+            const int j = j0 + (lane >> 4);
+            const bool live = j < T;
+            TrackRec *rec = trk + (live ? order[j] : 0);
+            if (cfg.dx == 9) predict_one_track<9>(cfg, st, rec, live, s, j, dt, Wj, lane, lane & 15, perr);
+            else predict_one_track<6>(cfg, st, rec, live, s, j, dt, Wj, lane, lane & 15, perr);
+        }
+        if (perr) atomicOr(&hdr->err, perr);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();
+    }
 
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
     for (int j = tid + kThreads; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
@@ -801,6 +826,15 @@ template <int PPT>
 static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                            int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
+    if (pred_in_track(cfg)) {  // (never with seek_inner)
+        if (cfg.var_ring)
+            mmw_launch(k_track<PPT, true, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc,
+                       db_n, db_labels, UM, parity);
+        else
+            mmw_launch(k_track<PPT, false, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc,
+                       db_n, db_labels, UM, parity);
+        return;
+    }
     if (cfg.seek_inner || cfg.var_ring)
         mmw_launch(k_track<PPT, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
                    db_labels, UM, parity);
@@ -821,8 +855,10 @@ void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, cons
 hipError_t prepare_track(const DevCfg &cfg)
 {
     const int lds = (int)track_lds_bytes(cfg);
-    const void *fns[6] = {(const void *)k_track<1, false>, (const void *)k_track<2, false>, (const void *)k_track<4, false>,
-                          (const void *)k_track<1, true>, (const void *)k_track<2, true>, (const void *)k_track<4, true>};
+    const void *fns[12] = {(const void *)k_track<1, false>, (const void *)k_track<2, false>, (const void *)k_track<4, false>,
+                           (const void *)k_track<1, true>, (const void *)k_track<2, true>, (const void *)k_track<4, true>,
+                           (const void *)k_track<1, false, true>, (const void *)k_track<2, false, true>, (const void *)k_track<4, false, true>,
+                           (const void *)k_track<1, true, true>, (const void *)k_track<2, true, true>, (const void *)k_track<4, true, true>};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;

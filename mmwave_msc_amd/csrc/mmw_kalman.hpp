@@ -151,11 +151,100 @@ __device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, doubl
     wave_sync();
 }
 
+// _predict_all for ONE track per 16-lane group (predict_state, Tracking.py:372-385: filterpy predict with the motion
+// model of constants.py:195-215) + the gate matrix of _calc_dist_fun (Tracking.py:549-560) into gate_buf[s][j].
+// Idle groups (`live` false) point at any valid record and store nothing.  All 64 lanes of the wave must call.
+template <int DX>
+__device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
+                                                  double *Wj, int lane, int c, int &err)
+{
+    stage_record(rec, Wj, c);
+    wave_sync();
+    const double dtm = Wj[rLife] + dt;
+    const double h = 0.5 * (dtm * dtm);
+    if (live) {
+        for (int k = c; k < 81; k += 16) {
+            // A = F P.  F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense
+            // dot product reduces to these terms (the others are exact zeros).
+            const int i = k / 9, cc = k - i * 9;
+            if (i < DX && cc < DX) {
+                double a = Wj[rP + k];
+                if (i + 3 < DX) a += dtm * Wj[rP + (i + 3) * 9 + cc];
+                if (i + 6 < DX) a += h * Wj[rP + (i + 6) * 9 + cc];
+                Wj[pA + k] = a;
+            }
+        }
+        if (c < DX) {
+            double xn = Wj[rX + c];
+            if (c + 3 < DX) xn += dtm * Wj[rX + c + 3];
+            if (c + 6 < DX) xn += h * Wj[rX + c + 6];
+            Wj[pXn + c] = xn;
+        }
+    }
+    wave_sync();
+    if (live) {
+        const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
+        for (int k = c; k < 81; k += 16) {
+            const int i = k / 9, cc = k - i * 9;
+            if (i < DX && cc < DX) {
+                double b = Wj[pA + k];  // B = A F^T
+                if (cc + 3 < DX) b += Wj[pA + i * 9 + cc + 3] * dtm;
+                if (cc + 6 < DX) b += Wj[pA + i * 9 + cc + 6] * h;
+                double qn = 0.0;
+                if (i / 3 == cc / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
+                    const int qi = i % 3, qc = cc % 3, sdeg = qi + qc;
+                    const double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
+                                      : sdeg == 3 ? dtm : 1.0;
+                    qn = base * cfg.kf_q_std;
+                }
+                const double pn = b + qn;
+                rec->P[k] = pn;
+                Wj[rP + k] = pn;
+            }
+        }
+        if (c < DX) { const double xn = Wj[pXn + c]; rec->x[c] = xn; Wj[rX + c] = xn; }
+    }
+    wave_sync();
+    // gate matrix: lane c < 6 of the group holds column c of C = P[:6,:6] + diag((spread/2)^2) + group_disp_est
+    {
+        const bool valid = live && c < 6;
+        double v[6], det;
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;  // idle groups: identity
+        if (valid) {
+            const double hh = Wj[rSpr + c] / 2;
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] = (Wj[rP + i * 9 + c] + ((i == c) ? hh * hh : 0.0)) + Wj[rGd + i * 6 + c];
+        }
+        const bool ok = lu6_inverse_cols(v, lane, det);
+        if (live) {
+            if (!ok) err |= ERR_SINGULAR;
+            double *G = st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec;  // by effective_tracks position
+            if (c >= 6 && c < 12) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
+            }
+            if (c == 0) G[36] = dlog(fabs(det));
+            if (c < 6) G[37 + c] = Wj[rX + c];
+        }
+    }
+    wave_sync();
+}
+
 // When the track-wise layout is used: it needs one lane per bin (t_cap <= 63), and it only pays when there are more
 // waves than the chip runs at once -- a small context (256 scenes x 4 tracks) is bound by the latency of one wave, and
 // the lists put two more dependent loads in front of it (k_predict 8.3 -> 9.2 us there).  The threshold is 1024 waves;
 // MMW_DENSE_MIN_UNITS in the environment of mmw_create overrides it (the parity tests run both layouts on small contexts).
 __host__ __device__ inline bool tracks_dense(const DevCfg &cfg, int nq) { return cfg.t_cap <= 63 && cfg.n_scenes * nq > cfg.dense_min_units; }
+// Contexts whose step is launch latency (<= kPredInTrackScenes scenes, per-scene layout): _predict_all runs at the head of
+// k_track (k_track.hip, PRED instantiations) and k_predict is not launched -- one kernel boundary less.
+constexpr int kPredInTrackScenes = 512;
+__host__ __device__ inline bool pred_in_track(const DevCfg &cfg)
+{
+    int nq = (cfg.tr_max_tracks + 3) / 4;
+    if (nq < 1) nq = 1;
+    return cfg.n_scenes <= kPredInTrackScenes && !tracks_dense(cfg, nq) && !cfg.seek_inner;
+}
 
 // _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of the list
 // "scenes by track count, most tracks first" that k_track built this frame (st.upd_list / st.upd_count; every scene
