@@ -1415,8 +1415,11 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
 //                    (update_tracks_wave, mmw_kalman.hpp) -- the bulk work the BallTree scenes hide under.
 // The two touch disjoint state: the update covers the hdr->n_upd tracks that existed before this frame's
 // clusters, the spawn appends records behind them.
+// Three waves per SIMD (168 VGPRs): the BallTree path of the worker blocks would take 204 and hold the update waves -- the
+// bulk of the launch -- at two per SIMD; with the cap the workers spill 92 bytes per lane and k_post is 41 -> 37 us
+// (four per SIMD: 300 bytes of spills, 45 us).
 template <int DX>
-__global__ __launch_bounds__(256) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
+__global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
                                               int UMb, int CLb, int UM_out, int parity, int epoch, int32_t *__restrict__ labels_out,
                                               int32_t *__restrict__ db_n_out)
 {
