@@ -1742,8 +1742,8 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
         const size_t big = big_lds_bytes(umb, clb, false);
         if (big > lds) lds = big;
         // (with that much LDS a CU holds one workgroup: workers + update units must stay one wave of workgroups)
-        static const int g0_small = getenv("MMW_POST_WORKERS") ? atoi(getenv("MMW_POST_WORKERS")) : 64;
-        if (G0 > g0_small) G0 = g0_small;
+        constexpr int kSmallContextWorkers = 64;  // (32 .. 128 measured equal)
+        if (G0 > kSmallContextWorkers) G0 = kSmallContextWorkers;
     }
     const dim3 grid(G0 + (units + 3) / 4);
     if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
@@ -1753,7 +1753,12 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
 // The chain workers beside k_track and k_post (a second stream; see k_chain)
 void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side)
 {
-    static const int want = getenv("MMW_CHAIN_BLOCKS") ? atoi(getenv("MMW_CHAIN_BLOCKS")) : kChainBlocks;  // (diagnostic knob: 4 .. 12 trade 1 % between the 40- and the 160-frame window)
+    // (4 .. 12 workgroups trade 1 % between the 40- and the 160-frame window: profiles/README.md)
+#ifdef MMW_STAMPS
+    static const int want = getenv("MMW_CHAIN_BLOCKS") ? atoi(getenv("MMW_CHAIN_BLOCKS")) : kChainBlocks;  // diagnostic build only
+#else
+    const int want = kChainBlocks;
+#endif
     const int um = chain_um(UM, u_bound), cl = big_cl(um, cfg.t_cap, cfg.db_min_samples);
     const int g = want < cfg.n_scenes ? want : cfg.n_scenes;
     hipLaunchKernelGGL(k_chain, dim3(g > 0 ? g : 1), dim3(kBigThreads), chain_lds_bytes(um, cfg.t_cap, cfg.db_min_samples), side, cfg, st, um, cl, UM,
