@@ -459,3 +459,33 @@ def test_side_workers_are_probed_and_switchable():
                 assert np.array_equal(l[s, : od[s]], ol[s, : od[s]]), (f, s)
                 saw_big |= od[s] > 256
     assert saw_big
+
+
+def test_mid_size_context_takes_the_four_launch_step():
+    """Contexts of <= 512 scenes run a two-launch step (_predict_all at the head of k_track, the large clouds in k_post);
+    everything above runs k_predict / k_track / k_post / k_dbscan_big.  640 scenes -- the smallest kind of context that takes
+    the second form, in whichever Kalman layout the fixture selects -- against the oracle, start-up frames (large clouds)
+    included."""
+    from oracle import c_oracle as co
+    import bench
+    S, N, T, F = 640, 128, 3, 7
+    pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=4)
+    sb = _mk(S, N, tr_max_tracks=T)
+    ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        oa, ol, od = ob.step(pts[f].astype(np.float64), cnt[f], dts[f])
+        assert np.array_equal(dbn, od), f
+        assert np.array_equal(assoc, oa), f
+        for s in range(S):
+            if od[s] > 0:
+                assert np.array_equal(labels[s, : od[s]], ol[s, : od[s]]), (f, s)
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    for s in range(S):
+        want = ob.scenes[s].tracks()
+        assert ntr[s] == len(want), s
+        for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "n_est", "lifetime", "point_num", "ring_n"):
+            assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
+    sb.check()
+    sb.close()
