@@ -555,6 +555,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     // frames pushed so far, and the large-cloud launches are carved (LDS per workgroup -> workgroups per CU) for that bound
     if (c->ring_frames_bound < c->dc.ring) c->ring_frames_bound++;
     const int u_bound = c->ring_frames_bound * c->dc.max_pts;
+    c->dc.big_live = (c->dc.side_worker && c->ring_frames_bound >= c->dc.ring) ? 1 : 0;  // (set again below if the probe turns the workers off)
     // the chain workers of this step wait on the side stream for what k_track queues (nothing orders them with the
     // context's stream but the queue itself: they only touch scenes k_track has published)
     // They must not start long before k_track does -- a caller may have queued other work on the context's stream (the CNN
@@ -565,7 +566,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
         const int ok = probe_side_streams(c);
         if (ok < 0) return fail(c, MMW_E_HIP, "side-stream probe failed: %s", hipGetErrorString(hipGetLastError()));
         c->side_probed = 1;
-        if (!ok) c->dc.side_worker = 0;
+        if (!ok) c->dc.side_worker = c->dc.big_live = 0;
     }
     if (c->dc.side_worker) {
         HIPCHK(c, hipEventRecord(c->side_gate, c->stream));
