@@ -1539,7 +1539,7 @@ __global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, 
             if (have) { __threadfence(); atomicAdd(&(have == 2 ? qb : qs)[kQDone], 1); }
             int s = -1, h = -1, kind = 0;
             for (int spins = 0; spins < kIdleLimit + cfg.n_scenes; spins++) {  // (k_track's first push comes later in a larger context)
-                const int hb = q_load(&qb[kQHead]), cb = q_load(&qb[kQCount]);
+                const int hb = q_load(&qb[kQHead]), cb = cfg.big_live ? q_load(&qb[kQCount]) : 0;  // (start-up frames: pushed without a release, not ours)
                 if (hb < cb) {
                     if (atomicCAS(&qb[kQHead], hb, hb + 1) == hb) { h = hb; kind = 2; break; }
                     continue;
