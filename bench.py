@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--no-e2e-parity", action="store_true", help="skip the configs[3] end-to-end parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")
     ap.add_argument("--chain-side-stream", type=int, default=0, choices=(-1, 0, 1),
-                    help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1024 scenes), 1 = on, -1 = off")
+                    help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1536 scenes), 1 = on, -1 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / shard / gather plumbing only, on the CPU with gloo (tests/test_dist_gloo.py): no GPU work, no metric")
     ap.add_argument("--gen-workers", type=int, default=-1,

@@ -275,7 +275,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.var_ring = 0;
     // the BallTree chain workers beside k_track on a second stream: for contexts large enough that k_track is a long launch
     // (a small context's whole step is shorter than a chain), and not with seek_inner (k_inner may cancel queued scenes)
-    d.side_worker = (!d.seek_inner && (cfg->chain_side_stream > 0 || (cfg->chain_side_stream == 0 && n_scenes >= 1024))) ? 1 : 0;
+    d.side_worker = (!d.seek_inner && (cfg->chain_side_stream > 0 || (cfg->chain_side_stream == 0 && n_scenes >= 1536))) ? 1 : 0;
     if (d.seek_inner) {
         // seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
         // ring*max_pts rows: frames are stored whole.  A ring of size 0 would never leave add_frame's loop (Tracking.py:47-48).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak: many frames of a side-worker context (>= 1024 scenes), then mmw_check (a worker that gave up a wait it must not
+"""Soak: many frames of a side-worker context (SOAK_S >= 1536 scenes, or chain_side_stream = 1), then mmw_check (a worker that gave up a wait it must not
 give up is a sticky error) and the final state against the C oracle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ from mmwave_msc_amd import _lib
 from mmwave_msc_amd.batch import SceneBatch
 from oracle import c_oracle as co
 
-S, N, T, F = int(os.environ.get("SOAK_S", "1024")), 512, 8, int(os.environ.get("SOAK_F", "400"))
+S, N, T, F = int(os.environ.get("SOAK_S", "2048")), 512, 8, int(os.environ.get("SOAK_F", "400"))
 pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=16)
 ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
 t0 = time.perf_counter()

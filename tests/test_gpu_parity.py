@@ -23,7 +23,7 @@ def kalman_layout(request):
     """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense: by default the
     track-wise one is only chosen for contexts with more than 1024 four-track waves, mmw_config.kalman_dense_min_units), and
     a third time with the small-cloud DBSCAN workers on the side stream (k_chain beside k_track, mmw_config.chain_side_stream:
-    by default only for contexts of >= 1024 scenes)."""
+    by default only for contexts of >= 1536 scenes)."""
     _LAYOUT["value"] = -1 if request.param == "per_scene" else 1
     _LAYOUT["side"] = 1 if request.param.endswith("side_stream") else -1
     yield
