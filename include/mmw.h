@@ -78,8 +78,9 @@ typedef struct mmw_config {
     double tilt_sin;                /* sin(radians(S_TILT)) */
     float default_posture[MMW_NKP]; /* MODEL_DEFAULT_POSTURE :112-172 */
     int32_t kalman_dense_min_units; /* not a reference constant: layout of the Kalman kernels.  0 = automatic (laid out over tracks
-                                       when the context holds > 1024 four-track waves), < 0 = always per scene, n > 0 = over
-                                       tracks from n waves on (tests run both layouts) */
+                                       when the context holds more than 768 scenes and > 1024 four-track waves; smaller contexts run
+                                       a two-launch step per scene), < 0 = always per scene, n > 0 = over tracks from n waves on
+                                       (tests run both layouts) */
     int32_t seek_inner;             /* 0 = Tracking.py:656 stays commented out (the reference as shipped); 1 = run
                                        ClusterTrack.seek_inner_clusters (Tracking.py:409-448) after every associate_pointcloud */
     int32_t db_points_thres;        /* DB_POINTS_THRES :76   (seek_inner_clusters) */

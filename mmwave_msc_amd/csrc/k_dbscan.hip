@@ -1330,11 +1330,10 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
 //                     complete) and does not end before every claimed cloud is finished;
 //   k_dbscan_startup  the same for the first frames after a reset, when every cloud fits one point per thread, under a
 //                     register budget that lets two workgroups share a CU;
-//   k_post            in contexts of <= kBigInPostScenes scenes, whose step is launch latency: its worker blocks take the
+//   k_post            in contexts of <= kSmallContextScenes scenes, whose step is launch latency: its worker blocks take the
 //                     large clouds too (256 threads, strided build -- rare there) and k_dbscan_big is not launched.
 // Correctness never depends on k_chain_big having run.
 constexpr int kBigThreads = 512;
-constexpr int kBigInPostScenes = 512;
 template <int NT, bool AFTER_TRACK, bool TPP_ONLY>
 __device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
                                                 int epoch, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
@@ -1736,7 +1735,7 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
     size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);
     // a small context's step is launch latency: its large clouds are taken here too and k_dbscan_big is not launched
     int umb = 0, clb = 0;
-    if (S <= kBigInPostScenes && big_um(UM, u_bound) > kClassUM[0]) {
+    if (S <= kSmallContextScenes && big_um(UM, u_bound) > kClassUM[0]) {
         umb = big_um(UM, u_bound);
         clb = big_cl(umb, cfg.t_cap, cfg.db_min_samples);
         const size_t big = big_lds_bytes(umb, clb, false);
@@ -1771,7 +1770,7 @@ void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int u_boun
 {
     const int um = big_um(UM, u_bound);
     if (kClassUM[0] >= um) return;  // no cloud can exceed the small class
-    if (cfg.n_scenes <= kBigInPostScenes) return;  // k_post has taken them (launch_post)
+    if (cfg.n_scenes <= kSmallContextScenes) return;  // k_post has taken them (launch_post)
     const int S = cfg.n_scenes, cl = big_cl(um, cfg.t_cap, cfg.db_min_samples);
     if (um <= kBigThreads && um < UM) {
         const size_t lds = big_lds_bytes(um, cl, true);

@@ -295,7 +295,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.t_cap = cap; d.max_pts = max_pts; d.n_scenes = n_scenes;
     // layout of the Kalman kernels (mmw_kalman.hpp: tracks_dense): laid out over tracks when the context holds more
     // four-track waves than this; 0 = the default threshold (one wave per CU x 4), < 0 = always per scene
-    d.dense_min_units = cfg->kalman_dense_min_units == 0 ? 1024 : (cfg->kalman_dense_min_units < 0 ? 0x7fffffff : cfg->kalman_dense_min_units - 1);
+    d.dense_min_units = cfg->kalman_dense_min_units == 0 ? (n_scenes <= kSmallContextScenes ? 0x7fffffff : 1024)   // (small contexts: per scene, two-launch step)
+                                                         : (cfg->kalman_dense_min_units < 0 ? 0x7fffffff : cfg->kalman_dense_min_units - 1);
     if (d.seek_inner) d.dense_min_units = 0x7fffffff;  // k_inner changes a scene's track count between k_track and k_post: per-scene layout
     d.db_z_weight = cfg->db_z_weight; d.db_range_weight = cfg->db_range_weight; d.db_eps = cfg->db_eps;
     d.tr_lifetime_dynamic = cfg->tr_lifetime_dynamic; d.tr_lifetime_static = cfg->tr_lifetime_static;

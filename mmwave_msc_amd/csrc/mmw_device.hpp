@@ -110,6 +110,10 @@ struct DevState {
     int32_t *inner_buf;            // [S][kInnerHdr + inner_cap] seek_inner_clusters calls of the last frame (cfg.seek_inner; mmw_get_inner)
     int32_t inner_cap;             // label words per scene
 };
+// Contexts of at most this many scenes run a two-launch step (mmw_kalman.hpp: pred_in_track, k_dbscan.hip: k_post takes the large
+// clouds): their step is launch latency.  768 = what is resident at once with the PRED build of k_track (three workgroups
+// per CU); measured 0.0777 -> 0.0705 ms at 768 scenes, 0.0937 -> 0.1128 at 1024.
+constexpr int kSmallContextScenes = 768;
 constexpr int kQCount = 0, kQHead = 1, kQDone = 2, kQStop = 3, kQTimeout = 4;
 constexpr int kQBig = 16;   // q[kQBig + 8p + kQCount/kQHead/kQDone]: the queue of the clouds of more than 256 points
 constexpr int kQWords = 32;

@@ -236,14 +236,14 @@ __device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevSt
 // the lists put two more dependent loads in front of it (k_predict 8.3 -> 9.2 us there).  The threshold is 1024 waves;
 // MMW_DENSE_MIN_UNITS in the environment of mmw_create overrides it (the parity tests run both layouts on small contexts).
 __host__ __device__ inline bool tracks_dense(const DevCfg &cfg, int nq) { return cfg.t_cap <= 63 && cfg.n_scenes * nq > cfg.dense_min_units; }
-// Contexts whose step is launch latency (<= kPredInTrackScenes scenes, per-scene layout): _predict_all runs at the head of
-// k_track (k_track.hip, PRED instantiations) and k_predict is not launched -- one kernel boundary less.
-constexpr int kPredInTrackScenes = 512;
+// Contexts whose step is launch latency (<= kSmallContextScenes scenes, per-scene layout -- mmw_create picks it for them unless
+// told otherwise): _predict_all runs at the head of k_track (k_track.hip, PRED instantiations) and k_predict is not
+// launched -- one kernel boundary less.
 __host__ __device__ inline bool pred_in_track(const DevCfg &cfg)
 {
     int nq = (cfg.tr_max_tracks + 3) / 4;
     if (nq < 1) nq = 1;
-    return cfg.n_scenes <= kPredInTrackScenes && !tracks_dense(cfg, nq) && !cfg.seek_inner;
+    return cfg.n_scenes <= kSmallContextScenes && !tracks_dense(cfg, nq) && !cfg.seek_inner;
 }
 
 // _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of the list

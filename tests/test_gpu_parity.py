@@ -462,13 +462,13 @@ def test_side_workers_are_probed_and_switchable():
 
 
 def test_mid_size_context_takes_the_four_launch_step():
-    """Contexts of <= 512 scenes run a two-launch step (_predict_all at the head of k_track, the large clouds in k_post);
-    everything above runs k_predict / k_track / k_post / k_dbscan_big.  640 scenes -- the smallest kind of context that takes
+    """Contexts of <= 768 scenes run a two-launch step (_predict_all at the head of k_track, the large clouds in k_post);
+    everything above runs k_predict / k_track / k_post / k_dbscan_big.  832 scenes -- the smallest kind of context that takes
     the second form, in whichever Kalman layout the fixture selects -- against the oracle, start-up frames (large clouds)
     included."""
     from oracle import c_oracle as co
     import bench
-    S, N, T, F = 640, 128, 3, 7
+    S, N, T, F = 832, 128, 3, 7
     pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=4)
     sb = _mk(S, N, tr_max_tracks=T)
     ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
