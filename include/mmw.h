@@ -287,6 +287,10 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
  * Dense-1 of the same form:  out16[n][2][frames * 2048] fp16 = [hi | lo'] in Keras' Flatten order. */
 int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
                         const float *b2, void *out16, int32_t n);
+/* Dense-1 of the split form (train.py:49 / :87: Dense + ReLU) as two partial GEMMs that run side by side on two streams:
+ * g1 = bias + hi.W_hi, g2 = [hi | lo'].[W_lo' ; W_hi]; this merges them, g1[i] = max(g1[i] + scale * g2[i], 0) with
+ * scale = 2^-11.  n = number of floats (a multiple of 4), both pointers 16-byte aligned. */
+int mmw_mars_add_scaled_relu(void *hip_stream, float *g1, const float *g2, float scale, int64_t n);
 
 /* ReadIWR14xx.read (ReadDataIWR1443.py:27-201) on a byte buffer, host only (no context, no GPU work): the input
  * step before mmw_normalize.  Looks for the LAST 8-byte magic word 02 01 04 03 06 05 08 07 in buf[0 .. len-8),

@@ -468,4 +468,28 @@ void launch_mars_conv16(int nz, const float *feat, const float *w1, const float 
     else launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, B, stream);
 }
 
+// Dense-1's merge: h = relu(g1 + scale * g2) in place of g1 (the two partial GEMMs of the split product run side by side on
+// two streams, see mars.py; scale = 2^-11 is exact, so this is what beta = 1 accumulation in the second GEMM gave).
+__global__ __launch_bounds__(256) void k_add_scaled_relu(float4 *__restrict__ g1, const float4 *__restrict__ g2, float scale, long long n4)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 a = g1[i];
+        const float4 b = g2[i];
+        a.x = fmaxf(a.x + b.x * scale, 0.f);
+        a.y = fmaxf(a.y + b.y * scale, 0.f);
+        a.z = fmaxf(a.z + b.z * scale, 0.f);
+        a.w = fmaxf(a.w + b.w * scale, 0.f);
+        g1[i] = a;
+    }
+}
+void launch_add_scaled_relu(float *g1, const float *g2, float scale, long long n, hipStream_t stream)
+{
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_add_scaled_relu, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<float4 *>(g1),
+                       reinterpret_cast<const float4 *>(g2), scale, n4);
+}
+
 }  // namespace mmw

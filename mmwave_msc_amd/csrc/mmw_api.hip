@@ -50,6 +50,7 @@ void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
                       hipStream_t stream);
+void launch_add_scaled_relu(float *g1, const float *g2, float scale, long long n, hipStream_t stream);
 void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
                         hipStream_t stream);
 }  // namespace mmw
@@ -859,6 +860,17 @@ int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, con
     launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, n, (hipStream_t)hip_stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv_split launch -> %s", hipGetErrorString(e));
+    return MMW_OK;
+}
+
+int mmw_mars_add_scaled_relu(void *hip_stream, float *g1, const float *g2, float scale, int64_t n)
+{
+    if (n < 0 || (n & 3) != 0 || (n > 0 && (!g1 || !g2)) || (((uintptr_t)g1 | (uintptr_t)g2) & 15) != 0)
+        return fail(nullptr, MMW_E_ARG, "mmw_mars_add_scaled_relu: n must be a multiple of 4, pointers 16-byte aligned");
+    if (n == 0) return MMW_OK;
+    launch_add_scaled_relu(g1, g2, scale, (long long)n, (hipStream_t)hip_stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_add_scaled_relu launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 

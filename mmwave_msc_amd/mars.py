@@ -69,6 +69,7 @@ class MarsCNN(nn.Module):
         if arith not in ("f32", "f16x3"):
             raise ValueError(arith)
         self.arith = arith
+        self._side_streams = {}   # device index -> the stream the second Dense-1 GEMM runs on
         self.frames = int(frames)
         self.three_d = self.frames > 1
         conv = nn.Conv3d if self.three_d else nn.Conv2d
@@ -179,18 +180,42 @@ class MarsCNN(nn.Module):
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return out
 
-    def _dense1_split(self, a2: torch.Tensor) -> torch.Tensor:
-        """bias + hi.W_hi + 2^-11 [hi | lo'].[W_lo' ; W_hi]: two fp16 GEMMs with fp32 accumulation and output."""
+    # a batch below this many rows leaves the chip mostly idle either way: one stream, no merge kernel
+    SIDE_BY_SIDE_MIN_ROWS = 2048
+
+    def _dense1_split_relu(self, a2: torch.Tensor) -> torch.Tensor:
+        """relu(bias + hi.W_hi + 2^-11 [hi | lo'].[W_lo' ; W_hi]): two fp16 GEMMs with fp32 accumulation and output.
+        Large batches run the two GEMMs SIDE BY SIDE on two streams -- each is 1.7 waves of 256x256 tiles on 256 CUs, together
+        3.4 instead of 2 + 2 -- and merge them with one elementwise pass (mmw_mars_add_scaled_relu; 2^-11 is exact, so the
+        result is bit for bit what accumulating the second GEMM onto the first gives): 1.22 -> 1.09 ms at 18 k rows."""
         k = a2.shape[1] // 2
+        if a2.shape[0] < self.SIDE_BY_SIDE_MIN_ROWS:
+            g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi_t.t(), out_dtype=torch.float32)
+            return F.relu_(torch.addmm(g1, a2, self.d1_w2_t.t(), out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE))
+        from . import _lib
+        L = _lib.load()
+        cur = torch.cuda.current_stream(a2.device)
+        side = self._side_streams.get(a2.device.index)
+        if side is None:
+            side = self._side_streams[a2.device.index] = torch.cuda.Stream(device=a2.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            g2 = torch.mm(a2, self.d1_w2_t.t(), out_dtype=torch.float32)
         g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi_t.t(), out_dtype=torch.float32)
-        return torch.addmm(g1, a2, self.d1_w2_t.t(), out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE)
+        cur.wait_stream(side)
+        g2.record_stream(cur)
+        a2.record_stream(side)
+        rc = L.mmw_mars_add_scaled_relu(cur.cuda_stream, g1.data_ptr(), g2.data_ptr(), 1.0 / SPLIT_SCALE, g1.numel())
+        if rc != 0:
+            raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
+        return g1
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""
         if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32 and (self.arith == "f16x3" or self.use_hip_conv_f32):
             with torch.cuda.device(x.device):
                 if self.arith == "f16x3":
-                    h = F.relu_(self._dense1_split(self._hip_convs_split(x)))
+                    h = self._dense1_split_relu(self._hip_convs_split(x))
                 else:
                     h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
             return self.dense2(h)

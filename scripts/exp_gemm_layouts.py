@@ -59,3 +59,22 @@ for name, f in (("two GEMMs, W [K,N]", two_nn), ("two GEMMs, W^T [N,K]", two_nt)
     err = float((out[:256].double() - ref).abs().max())
     print(f"tuned {name:28s} {tm(f):.3f} ms   max err vs fp64 {err:.2e}   (tuning so far {time.perf_counter() - t0:.0f} s)")
 for r in tun.get_results(): print(r)
+
+# the two GEMMs side by side on two streams, merged by one elementwise pass
+tun.enable(False)
+s2 = torch.cuda.Stream(device=dev)
+def two_concurrent():
+    cur = torch.cuda.current_stream(dev)
+    s2.wait_stream(cur)
+    with torch.cuda.stream(s2):
+        g2 = torch.mm(a2, w2_t.t(), out_dtype=torch.float32)
+    g1 = torch.addmm(bias, a2[:, :K], w_hi_t.t(), out_dtype=torch.float32)
+    cur.wait_stream(s2)
+    g2.record_stream(cur)
+    return torch.relu_(g1.add_(g2, alpha=1.0 / S))
+def two_serial_relu():
+    return torch.relu_(two_nt())
+a = two_concurrent(); b = two_serial_relu()
+print("concurrent == serial:", bool(torch.equal(a, b)), float((a - b).abs().max()))
+for name, f in (("serial + relu", two_serial_relu), ("two streams + add + relu", two_concurrent)):
+    print(f"{name:28s} {tm(f, 20):.3f} ms")
