@@ -13,16 +13,18 @@
 //
 // Layout: x,y,z of the candidate points sit in LDS as fp64 SoA (indexed by point
 // index); `idx` maps tree position -> point index so every node is a contiguous
-// position range.  A query leaves a 2-bit state per leaf (64-bit mask per point)
-// that the labelling phase re-uses instead of an adjacency matrix.
+// position range.  A query leaves a 2-bit state per leaf (64-bit mask per point); for
+// clouds of <= 512 points it also records the neighbourhood itself as a bit row, and
+// the labelling runs on the (transposed) bit matrix alone; larger clouds re-use the
+// leaf states.  query_radius is walked one WAVE at a time (uniform node / level).
 //
-// Size classes: the cloud is the concatenation of <= ring frames of UNASSIGNED points, so
-// its size U varies from a few dozen (steady state: clutter only) to ring*max_pts.  LDS is
-// carved per class so that small clouds do not pay for the largest one:
-//   class 0: U <= 256   256 threads, thread i owns point i with all 8 columns in registers
-//   class 1: U <= 768   256 threads
-//   class 2: U <= 1920  256 threads
-// k_track appends every scene that must cluster to the work list of its class.
+// Who runs it: the cloud is the concatenation of <= ring frames of UNASSIGNED points, so its
+// size U varies from a few dozen (steady state: clutter only) to ring*max_pts.
+//   U <= 256          256 threads, thread i owns point i with all 8 columns in registers: the worker blocks of k_post
+//   U <= 1920         512 threads (thread per point up to 512, strided build above): k_dbscan_big / k_dbscan_startup
+//   both, early       the 512-thread workgroups of k_chain on a side stream, while k_track and k_post are still running
+// k_track pushes every scene that must cluster into one of two queues (or, without side workers, a work list); LDS is
+// carved per capacity so that small clouds do not pay for the largest one.
 #include <cstdlib>
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
@@ -1324,15 +1326,16 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
 // The clouds of more than 256 points (a scene without tracks clusters its whole ring: the start-up frames, and every scene
 // whose tracks have all expired): 100-250 us of BallTree chain each on a 512-thread workgroup.  They sit in a queue k_track
 // fills while it runs (q[kQBig + ...], ring = list 1).  Consumers:
-//   k_chain_big       a few workgroups on a side stream, BESIDE k_track and k_post (claims by compare-and-swap, leaves
-//                     when k_post has begun and the queue is empty);
+//   k_chain           eight workgroups on a side stream, BESIDE k_track and k_post, for this queue and the small clouds'
+//                     (claims by compare-and-swap, leaves when k_post has begun and both queues are empty; not in the
+//                     start-up frames, whose pushes carry no release: cfg.big_live);
 //   k_dbscan_big      behind k_post on the context's stream: takes what is left (tickets by atomicAdd: the pushes are
 //                     complete) and does not end before every claimed cloud is finished;
 //   k_dbscan_startup  the same for the first frames after a reset, when every cloud fits one point per thread, under a
 //                     register budget that lets two workgroups share a CU;
 //   k_post            in contexts of <= kSmallContextScenes scenes, whose step is launch latency: its worker blocks take the
 //                     large clouds too (256 threads, strided build -- rare there) and k_dbscan_big is not launched.
-// Correctness never depends on k_chain_big having run.
+// Correctness never depends on k_chain having run.
 constexpr int kBigThreads = 512;
 template <int NT, bool AFTER_TRACK, bool TPP_ONLY>
 __device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
