@@ -489,3 +489,41 @@ def test_mid_size_context_takes_the_four_launch_step():
             assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
     sb.check()
     sb.close()
+
+
+def test_largest_capacity_context_vs_oracle():
+    """ring * max_pts = 1920, the largest cloud the BallTree emulation holds (63 nodes): the LDS carve-up of that capacity
+    keeps 256-point bit rows only, k_track runs its four-points-per-thread build; start-up frames cluster 640, 1280 and
+    1920 points."""
+    from oracle import c_oracle as co
+    import bench
+    S, N, T, F = 24, 640, 4, 6
+    pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=4)
+    for s in range(0, S, 3):   # every third scene clutter only: it keeps clustering its whole ring
+        rng = np.random.default_rng(9000 + s)
+        pts[:, s, :, 0] = rng.uniform(-6, 6, size=(F, N)).astype(np.float32)
+        pts[:, s, :, 1] = rng.uniform(0.3, 7.5, size=(F, N)).astype(np.float32)
+        pts[:, s, :, 2] = rng.uniform(0.05, 2.4, size=(F, N)).astype(np.float32)
+    sb = _mk(S, N, tr_max_tracks=T)
+    assert sb.UM == 1920
+    ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
+    biggest = 0
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        oa, ol, od = ob.step(pts[f].astype(np.float64), cnt[f], dts[f])
+        assert np.array_equal(dbn, od), f
+        assert np.array_equal(assoc, oa), f
+        for s in range(S):
+            if od[s] > 0:
+                assert np.array_equal(labels[s, : od[s]], ol[s, : od[s]]), (f, s)
+        biggest = max(biggest, int(od.max()))
+    assert biggest > 1536
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    for s in range(S):
+        want = ob.scenes[s].tracks()
+        assert ntr[s] == len(want), s
+        for name in ("x", "P", "centroid", "spread_est", "n_est", "lifetime", "point_num", "ring_n"):
+            assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
+    sb.check()
+    sb.close()
