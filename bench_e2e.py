@@ -111,7 +111,7 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def oracle_reference(workers=1):
+def oracle_reference(workers=1, par=None):
     """configs[3] on the CPU oracle: per frame track -> features -> (CNN deferred) -> set_keypoints.  The CNN is a pure
     function of the feature tensor, so the oracle stores every tensor it would have fed to `model.predict`, tags the
     track with the tensor's index instead of real keypoints, and evaluates the fp64 CNN once at the end for the
@@ -122,7 +122,7 @@ def oracle_reference(workers=1):
     from oracle.mars_np import mars_forward_np
     import bench
 
-    p = E2E_PAR
+    p = par or E2E_PAR
     S, N, T, F = p["S"], p["N"], p["T"], p["F"]
     ids = np.arange(p["seed0"], p["seed0"] + S)
     pts, cnt, dts = bench.generate(ids, F, N, T, workers)
@@ -155,7 +155,7 @@ def oracle_reference(workers=1):
     default = np.array(list(cfg.default_posture), dtype=np.float64)
     want_kp = [np.stack([kp_of[int(r["keypoints"][0])] if r["keypoints"][1] == MARK else default for r in fin])
                if len(fin) else np.zeros((0, 57)) for fin in finals]
-    return {"pts": pts, "cnt": cnt, "dts": dts, "finals": finals, "want_kp": want_kp, "weights": w,
+    return {"par": dict(p), "pts": pts, "cnt": cnt, "dts": dts, "finals": finals, "want_kp": want_kp, "weights": w,
             "oracle_s": round(time.perf_counter() - t0, 1), "samples_cnn": len(need)}
 
 
@@ -167,7 +167,7 @@ def e2e_parity_leg(ref, device):
     from mmwave_msc_amd.mars import MarsCNN
     from mmwave_msc_amd.posture import PosturePipeline
 
-    p = E2E_PAR
+    p = ref.get("par") or E2E_PAR
     S, N, T, F = p["S"], p["N"], p["T"], p["F"]
     dev = torch.device("cuda", device)
     sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N, device=device)
@@ -208,7 +208,7 @@ def e2e_parity_leg(ref, device):
             max_err = max(max_err, float(err.max()))
             n_kp += len(want)
     sb.close()
-    return {"config": f"{S} scenes x {N} pts x TR_MAX_TRACKS={T}, {F} frames, track+features+CNN+keypoints every frame; BASELINE.json configs[3]",
+    return {"config": f"{S} scenes x {N} pts x TR_MAX_TRACKS={T}, {F} frames, track+features+CNN+keypoints every frame; BASELINE.json {p.get('label', 'configs[3]')}",
             "tracker_state_bit_equal_vs_oracle": bool(ints_ok), "tracks_checked": int(n_kp),
             "keypoint_max_err": float(f"{max_err:.3e}"), "keypoint_tol": KP_TOL, "keypoints_ok": bool(ints_ok and max_err <= KP_TOL),
             "cnn_oracle": "oracle/mars_np.py (fp64 numpy restatement of train.py:71-106; parity unpinned: no Keras / MARS.h5 in the image)",

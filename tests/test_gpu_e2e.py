@@ -27,6 +27,18 @@ def test_e2e_256_scenes_every_frame_vs_oracle():
     assert res["keypoint_max_err"] <= KP_TOL, res
 
 
+def test_e2e_one_rank_of_configs4_vs_oracle():
+    """BASELINE.json configs[4] is configs[3]'s loop on 4096 scenes x 512 points x 8 tracks over 8 GPUs: one rank's shard
+    (512 scenes) end to end against the oracle -- tracker state bit-equal, keypoints within 1e-4 of the fp64 CNN."""
+    import bench_e2e
+    ref = bench_e2e.oracle_reference(workers=4, par=dict(S=512, N=512, T=8, F=6, seed0=512 * 3, label="configs[4], rank 3 of 8"))
+    assert ref["samples_cnn"] > 1024
+    res = bench_e2e.e2e_parity_leg(ref, 0)
+    assert res["tracker_state_bit_equal_vs_oracle"], res
+    assert res["tracks_checked"] >= ref["samples_cnn"]
+    assert res["keypoint_max_err"] <= KP_TOL, res
+
+
 def _run_loop(sb, pts, cnt, dts, model, pipelined):
     import torch
     from mmwave_msc_amd.posture import PosturePipeline
