@@ -97,6 +97,11 @@ class MarsCNN(nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)
 
+    def __getstate__(self):   # (streams are process-local: a pickled / deep-copied model makes its own)
+        d = dict(self.__dict__)
+        d["_side_streams"] = {}
+        return d
+
     @classmethod
     def from_keras_weights(cls, w: dict, arith: str = "f16x3") -> "MarsCNN":
         three_d = np.asarray(w["conv1_w"]).ndim == 5
