@@ -274,6 +274,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the invalidate has completed before the first gate record is requested
     }
 
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
