@@ -54,9 +54,11 @@ def _gen_one(args):
     return make_scene(sid, frames, n_pts, n_targets)
 
 
-def generate(scene_ids, frames, n_pts, tracks, workers):
-    """points[F,S,N,8] float32, counts[F,S] int32, dt[F,S] float64 for the given global scene ids."""
-    jobs = [(int(s), frames, n_pts, 1 + int(s) % tracks) for s in scene_ids]
+def generate(scene_ids, frames, n_pts, tracks, workers, population="mixed"):
+    """points[F,S,N,8] float32, counts[F,S] int32, dt[F,S] float64 for the given global scene ids.  population "mixed":
+    scene s holds 1 + (s mod T) targets (the headline workload); "full": every scene holds T targets (SURVEY.md
+    §8(d)'s K = T: every track spawns in the first frames and apply_DBscan is never called again)."""
+    jobs = [(int(s), frames, n_pts, tracks if population == "full" else 1 + int(s) % tracks) for s in scene_ids]
     if workers > 1 and len(jobs) > 8:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
@@ -246,6 +248,10 @@ def main():
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")
     ap.add_argument("--chain-side-stream", type=int, default=0, choices=(-1, 0, 1),
                     help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1536 scenes), 1 = on, -1 = off")
+    ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
+    ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
+    ap.add_argument("--fused-step", type=int, default=0, choices=(-1, 0, 1),
+                    help="mmw_config.fused_step: 0 = the library's choice (k_scene for contexts whose scenes are all resident), 1 = on, -1 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / shard / gather plumbing only, on the CPU with gloo (tests/test_dist_gloo.py): no GPU work, no metric")
     ap.add_argument("--gen-workers", type=int, default=-1,
@@ -288,6 +294,11 @@ def main():
     cpu, finals = {}, None
     if single and not args.no_cpu:
         cpu, finals = cpu_legs(pts, cnt, dts, args.tracks, cores, W, args.py_scenes_per_core, args.py_frames, args.c_scenes)
+    full_host, cpu_full, finals_full = None, {}, None
+    if single and not args.no_full:
+        full_host = generate(ids, F, N, args.tracks, workers=workers, population="full")
+        if not args.no_cpu:
+            cpu_full, finals_full = cpu_legs(*full_host, args.tracks, cores, W, args.py_scenes_per_core, args.py_frames, args.c_scenes)
     e2e_ref = None
     if single and not args.no_e2e_parity:
         from bench_e2e import oracle_reference  # CPU side of the configs[3] leg (oracle), before the GPU is initialised
@@ -311,7 +322,8 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
     n_ranks_seen = dist.get_world_size() if world > 1 else 1
-    sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream), S, N, device=local_rank)
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream, fused_step=args.fused_step),
+                    S, N, device=local_rank)
     # one real stream for torch and the context: uploads, the CNN of the posture leg and the mmw_* calls on device
     # tensors are then ordered by the stream itself (torch's default stream would read as "context's own stream")
     side = torch.cuda.Stream(device=dev)
@@ -415,19 +427,107 @@ def main():
     prof = {k: sb.profile_get(k) for k in (_lib.K_TRACK, _lib.K_DBSCAN, _lib.K_TABLE, _lib.K_PREDICT, _lib.K_POST)}
     gathered_rows = int(gathered.shape[0])
 
+    def final_state_equal(ctx, want_states):
+        """final track state of the context's first len(want_states) scenes against the oracle's, bit for bit"""
+        ntr_ = ctx.num_tracks()
+        trk_ = ctx.tracks(cap=max(int(ntr_.max()), 1))
+        for s_, want in enumerate(want_states):
+            if len(want) != ntr_[s_]:
+                return False
+            got = trk_[s_, : ntr_[s_]]
+            for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "lifetime", "point_num", "is_static", "ring_n"):
+                if not np.array_equal(got[name], want[name]):
+                    return False
+        return True
+
+    def timed_window(ctx, p_dev, c_dev, t_dev, n_ctx):
+        """W untimed + K timed steps of a context over the first n_ctx scenes of the resident frames (the same window as the
+        headline: frames W..F-1 timed); returns (seconds, per-kernel average ms from the sampled HIP-event pairs)."""
+        a_, l_, b_ = d_assoc[:n_ctx], d_lab[:n_ctx], d_dbn[:n_ctx]
+
+        def st_(f):
+            ctx.step_dev(p_dev[f][:n_ctx].data_ptr(), c_dev[f][:n_ctx].data_ptr(), t_dev[f][:n_ctx].data_ptr(),
+                         a_.data_ptr(), l_.data_ptr(), b_.data_ptr())
+        for f in range(W):
+            st_(f)
+        torch.cuda.synchronize()
+        ctx.check()
+        ctx.stats_reset()
+        ctx.profile_reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for f in range(W, F):
+            if (f - W) % PROF_EVERY == 0:
+                ctx.profile(True, kernels=(_lib.K_TRACK, OTHER_KERNELS[((f - W) // PROF_EVERY) % len(OTHER_KERNELS)]))
+            else:
+                ctx.profile(False)
+            st_(f)
+        torch.cuda.synchronize()
+        el_ = time.perf_counter() - t1
+        ctx.profile(False)
+        ctx.check()
+        pk_ = {name: ctx.profile_get(k) for k, name in ((_lib.K_PREDICT, "k_predict"), (_lib.K_TRACK, "k_track"),
+                                                        (_lib.K_DBSCAN, "k_dbscan_big"), (_lib.K_POST, "k_post"))}
+        return el_, {name: round(v[0] / max(v[1], 1), 5) for name, v in pk_.items()}
+
     parity = None
     if finals is not None:
-        ntr = sb.num_tracks()
-        trk = sb.tracks(cap=max(int(ntr.max()), 1))
-        ok = True
-        for s, want in enumerate(finals):
-            got = trk[s, : ntr[s]]
-            ok &= len(want) == ntr[s]
-            if not ok:
-                break
-            for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "lifetime", "point_num", "is_static", "ring_n"):
-                ok &= bool(np.array_equal(got[name], want[name]))
-        parity = {"scenes_checked": len(finals), "frames": F, "bit_equal_vs_oracle": bool(ok)}
+        parity = {"scenes_checked": len(finals), "frames": F, "bit_equal_vs_oracle": bool(final_state_equal(sb, finals))}
+
+    STEP_NAMES = {1: "k_scene + k_post workers", 2: "k_track (with _predict_all) + k_post", 4: "k_predict + k_track + k_post + k_dbscan_big"}
+
+    # ---- shard legs: what ONE rank of the 2- / 4- / 8-GPU strong-scaling job runs (rank 0's scenes 0..S/G-1, same
+    #      generator, same frame window), on this GPU; projected whole-node value = G x S_shard x K / t_shard ----
+    shards = None
+    if single and not args.no_shards and scaling == "strong" and S >= 8:
+        shards = {}
+        for G in (2, 4, 8):
+            n_sh = shard_range(S_total, 0, G)[1]
+            ctx = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream, fused_step=args.fused_step),
+                             n_sh, N, device=local_rank)
+            ctx.follow_torch_stream(side)
+            el_s, k_s = timed_window(ctx, d_pts, d_cnt, d_dt, n_sh)
+            ent = {"scenes": n_sh, "ms_per_step": round(el_s / K * 1e3, 4), "scene_frames_per_s": round(n_sh * K / el_s, 1),
+                   "projected_whole_node": round(G * n_sh * K / el_s, 1), "step_kernels": STEP_NAMES[ctx.step_kind()], "kernels_avg_ms": k_s}
+            if finals is not None:
+                nchk = min(n_sh, len(finals))
+                ent["parity"] = {"scenes_checked": nchk, "frames": F, "bit_equal_vs_oracle": bool(final_state_equal(ctx, finals[:nchk]))}
+            shards[f"{G}_gpus"] = ent
+            ctx.close()
+        shards["note"] = ("one rank's share of the G-GPU job (scenes 0..S/G-1) stepped on this one GPU; projected_whole_node = G x that "
+                          "rank's scene-frames/s (no data-path collective; the once-per-run all-gather of 324 B per track is not in it)")
+
+    # ---- SURVEY.md §8(d)'s population: every scene holds K = T targets (all tracks spawn in the first frames, apply_DBscan is
+    #      never called again: 1.8x the gate / Kalman work of the mixed population, no clustering) ----
+    full = None
+    if full_host is not None:
+        fp_, fc_, fd_ = full_host
+        d_fp = torch.empty((F, S, N, 8), dtype=torch.float64, device=dev)
+        for f in range(F):
+            d_fp[f] = torch.from_numpy(fp_[f]).to(dev).double()
+        d_fc, d_fd = torch.from_numpy(fc_).to(dev), torch.from_numpy(fd_).to(dev)
+        ctx = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream, fused_step=args.fused_step),
+                         S, N, device=local_rank)
+        ctx.follow_torch_stream(side)
+        el_f, k_f = timed_window(ctx, d_fp, d_fc, d_fd, S)
+        stf = ctx.stats()
+        kt_ms = k_f["k_track"]
+        full = {"workload": f"{S} scenes x {N} pts x TR_MAX_TRACKS={args.tracks}, EVERY scene holds {args.tracks} targets (SURVEY.md §8d: K = T)",
+                "value": round(S * K / el_f, 1), "unit": "scene-frames/s", "ms_per_step": round(el_f / K * 1e3, 4), "kernels_avg_ms": k_f,
+                "step_kernels": STEP_NAMES[ctx.step_kind()],
+                "gate_evals_per_step": round(float(stf[6]) / K, 1), "tracks_per_scene": round(float(stf[5]) / max(float(stf[2]), 1.0), 2),
+                "dbscan_calls_per_step": round(float(stf[3]) / K, 1),
+                "roofline": {"kernel": "k_track", "bound": "hbm", "achieved": round(float(stf[0]) / K / max(kt_ms, 1e-9) / 1e6, 2), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(float(stf[0]) / K / max(kt_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 6),
+                             "algorithmic_bytes_per_launch": round(float(stf[0]) / K, 1), "avg_launch_ms": kt_ms}}
+        if finals_full is not None:
+            full["parity"] = {"scenes_checked": len(finals_full), "frames": F, "bit_equal_vs_oracle": bool(final_state_equal(ctx, finals_full))}
+        full.update(cpu_full)
+        if "cpu_baseline" in cpu_full:
+            full["speedup_vs_cpu_baseline"] = round(full["value"] / cpu_full["cpu_baseline"]["value"], 1)
+            full["speedup_vs_cpu_native"] = round(full["value"] / cpu_full["cpu_baseline_native"]["value"], 1)
+        ctx.close()
+        del d_fp
 
     # ---- end to end: the same scenes again from frame 0, estimate_posture after every track() ----
     e2e = None
@@ -530,12 +630,17 @@ def main():
                      "gate_evals_per_step": round(gate_evals / K, 1), "tracks_per_scene": round(mean_T, 2),
                      "clusters_found_per_step": round(float(stats[7]) / K, 2)},
             "side_workers": side_workers,
+            "step_kernels": STEP_NAMES[sb.step_kind()],
             "host": {"cores": cores, "logical_cpus": os.cpu_count(), "gen_s": round(t_gen, 1),
                      "note": "cores = min(logical CPUs, affinity mask, cgroup CPU quota): what the CPU baselines can really use"},
         }
         line.update(cpu)
         if parity is not None:
             line["parity"] = parity
+        if shards is not None:
+            line["shards"] = shards
+        if full is not None:
+            line["full_tracks"] = full
         if cold is not None:
             line["cold_start"] = cold
         if e2e is not None:

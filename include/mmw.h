@@ -95,6 +95,13 @@ typedef struct mmw_config {
     double v_screen_fade_size_max;  /* V_SCREEN_FADE_SIZE_MAX :48 */
     double v_screen_fade_size_min;  /* V_SCREEN_FADE_SIZE_MIN :49 */
     double v_screen_fade_weight;    /* V_SCREEN_FADE_WEIGHT :50 */
+    int32_t fused_step;             /* not a reference constant: which kernels make a step.  0 = automatic: a context of 257..512 scenes
+                                       whose scenes are all resident at once, two workgroups per CU (<= 512 points per frame), runs
+                                       TrackBuffer.track of a scene in ONE workgroup start to finish (k_scene: the step is one scene's
+                                       latency there), others the bulk kernels; 1 = the one-workgroup step whenever the configuration
+                                       allows it (not with seek_inner, resized rings, track_cap > 63 or the side-stream workers);
+                                       -1 = never (tests run both) */
+    int32_t reserved_;
 } mmw_config;
 
 /* One entry of TrackBuffer.effective_tracks (Tracking.py:139-230), flattened:
@@ -321,6 +328,11 @@ int mmw_stats_reset(mmw_ctx *ctx);
  * queue with the context's stream: checked by the first mmw_step after mmw_create / mmw_set_stream /
  * mmw_set_chain_side_stream), 1 = yes, 2 = configured, not checked yet (no step since). */
 int mmw_side_workers(mmw_ctx *ctx);
+/* Which kernels the next mmw_step launches for TrackBuffer.track (Tracking.py:683-703): 1 = the one-workgroup step (k_scene: a
+ * scene's whole track() in one workgroup, then the DBSCAN worker blocks of k_post; contexts whose scenes are all resident at
+ * once, mmw_config.fused_step), 2 = two launches (k_track with _predict_all at its head, k_post), 4 = the bulk kernels
+ * (k_predict, k_track, k_post, k_dbscan_big).  The results do not depend on it. */
+int mmw_step_kind(mmw_ctx *ctx);
 /* Diagnostic: the queue of scenes whose small-cloud DBSCAN k_track could not rule out (k_dbscan.hip), per step parity p:
  * [8p] pushed, [8p+1] claimed, [8p+2] finished this step; [3] last step whose k_post has begun, [4] waits given up (also
  * reported by mmw_check); [16 + 8p ...] the same three words for the queue of the clouds of more than 256 points.

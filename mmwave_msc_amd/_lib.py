@@ -32,7 +32,7 @@ EXPORTS = [
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
-    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_add_scaled_relu", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers",
+    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_add_scaled_relu", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind",
 ]
 
 
@@ -54,6 +54,7 @@ class MmwConfig(C.Structure):
         ("db_spread_thres", C.c_double), ("db_inner_eps", C.c_double),
         ("m_x", C.c_double), ("m_y", C.c_double), ("m_z", C.c_double),
         ("v_screen_fade_size_max", C.c_double), ("v_screen_fade_size_min", C.c_double), ("v_screen_fade_weight", C.c_double),
+        ("fused_step", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -171,6 +172,7 @@ def load():
         "mmw_stats_reset": (C.c_int, [vp]),
         "mmw_diag_queue": (C.c_int, [vp, vp]),
         "mmw_side_workers": (C.c_int, [vp]),
+        "mmw_step_kind": (C.c_int, [vp]),
         "mmw_set_chain_side_stream": (C.c_int, [vp, i32]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
         "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),

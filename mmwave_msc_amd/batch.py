@@ -118,6 +118,10 @@ class SceneBatch:
         queue with the context's stream), 1 = in use, 2 = configured but no step has checked the streams yet."""
         return int(self.L.mmw_side_workers(self.h))
 
+    def step_kind(self) -> int:
+        """mmw_step_kind: 1 = the one-workgroup step (k_scene), 2 = two launches, 4 = the bulk kernels."""
+        return int(self.L.mmw_step_kind(self.h))
+
     def synchronize(self):
         self._chk(self.L.mmw_synchronize(self.h))
 

@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const 
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     if ((int)blockIdx.x < G0) {
         __builtin_amdgcn_s_setprio(3);  // the latency chain goes first whenever it has an instruction ready
-        if ((int)blockIdx.x == G0 - 1) {
+        if ((int)blockIdx.x == G0 - 1 && !cfg.fused) {  // (k_scene reads no schedule: every scene is resident)
             // (the worker least likely to have a scene) next frame's schedule for k_track: scenes by descending
             // track count -- a counting sort over the scene headers; the order inside a count is irrelevant.
             // (Scenes without tracks FIRST -- they are the ones that cluster their whole ring, 100-250 us on a chain
@@ -1732,7 +1732,7 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
 {
     int nq = (cfg.tr_max_tracks + 3) / 4;
     if (nq < 1) nq = 1;
-    const int S = cfg.n_scenes, units = S * nq;
+    const int S = cfg.n_scenes, units = cfg.fused ? 0 : S * nq;  // (fused step: _update_all ran inside k_scene, only the DBSCAN workers are left)
     int G0 = S < 256 ? S : 256;
     const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);
     size_t lds = post_lds_bytes(UM, cfg.t_cap, cfg.db_min_samples);

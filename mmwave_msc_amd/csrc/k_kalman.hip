@@ -162,7 +162,7 @@ static int waves_per_scene(const DevCfg &cfg)
 
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream)
 {
-    if (pred_in_track(cfg)) return;  // _predict_all runs at the head of k_track there (mmw_kalman.hpp)
+    if (pred_in_track(cfg) || cfg.fused) return;  // _predict_all runs at the head of k_track / inside k_scene there (mmw_kalman.hpp)
     const int nq = waves_per_scene(cfg);
     const int grid = cfg.n_scenes * nq + (tracks_dense(cfg, nq) ? kSpecialUnits : 0);
     if (cfg.dx == 9) mmw_launch(k_predict<9>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);

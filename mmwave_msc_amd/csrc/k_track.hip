@@ -31,15 +31,24 @@ namespace mmw {
         }                                                                                     \
     } while (0)
 // PROBE(id): raw clock of lane 0 of every wave of ONE workgroup (scene kProbeScene), for timelines
-constexpr int kProbeScene = 1234;
+constexpr int kProbeScene = 460;   // (a block index: st.perm puts the scenes with the most tracks first)
 #define PROBE(id)                                                                             \
     do {                                                                                      \
         if (blockIdx.x == kProbeScene && (threadIdx.x & 63) == 0)                             \
-            st.stats[kStatSlots * kStatWords + (threadIdx.x >> 6) * 32 + (id)] = __builtin_amdgcn_s_memtime(); \
+            st.stats[kStatSlots * kStatWords + (threadIdx.x >> 6) * 64 + (id)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// WGTIME(k): s_memrealtime (100 MHz, chip-wide) and s_memtime of every workgroup's start (k = 0) and end (k = 1)
+#define WGTIME(k)                                                                             \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < 2048) {                                          \
+            st.stats[kStatSlots * kStatWords + 256 + blockIdx.x * 4 + (k) * 2] = __builtin_amdgcn_s_memrealtime(); \
+            st.stats[kStatSlots * kStatWords + 256 + blockIdx.x * 4 + (k) * 2 + 1] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                     \
     } while (0)
 #else
 #define STAMP(k)
 #define PROBE(id)
+#define WGTIME(k)
 #endif
 
 
@@ -206,6 +215,8 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     const int s = st.perm[(size_t)parity * cfg.n_scenes + blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    PROBE(19);
+    WGTIME(0);
     // The single-wave job below (track maintenance) goes to wave `role == 0`, rotated by scene so that the
     // resident workgroups of a CU do not all queue it on the same SIMD.
     const int role = (wave + s) & (kWaves - 1);
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
 #ifdef MMW_STAMPS
     unsigned long long t_prev = __builtin_amdgcn_s_memtime();
 #endif
+    PROBE(16);
     if constexpr (PRED) {
         // _predict_all (Tracking.py:591-596) + the gate matrices, as k_predict does them: a 16-lane group per track, sixteen
         // tracks per round over the four waves; scratch = the head of this kernel's LDS (nothing else lives there yet).
@@ -269,12 +281,14 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             if (cfg.dx == 9) predict_one_track<9>(cfg, st, rec, live, s, j, dt, Wj, lane, lane & 15, perr);
             else predict_one_track<6>(cfg, st, rec, live, s, j, dt, Wj, lane, lane & 15, perr);
         }
+        PROBE(17);
         if (perr) atomicOr(&hdr->err, perr);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_s_dcache_inv();
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the invalidate has completed before the first gate record is requested
+        PROBE(18);
     }
 
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
@@ -300,7 +314,31 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         typedef const double __attribute__((address_space(4))) *gate_ptr;
         const int su = __builtin_amdgcn_readfirstlane(s), Tu = __builtin_amdgcn_readfirstlane(T);
         gate_ptr gb = (gate_ptr)(st.gate_buf + (size_t)su * cfg.t_cap * kGateRec);
+        // (PRED: the records were written by this launch.  The constant address space promises the compiler memory that does
+        //  not change, so the pointer itself is made opaque HERE, behind the invalidate: no load through it can be moved above
+        //  this statement)
+        asm volatile("" : "+s"(gb) : : "memory");
+        {
+            // Warm the scalar cache: one dword of every 64-byte line of the scene's gate records, all requests in flight
+            // together.  The loop below then takes its records (six s_loads per track, waited for as a batch) from the
+            // scalar cache instead of paying an L2 round trip per track -- with two workgroups per CU nothing hides that.
+            typedef const int __attribute__((address_space(4))) *line_ptr;
+            const unsigned long long a0 = (unsigned long long)gb & ~63ULL;
+            const int lines = (int)((((unsigned long long)gb + (unsigned long long)Tu * kGateRec * 8 + 63ULL) & ~63ULL) - a0) >> 6;
+            line_ptr w = (line_ptr)a0;
+            int acc = 0;
+            for (int l0 = 0; l0 < lines; l0 += 16) {
+                int t[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const int l = l0 + u < lines ? l0 + u : lines - 1; t[u] = w[l * 16]; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc |= t[u];
+            }
+            asm volatile("" : : "s"(acc));
+        }
+        PROBE(32);
         for (int j = 0; j < Tu; j++) {
+            if (j < 8) PROBE(33 + j);
             gate_ptr G = gb + j * kGateRec;
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
@@ -765,6 +803,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     //      clutter in which no point can be a core point; for most scenes an O(U) cell count proves it
     //      (cloud_cells_prove_no_core, mmw_cloud.hpp) on the rows this workgroup has just appended, and the scene is
     //      finished with all labels -1.  The others go to the work lists of k_post / k_dbscan_big. ----
+    PROBE(8);
     lds_barrier();
     const int Udb = L.misc[2];
     if (Udb > 0) {  // uniform
@@ -826,6 +865,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);
     }
     if (tid == 0 && upd_pos >= 0) st.upd_list[((size_t)parity * (cfg.t_cap + 1) + T) * cfg.n_scenes + upd_pos] = s;
+    WGTIME(1);
 }
 
 template <int PPT>

@@ -12,6 +12,7 @@
 
 #include "mmw_device.hpp"
 #include "mmw_launch.hpp"
+#include "mmw_kalman.hpp"
 
 namespace mmw {
 thread_local LaunchProf g_launch_prof;
@@ -22,6 +23,10 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
                  int32_t *db_n, hipStream_t stream);
 void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side);
 void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+                  int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
+size_t scene_lds_bytes(const DevCfg &c);
+hipError_t prepare_scene(const DevCfg &cfg);
+void launch_scene(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
 size_t dbscan_only_lds_bytes(int UM);
@@ -71,6 +76,7 @@ struct mmw_ctx {
     hipStream_t side_stream = nullptr;   // k_chain beside k_track (contexts with dc.side_worker)
     hipEvent_t side_gate = nullptr;      // recorded on the context's stream at the head of a step: k_chain does not start before it
     int side_wanted = 0;                 // what the configuration / mmw_set_chain_side_stream asked for
+    int fused_wanted = 0;                // the one-workgroup step (k_scene) is what this context runs unless a ring was resized or the side workers were asked for
     int side_probed = 0;                 // the side streams have been checked against the current context stream (probe_side_streams)
     int32_t *d_probe = nullptr;          // [4] flag + results of that check
     int epoch = 0;                       // step number (queue protocol of list 3, k_dbscan.hip)
@@ -189,7 +195,7 @@ int mmw_config_default(mmw_config *c)
     memset(c, 0, sizeof(*c));
     c->fb_frames_batch = 2; c->db_min_samples = 35; c->tr_max_tracks = 4; c->kf_enable_est = 0;
     c->model_min_input = 0; c->dim_x = 9; c->ring_rows = 64; c->track_cap = 0; c->kalman_dense_min_units = 0;
-    c->seek_inner = 0; c->chain_side_stream = 0; c->db_points_thres = 40; c->fb_frames_batch_static = 2; c->db_spread_thres = 0.7; c->db_inner_eps = 0.1;
+    c->seek_inner = 0; c->chain_side_stream = 0; c->fused_step = 0; c->db_points_thres = 40; c->fb_frames_batch_static = 2; c->db_spread_thres = 0.7; c->db_inner_eps = 0.1;
     c->m_x = 0.32; c->m_y = -0.6; c->m_z = 1.3;
     c->v_screen_fade_size_max = 0.3; c->v_screen_fade_size_min = 0.2; c->v_screen_fade_weight = 0.08;
     c->db_z_weight = 0.4; c->db_range_weight = 0.03; c->db_eps = 0.3;
@@ -277,6 +283,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     // the BallTree chain workers beside k_track on a second stream: for contexts large enough that k_track is a long launch
     // (a small context's whole step is shorter than a chain), and not with seek_inner (k_inner may cancel queued scenes)
     d.side_worker = (!d.seek_inner && (cfg->chain_side_stream > 0 || (cfg->chain_side_stream == 0 && n_scenes >= 1536))) ? 1 : 0;
+    d.fused = 0;   // (decided below, once the track capacity is known)
     if (d.seek_inner) {
         // seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
         // ring*max_pts rows: frames are stored whole.  A ring of size 0 would never leave add_frame's loop (Tracking.py:47-48).
@@ -309,6 +316,22 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.m_x = cfg->m_x; d.m_y = cfg->m_y; d.m_z = cfg->m_z;
     d.fade_max = cfg->v_screen_fade_size_max; d.fade_min = cfg->v_screen_fade_size_min; d.fade_weight = cfg->v_screen_fade_weight;
     c->UM = ring * max_pts;
+    {
+        // The one-workgroup step (k_scene.hip): a scene's whole track() in one workgroup, for contexts whose scenes are all
+        // resident at once, two workgroups per CU -- there a step is one scene's latency, and one launch boundary less is
+        // what pays: measured on one box, 512 scenes x 512 points x 8 tracks 0.0617 -> 0.0588 ms per step; at 256 scenes
+        // (one workgroup per CU either way) the two-launch step wins, 0.0448 against 0.0477 ms -- the update is 7 us of chain
+        // inside k_scene and 4 us over k_post's floor as a batched launch.  Hence "automatic" = more than one workgroup per CU
+        // and all of them resident.  Not with seek_inner (k_inner sits between association and update), the side-stream
+        // workers (they claim scenes while the association kernel runs) or more than 63 tracks per scene (a lane per track in
+        // its maintenance step).
+        const size_t sl = scene_lds_bytes(d);
+        const int per_cu = sl <= 80 * 1024 ? 2 : (sl <= 160 * 1024 ? 1 : 0);
+        const bool can = per_cu > 0 && !d.seek_inner && d.t_cap <= 63 && cfg->chain_side_stream <= 0;
+        const bool want = cfg->fused_step > 0 || (cfg->fused_step == 0 && cfg->kalman_dense_min_units == 0 && per_cu == 2 && n_scenes > 256 && n_scenes <= 512);
+        c->fused_wanted = d.fused = (can && want) ? 1 : 0;
+        if (d.fused) { d.dense_min_units = 0x7fffffff; d.side_worker = 0; }
+    }
 
 #define ALLOC(ptr, bytes)                                                                                   \
     do {                                                                                                    \
@@ -323,7 +346,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->st.g_ring, S * (size_t)ring * max_pts * 8 * sizeof(double));
     ALLOC(c->d_posture, MMW_NKP * sizeof(float));
     ALLOC(c->d_row_off, (S + 1) * sizeof(int32_t));
-    ALLOC(c->d_stats, ((size_t)kStatSlots * kStatWords + 128) * sizeof(unsigned long long));  // + probe words of the diagnostic build
+    ALLOC(c->d_stats, ((size_t)kStatSlots * kStatWords + 256 + 8192) * sizeof(unsigned long long));  // + probe words, workgroup times of the diagnostic build
     ALLOC(c->d_db_list, 4 * S * sizeof(int32_t));
     ALLOC(c->d_db_count, 8 * sizeof(int32_t));
     ALLOC(c->d_q, kQWords * sizeof(int32_t));
@@ -372,6 +395,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         if (hipMemset(c->st.inner_buf, 0, S * (size_t)(kInnerHdr + c->st.inner_cap) * sizeof(int32_t)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     }
     hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap, cfg->db_min_samples);
+    if (e1 == hipSuccess && scene_lds_bytes(d) <= 160 * 1024) e1 = prepare_scene(d);
     if (e1 != hipSuccess || e2 != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
     launch_reset(d, c->st, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "reset kernel failed: %s", hipGetErrorString(hipGetLastError())); }
@@ -405,6 +429,7 @@ int mmw_reset(mmw_ctx *c)
     launch_reset(c->dc, c->st, c->stream);
     HIPCHK(c, hipGetLastError());
     c->dc.var_ring = 0;   // fresh BatchedData objects: default sizes again
+    c->dc.fused = (c->fused_wanted && !c->dc.side_worker) ? 1 : 0;
     c->ring_frames_bound = 0;
     return MMW_OK;
 }
@@ -441,6 +466,7 @@ int mmw_set_batch_size(mmw_ctx *c, const int32_t *scene_flags, int32_t new_size)
     HIPCHK(c, hipGetLastError());
     if (scene_flags) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dc.var_ring = 1;
+    c->dc.fused = 0;   // resized rings are k_track's (its INNER instantiations read the sizes per ring); the state layout is the same
     return MMW_OK;
 }
 
@@ -469,6 +495,7 @@ int mmw_set_chain_side_stream(mmw_ctx *c, int32_t on)
     if (on && c->dc.seek_inner) return fail(c, MMW_E_ARG, "mmw_set_chain_side_stream: not with seek_inner (k_inner may cancel queued scenes)");
     if (on && !c->side_stream) HIPCHK(c, create_side_streams(c));
     c->dc.side_worker = c->side_wanted = on ? 1 : 0;   // takes effect with the next mmw_step (the queues are empty between steps)
+    c->dc.fused = (c->fused_wanted && !on && !c->dc.var_ring) ? 1 : 0;   // the workers claim scenes while k_track runs: the bulk kernels' step
     c->side_probed = 0;
     return MMW_OK;
 }
@@ -580,7 +607,8 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     launch_predict(c->dc, c->st, n_pts, dt, c->step_parity, c->stream);
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_TRACK, ep);
-    launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
+    if (c->dc.fused) launch_scene(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
+    else launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
     prof_armed_done(c, ep);
     if (c->dc.seek_inner) launch_inner(c->dc, c->st, n_pts, db_n, c->stream);  // Tracking.py:656 active
     prof_arm(c, MMW_K_POST, ep);
@@ -953,10 +981,10 @@ int mmw_stats_get_ext(mmw_ctx *c, uint64_t *out)
     return read_stats(c, out, kStatWords);
 }
 #ifdef MMW_STAMPS
-int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[128]*/)
+int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[256 + 8192]*/)
 {
     if (!c || !out) return MMW_E_ARG;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_stats + (size_t)kStatSlots * kStatWords, 128 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_stats + (size_t)kStatSlots * kStatWords, (256 + 8192) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
 }
@@ -965,6 +993,11 @@ int mmw_side_workers(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
     return c->dc.side_worker ? (c->side_probed ? 1 : 2) : 0;
+}
+int mmw_step_kind(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    return c->dc.fused ? 1 : (pred_in_track(c->dc) ? 2 : 4);
 }
 int mmw_diag_queue(mmw_ctx *c, int32_t *out /*[32]*/)
 {

@@ -207,12 +207,13 @@ __device__ __forceinline__ bool cloud_cells_prove_no_core_rows(const DevCfg &cfg
     return *flag == 0;
 }
 
-// Stage 2, O(U^2): the exact superset count over all pairs, for the clouds stage 1 left undecided (k_post),
-// read from the scene's global ring.  P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.  NT = threads of
+// Stage 2, O(U^2): the exact superset count over all pairs, for the clouds stage 1 left undecided (k_post: rows read from
+// the scene's global ring; k_scene: from the registers that fed stage 1).  P4 [256] float4, cnt [256] ints, mm [3] u64, flag [1] are LDS scratch.  NT = threads of
 // the workgroup (256 in k_post, 512 in k_chain); the count -- and with it the answer -- does not depend on it.
+// (px, py, pz) = point `tid` of the cloud (threads tid >= U pass anything).
 template <int NT = 256>
-__device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
-                                                          unsigned long long *mm, int *flag)
+__device__ __forceinline__ bool cloud_pairs_prove_no_core_xyz(const DevCfg &cfg, int U, double px, double py, double pz, float4 *P4, int *cnt,
+                                                              unsigned long long *mm, int *flag)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const double rw = cfg.db_range_weight, zw = cfg.db_z_weight, eps = cfg.db_eps;
@@ -221,12 +222,10 @@ __device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, con
     const double sqzw = sqrt(zw);
     double y = 0.0, mag = 0.0;
     if (tid < U) {
-        const double *r = src.row(tid);
-        const double2 a = *reinterpret_cast<const double2 *>(r);
-        const double zs = r[2] * sqzw;
-        y = a.y;
-        P4[tid] = make_float4((float)a.x, (float)a.y, (float)zs, 0.f);
-        mag = fmax(fmax(fabs(a.x), fabs(a.y)), fabs(zs));
+        const double zs = pz * sqzw;
+        y = py;
+        P4[tid] = make_float4((float)px, (float)py, (float)zs, 0.f);
+        mag = fmax(fmax(fabs(px), fabs(py)), fabs(zs));
         if (!(mag <= 1e15)) mag = __longlong_as_double(0x7ff0000000000000LL);  // NaN/inf/huge: give up below
         cnt[tid] = 0;
     }
@@ -272,6 +271,19 @@ __device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, con
     if (tid < U && cnt[tid] >= min_samples) *flag = 1;
     lds_barrier();
     return *flag == 0;
+}
+// ... with the rows read from the scene's global ring
+template <int NT = 256>
+__device__ __forceinline__ bool cloud_pairs_prove_no_core(const DevCfg &cfg, const RowSrc src, int U, float4 *P4, int *cnt,
+                                                          unsigned long long *mm, int *flag)
+{
+    double px = 0.0, py = 0.0, pz = 0.0;
+    if ((int)threadIdx.x < U) {
+        const double *r = src.row(threadIdx.x);
+        const double2 a = *reinterpret_cast<const double2 *>(r);
+        px = a.x; py = a.y; pz = r[2];
+    }
+    return cloud_pairs_prove_no_core_xyz<NT>(cfg, U, px, py, pz, P4, cnt, mm, flag);
 }
 
 }  // namespace mmw

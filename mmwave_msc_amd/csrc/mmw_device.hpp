@@ -35,6 +35,7 @@ struct DevCfg {
     int32_t seek_inner;       // Tracking.py:656 active: seek_inner_clusters after every associate_pointcloud (k_inner)
     int32_t db_points_thres, fb_frames_batch_static;
     int32_t big_live;        // this step's large clouds may be claimed WHILE k_track runs (side workers on, start-up frames over): they are pushed with a release; otherwise plainly, for the kernels behind k_track
+    int32_t fused;           // the step is k_scene (one workgroup runs a scene's whole track(): k_scene.hip) + the worker blocks of k_post: contexts whose scenes are all resident at once
     int32_t var_ring, side_worker;   // side_worker: k_chain runs beside k_track on a second stream (mmw_api.hip); var_ring: a global ring size was changed (mmw_set_batch_size): k_track reads ring sizes from the headers
     double db_spread_thres, db_inner_eps;
     double db_z_weight, db_range_weight, db_eps;

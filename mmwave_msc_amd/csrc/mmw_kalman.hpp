@@ -20,75 +20,97 @@ constexpr int kRecStage = 160;  // words actually copied: ten per lane of a 16-l
 static_assert(kRecStage >= kRecRaw && kRecStage * 8 <= (int)sizeof(TrackRec), "staged prefix");
 
 // per-track LDS scratch (doubles)
-constexpr int pA = kRecStage, pXn = pA + 81, pS = pXn + 9, kPredScratch = pS + 2;
-constexpr int uA = kRecStage, uK = uA + 81, uSI = uK + 54, uC1 = uSI /* C1 replaces S^-1 once K is formed */, uY = uSI + 54, uRc = uY + 6,
-              kUpdScratch = uRc + 36;
+constexpr int kPredScratch = kRecStage + 81 + 9 + 2;           // staged record | predict_math's scratch (kPredW)
+constexpr int kUpdScratch = kRecStage + 81 + 54 + 54 + 6 + 36;   // staged record | update_math's scratch (kUpdW)
 
 // All 64 lanes load and store unconditionally (the caller points idle groups at a valid record; nothing of
 // theirs is stored later): ten loads, ten LDS stores, no branches.  The copy is 160 words, i.e. it runs a little
-// into the record's ring bookkeeping -- inside the 187-word record, never read from the copy.
-__device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int c)
+// into the record's ring bookkeeping -- inside the 187-word record: ring_len / uid, ring_n[], ring_slot[] sit in words
+// 153..157 (k_scene reads them from the copy).  LP = lanes that own one track (16: four tracks per wave, the batched
+// Kalman kernels; 32 / 64: the per-scene kernel k_scene, whose step is one track's latency), c = lane % LP.
+template <int LP>
+struct StageRegs { double t[(kRecStage + LP - 1) / LP]; };
+// (the two halves apart: k_scene puts the frame's point loads between them -- requested behind the records, not in front)
+template <int LP>
+__device__ __forceinline__ void stage_record_load(const TrackRec *rec, int c, StageRegs<LP> &S)
 {
     const double *src = reinterpret_cast<const double *>(rec);
-    double t[10];
+    constexpr int NU = (kRecStage + LP - 1) / LP;
+    constexpr bool exact = NU * LP == kRecStage;
 #pragma unroll
-    for (int u = 0; u < 10; u++) t[u] = src[c + 16 * u];
+    for (int u = 0; u < NU; u++) { const int w = c + LP * u; S.t[u] = src[(exact || w < kRecStage) ? w : kRecStage - 1]; }
+}
+template <int LP>
+__device__ __forceinline__ void stage_record_store(double *R, int c, const StageRegs<LP> &S)
+{
+    constexpr int NU = (kRecStage + LP - 1) / LP;
+    constexpr bool exact = NU * LP == kRecStage;
 #pragma unroll
-    for (int u = 0; u < 10; u++) R[c + 16 * u] = t[u];
+    for (int u = 0; u < NU; u++) { const int w = c + LP * u; if (exact || w < kRecStage) R[w] = S.t[u]; }
+}
+template <int LP = 16>
+__device__ __forceinline__ void stage_record(const TrackRec *rec, double *R, int c)
+{
+    StageRegs<LP> S;
+    stage_record_load<LP>(rec, c, S);
+    stage_record_store<LP>(R, c, S);
 }
 
-// One Kalman update (update_state, Tracking.py:387-398; _get_Rc 299-312; filterpy's Joseph-form update) per 16-lane
-// group: `rec` = the group's track record (idle groups: any valid record, `live` false -- they compute and store
-// nothing that matters), `Wj` = the group's kUpdScratch doubles.  All 64 lanes of the wave must call.
-template <int DX>
-__device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, double *Wj, int lane, int c, int &err)
+// One Kalman update (update_state, Tracking.py:387-398; _get_Rc 299-312; filterpy's Joseph-form update) for the track
+// whose record prefix is staged at `R` (LDS, kRecStage words), by the LP lanes that own it (c = lane % LP): the products
+// are laid out over elements, so more lanes only shorten the loops -- the arithmetic per element is the same.  `W` = the
+// track's scratch (kUpdW doubles), `rec` = where x and P go.  Idle groups (`live` false) compute and store nothing that
+// matters.  All 64 lanes of the wave must call (the 6x6 inverse runs in the first 16 lanes of every group).
+constexpr int wA = 0, wK = wA + 81, wSI = wK + 54, wC1 = wSI /* C1 replaces S^-1 once K is formed */, wY = wSI + 54, wRc = wY + 6,
+              kUpdW = wRc + 36;
+template <int DX, int LP>
+__device__ __forceinline__ void update_math(TrackRec *rec, bool live, const double *R, double *W, int lane, int c, int &err)
 {
-    stage_record(rec, Wj, c);
-    wave_sync();
-    const double *Pw = Wj + rP;
+    const double *Pw = R + rP;
     // Rc = Rm/N + ((N_est-N)/((N_est-1)N)) gd ; S = H P H^T + Rc ; SI = S^-1
     {
         const bool valid = live && c < 6;
+        const int c16 = lane & 15;
         double v[6], det;
 #pragma unroll
-        for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;
+        for (int i = 0; i < 6; i++) v[i] = (c16 == i) ? 1.0 : 0.0;
         if (valid) {
-            const double N = (double)reinterpret_cast<const int32_t *>(Wj + rInts)[0], nest = Wj[rNest];
+            const double N = (double)reinterpret_cast<const int32_t *>(R + rInts)[0], nest = R[rNest];
             const double den = (nest - 1) * N;
             if (den == 0.0) err |= ERR_DIVZERO;
             const double coef = (nest - N) / den;
-            const double hh = Wj[rSpr + c] / 2;
+            const double hh = R[rSpr + c] / 2;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * Wj[rGd + i * 6 + c];
-                Wj[uRc + i * 6 + c] = rc;
+                const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * R[rGd + i * 6 + c];
+                W[wRc + i * 6 + c] = rc;
                 v[i] = Pw[i * 9 + c] + rc;  // S = H P H^T + R
             }
-            Wj[uY + c] = Wj[rCen + c] - Wj[rX + c];  // y = z - H x
+            W[wY + c] = R[rCen + c] - R[rX + c];  // y = z - H x
         }
         const bool ok = lu6_inverse_cols(v, lane, det);
-        if (live) {
+        if (live && c < 16) {
             if (!ok) err |= ERR_SINGULAR;
             if (c >= 6 && c < 12) {
 #pragma unroll
-                for (int r = 0; r < 6; r++) Wj[uSI + r * 6 + c - 6] = v[r];
+                for (int r = 0; r < 6; r++) W[wSI + r * 6 + c - 6] = v[r];
             }
         }
     }
     wave_sync();
     if (live) {
-        for (int k = c; k < DX * 6; k += 16) {  // K = P H^T S^-1
+        for (int k = c; k < DX * 6; k += LP) {  // K = P H^T S^-1
             const int i = k / 6, cc = k - i * 6;
-            double a = Pw[i * 9] * Wj[uSI + cc];
+            double a = Pw[i * 9] * W[wSI + cc];
 #pragma unroll
-            for (int m = 1; m < 6; m++) a += Pw[i * 9 + m] * Wj[uSI + m * 6 + cc];
-            Wj[uK + k] = a;
+            for (int m = 1; m < 6; m++) a += Pw[i * 9 + m] * W[wSI + m * 6 + cc];
+            W[wK + k] = a;
         }
     }
     wave_sync();
     if (live) {
-        const double *Kw = Wj + uK, *yw = Wj + uY, *Rcw = Wj + uRc;
-        for (int k = c; k < 81; k += 16) {  // A = (I - K H) P
+        const double *Kw = W + wK, *yw = W + wY, *Rcw = W + wRc;
+        for (int k = c; k < 81; k += LP) {  // A = (I - K H) P
             const int i = k / 9, cc = k - i * 9;
             if (i < DX && cc < DX) {
                 double a = 0.0;
@@ -98,24 +120,25 @@ __device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, doubl
                     const double ikh = m < 6 ? d - Kw[i * 6 + m] : d;
                     a = (m == 0) ? ikh * Pw[cc] : a + ikh * Pw[m * 9 + cc];
                 }
-                Wj[uA + k] = a;
+                W[wA + k] = a;
             }
         }
         if (c < DX) {  // x = x + K y
             double a = Kw[c * 6] * yw[0];
 #pragma unroll
             for (int m = 1; m < 6; m++) a += Kw[c * 6 + m] * yw[m];
-            double xnew = Wj[rX + c] + a;
+            double xnew = R[rX + c] + a;
             if (c == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
-                const double var = Wj[rCen] - xnew;
-                if (!(var == 0.0) && Wj[rLife] == 0.0) xnew += var * 0.4;
+                const double var = R[rCen] - xnew;
+                if (!(var == 0.0) && R[rLife] == 0.0) xnew += var * 0.4;
             }
             rec->x[c] = xnew;
         }
-        double c1[4];  // C1 = K R, into the S^-1 area: every lane forms its entries first, then they are stored
+        constexpr int NC = (54 + LP - 1) / LP;
+        double c1[NC];  // C1 = K R, into the S^-1 area: every lane forms its entries first, then they are stored
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int k = c + 16 * u;
+        for (int u = 0; u < NC; u++) {
+            const int k = c + LP * u;
             c1[u] = 0.0;
             if (k < DX * 6) {
                 const int i = k / 6, cc = k - i * 6;
@@ -126,12 +149,12 @@ __device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, doubl
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int k = c + 16 * u; if (k < DX * 6) Wj[uC1 + k] = c1[u]; }
+        for (int u = 0; u < NC; u++) { const int k = c + LP * u; if (k < DX * 6) W[wC1 + k] = c1[u]; }
     }
     wave_sync();
     if (live) {
-        const double *Aw = Wj + uA, *Kw = Wj + uK, *C1w = Wj + uC1;
-        for (int k = c; k < 81; k += 16) {  // P = A (I-KH)^T + C1 K^T
+        const double *Aw = W + wA, *Kw = W + wK, *C1w = W + wC1;
+        for (int k = c; k < 81; k += LP) {  // P = A (I-KH)^T + C1 K^T
             const int i = k / 9, cc = k - i * 9;
             if (i < DX && cc < DX) {
                 double b = 0.0;
@@ -151,45 +174,55 @@ __device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, doubl
     wave_sync();
 }
 
-// _predict_all for ONE track per 16-lane group (predict_state, Tracking.py:372-385: filterpy predict with the motion
-// model of constants.py:195-215) + the gate matrix of _calc_dist_fun (Tracking.py:549-560) into gate_buf[s][j].
-// Idle groups (`live` false) point at any valid record and store nothing.  All 64 lanes of the wave must call.
+// ... for a record that is still in global memory (the batched kernels): `rec` = the group's track record (idle groups:
+// any valid record), `Wj` = the group's kUpdScratch doubles = [staged record | scratch].
 template <int DX>
-__device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
-                                                  double *Wj, int lane, int c, int &err)
+__device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, double *Wj, int lane, int c, int &err)
 {
-    stage_record(rec, Wj, c);
+    stage_record<16>(rec, Wj, c);
     wave_sync();
-    const double dtm = Wj[rLife] + dt;
+    update_math<DX, 16>(rec, live, Wj, Wj + kRecStage, lane, c, err);
+}
+
+// _predict_all for ONE track per LP-lane group (predict_state, Tracking.py:372-385: filterpy predict with the motion
+// model of constants.py:195-215) + the gate matrix of _calc_dist_fun (Tracking.py:549-560) into `G` (the track's record in
+// gate_buf), on the record prefix staged at `R` (LDS; x and P are replaced by the predicted ones there, and in `rec` when
+// STORE), scratch `W` (kPredW doubles).  Idle groups (`live` false) store nothing.  All 64 lanes of the wave must call.
+constexpr int wPA = 0, wXn = wPA + 81, kPredW = wXn + 9 + 2;
+template <int DX, int LP, bool STORE>
+__device__ __forceinline__ void predict_math(const DevCfg &cfg, TrackRec *rec, double *G, bool live, double dt, double *R, double *W, int lane,
+                                             int c, int &err)
+{
+    const double dtm = R[rLife] + dt;
     const double h = 0.5 * (dtm * dtm);
     if (live) {
-        for (int k = c; k < 81; k += 16) {
+        for (int k = c; k < 81; k += LP) {
             // A = F P.  F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense
             // dot product reduces to these terms (the others are exact zeros).
             const int i = k / 9, cc = k - i * 9;
             if (i < DX && cc < DX) {
-                double a = Wj[rP + k];
-                if (i + 3 < DX) a += dtm * Wj[rP + (i + 3) * 9 + cc];
-                if (i + 6 < DX) a += h * Wj[rP + (i + 6) * 9 + cc];
-                Wj[pA + k] = a;
+                double a = R[rP + k];
+                if (i + 3 < DX) a += dtm * R[rP + (i + 3) * 9 + cc];
+                if (i + 6 < DX) a += h * R[rP + (i + 6) * 9 + cc];
+                W[wPA + k] = a;
             }
         }
         if (c < DX) {
-            double xn = Wj[rX + c];
-            if (c + 3 < DX) xn += dtm * Wj[rX + c + 3];
-            if (c + 6 < DX) xn += h * Wj[rX + c + 6];
-            Wj[pXn + c] = xn;
+            double xn = R[rX + c];
+            if (c + 3 < DX) xn += dtm * R[rX + c + 3];
+            if (c + 6 < DX) xn += h * R[rX + c + 6];
+            W[wXn + c] = xn;
         }
     }
     wave_sync();
     if (live) {
         const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
-        for (int k = c; k < 81; k += 16) {
+        for (int k = c; k < 81; k += LP) {
             const int i = k / 9, cc = k - i * 9;
             if (i < DX && cc < DX) {
-                double b = Wj[pA + k];  // B = A F^T
-                if (cc + 3 < DX) b += Wj[pA + i * 9 + cc + 3] * dtm;
-                if (cc + 6 < DX) b += Wj[pA + i * 9 + cc + 6] * h;
+                double b = W[wPA + k];  // B = A F^T
+                if (cc + 3 < DX) b += W[wPA + i * 9 + cc + 3] * dtm;
+                if (cc + 6 < DX) b += W[wPA + i * 9 + cc + 6] * h;
                 double qn = 0.0;
                 if (i / 3 == cc / 3) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
                     const int qi = i % 3, qc = cc % 3, sdeg = qi + qc;
@@ -198,37 +231,48 @@ __device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevSt
                     qn = base * cfg.kf_q_std;
                 }
                 const double pn = b + qn;
-                rec->P[k] = pn;
-                Wj[rP + k] = pn;
+                if (STORE) rec->P[k] = pn;
+                R[rP + k] = pn;
             }
         }
-        if (c < DX) { const double xn = Wj[pXn + c]; rec->x[c] = xn; Wj[rX + c] = xn; }
+        if (c < DX) { const double xn = W[wXn + c]; if (STORE) rec->x[c] = xn; R[rX + c] = xn; }
     }
     wave_sync();
     // gate matrix: lane c < 6 of the group holds column c of C = P[:6,:6] + diag((spread/2)^2) + group_disp_est
     {
         const bool valid = live && c < 6;
+        const int c16 = lane & 15;
         double v[6], det;
 #pragma unroll
-        for (int i = 0; i < 6; i++) v[i] = (c == i) ? 1.0 : 0.0;  // idle groups: identity
+        for (int i = 0; i < 6; i++) v[i] = (c16 == i) ? 1.0 : 0.0;  // idle groups: identity
         if (valid) {
-            const double hh = Wj[rSpr + c] / 2;
+            const double hh = R[rSpr + c] / 2;
 #pragma unroll
-            for (int i = 0; i < 6; i++) v[i] = (Wj[rP + i * 9 + c] + ((i == c) ? hh * hh : 0.0)) + Wj[rGd + i * 6 + c];
+            for (int i = 0; i < 6; i++) v[i] = (R[rP + i * 9 + c] + ((i == c) ? hh * hh : 0.0)) + R[rGd + i * 6 + c];
         }
         const bool ok = lu6_inverse_cols(v, lane, det);
-        if (live) {
+        if (live && c < 16) {
             if (!ok) err |= ERR_SINGULAR;
-            double *G = st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec;  // by effective_tracks position
             if (c >= 6 && c < 12) {
 #pragma unroll
                 for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
             }
             if (c == 0) G[36] = dlog(fabs(det));
-            if (c < 6) G[37 + c] = Wj[rX + c];
+            if (c < 6) G[37 + c] = R[rX + c];
         }
     }
     wave_sync();
+}
+
+// ... for a record that is still in global memory: `Wj` = the group's kPredScratch doubles = [staged record | scratch];
+// the gate record goes to gate_buf[s][j] (by effective_tracks position).
+template <int DX>
+__device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
+                                                  double *Wj, int lane, int c, int &err)
+{
+    stage_record<16>(rec, Wj, c);
+    wave_sync();
+    predict_math<DX, 16, true>(cfg, rec, st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec, live, dt, Wj, Wj + kRecStage, lane, c, err);
 }
 
 // When the track-wise layout is used: it needs one lane per bin (t_cap <= 63), and it only pays when there are more
@@ -243,7 +287,7 @@ __host__ __device__ inline bool pred_in_track(const DevCfg &cfg)
 {
     int nq = (cfg.tr_max_tracks + 3) / 4;
     if (nq < 1) nq = 1;
-    return cfg.n_scenes <= kSmallContextScenes && !tracks_dense(cfg, nq) && !cfg.seek_inner;
+    return cfg.n_scenes <= kSmallContextScenes && !tracks_dense(cfg, nq) && !cfg.seek_inner && !cfg.fused;
 }
 
 // _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of the list

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 from mmwave_msc_amd import _lib  # noqa: E402
 from mmwave_msc_amd.batch import SceneBatch  # noqa: E402
 
-S, N, T, F = 4096, 512, 8, 60
+S, N, T, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 512, 8, 60
 pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=16)
 sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
 bp = sb.alloc(S * N * 64); bn = sb.alloc(S * 4); bd = sb.alloc(S * 8)

@@ -15,20 +15,23 @@ from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_
 pytestmark = pytest.mark.gpu
 
 
-_LAYOUT = {"value": 0, "side": 0}
+_LAYOUT = {"value": 0, "side": 0, "fused": 0}
 
 
-@pytest.fixture(params=["per_scene", "track_wise", "track_wise+side_stream"], autouse=True)
+@pytest.fixture(params=["per_scene", "track_wise", "track_wise+side_stream", "one_workgroup"], autouse=True)
 def kalman_layout(request):
     """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense: by default the
     track-wise one is only chosen for contexts with more than 1024 four-track waves, mmw_config.kalman_dense_min_units), and
     a third time with the small-cloud DBSCAN workers on the side stream (k_chain beside k_track, mmw_config.chain_side_stream:
-    by default only for contexts of >= 1536 scenes)."""
-    _LAYOUT["value"] = -1 if request.param == "per_scene" else 1
-    _LAYOUT["side"] = 1 if request.param.endswith("side_stream") else -1
+    by default only for contexts of >= 1536 scenes), and a fourth time with the one-workgroup step (k_scene.hip,
+    mmw_config.fused_step: by default only for contexts of 257..512 scenes)."""
+    _LAYOUT["value"] = {"per_scene": -1, "one_workgroup": 0}.get(request.param, 1)
+    _LAYOUT["side"] = 1 if request.param.endswith("side_stream") else (0 if request.param == "one_workgroup" else -1)
+    _LAYOUT["fused"] = 1 if request.param == "one_workgroup" else -1
     yield
     _LAYOUT["value"] = 0
     _LAYOUT["side"] = 0
+    _LAYOUT["fused"] = 0
 
 
 def _mk(n_scenes, max_pts, **kw):
@@ -36,6 +39,7 @@ def _mk(n_scenes, max_pts, **kw):
     from mmwave_msc_amd.batch import SceneBatch
     kw.setdefault("kalman_dense_min_units", _LAYOUT["value"])
     kw.setdefault("chain_side_stream", _LAYOUT["side"])
+    kw.setdefault("fused_step", _LAYOUT["fused"])
     return SceneBatch(_lib.default_config(**kw), n_scenes, max_pts)
 
 
