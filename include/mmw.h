@@ -291,13 +291,20 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
  * measured closer to the fp64 oracle than the fp32 kernel above.  frames = 3: define_CNN_3D's Conv3D pair
  * (train.py:73-82), feat[n][3][8][8][5], kernels (kd,kh,kw,in,out); frames = 1: define_CNN's Conv2D pair
  * (train.py:35-44), feat[n][8][8][5], kernels (kh,kw,in,out).  The activation leaves the kernel already split, for a
- * Dense-1 of the same form:  out16[n][2][frames * 2048] fp16 = [hi | lo'] in Keras' Flatten order. */
+ * Dense-1 of the same form: out16[n][ld_out] fp16, ld_out >= 2 * frames * 2048; value j of Keras' Flatten order has its
+ * hi half at (j / 32) * 64 + j % 32 and its lo' half 32 further -- runs of [hi 32 | lo' 32], one 128-byte line per
+ * 32-deep step of Dense-1.  The split is exact inside fp16's range only: range_flag (device pointer, may be NULL) gets
+ * bit 0 set when an input or an activation of magnitude >= 65 504 (or a non-finite input) was split -- that sample's
+ * outputs are then meaningless, where Keras' fp32 would have been finite; nothing clears it but the caller. */
 int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
-                        const float *b2, void *out16, int32_t n);
-/* Dense-1 of the split form (train.py:49 / :87: Dense + ReLU) as two partial GEMMs that run side by side on two streams:
- * g1 = bias + hi.W_hi, g2 = [hi | lo'].[W_lo' ; W_hi]; this merges them, g1[i] = max(g1[i] + scale * g2[i], 0) with
- * scale = 2^-11.  n = number of floats (a multiple of 4), both pointers 16-byte aligned. */
-int mmw_mars_add_scaled_relu(void *hip_stream, float *g1, const float *g2, float scale, int64_t n);
+                        const float *b2, void *out16, int64_t ld_out, int32_t n, int32_t *range_flag);
+/* Dense-1 of the MARS CNN (train.py:49,87: Dense(512 k, relu); BatchNormalization folded in) on split-fp16 operands, one
+ * kernel: out = relu(bias + hi . W_hi + 2^-11 (hi . W_lo' + lo' . W_hi)), fp32 accumulation and output (k_dense.hip).
+ * a2 [rows_padded][lda] fp16 as mmw_mars_conv_split writes it; w2 [n][ldw] fp16 = the transposed weights (K contiguous)
+ * split and interleaved the same way; bias [n], out [rows_padded][n] fp32.  rows_padded is a multiple of 256 (rows past
+ * the batch may hold anything: a row only feeds its own output row), k of 32, n of 128; lda, ldw >= 2 k.  hip_stream as above. */
+int mmw_mars_dense1_split(void *hip_stream, const void *a2, int64_t lda, const void *w2, int64_t ldw, const float *bias, float *out,
+                          int32_t rows_padded, int32_t k, int32_t n);
 
 /* ReadIWR14xx.read (ReadDataIWR1443.py:27-201) on a byte buffer, host only (no context, no GPU work): the input
  * step before mmw_normalize.  Looks for the LAST 8-byte magic word 02 01 04 03 06 05 08 07 in buf[0 .. len-8),

@@ -32,7 +32,7 @@ EXPORTS = [
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
-    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_add_scaled_relu", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind",
+    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind",
 ]
 
 
@@ -176,8 +176,8 @@ def load():
         "mmw_set_chain_side_stream": (C.c_int, [vp, i32]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
         "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),
-        "mmw_mars_conv_split": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, i32]),
-        "mmw_mars_add_scaled_relu": (C.c_int, [vp, vp, vp, C.c_float, C.c_int64]),
+        "mmw_mars_conv_split": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, C.c_int64, i32, vp]),
+        "mmw_mars_dense1_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, i32, i32, i32]),
         "mmw_parse_uart": (C.c_int, [vp, C.c_size_t, vp, vp, vp, i32, vp, vp, vp, vp]),
         "mmw_format_frames": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     }

@@ -1,0 +1,184 @@
+// k_dense.hip -- Dense-1 of the MARS CNN (train.py:49,87: Dense(512 k, relu) on the flattened conv output; 75 % of the CNN's
+// multiply-adds) for the split-fp16 arithmetic of k_mars_conv16, as ONE kernel:
+//
+//     H = relu(bias + hi . W_hi + 2^-11 (hi . W_lo' + lo' . W_hi))
+//
+// with the activation split as the conv kernel leaves it (fp16 halves of every fp32 value, a = hi + 2^-11 lo') and the
+// BN-folded weights split the same way.  Both operands are stored with the halves INTERLEAVED in runs of 32 values,
+// [hi 0..31 | lo' 0..31 | hi 32..63 | lo' 32..63 | ...]: a K-step of 32 is then one 128-byte line per row.  Every partial product of two 11-bit significands is exact in the fp32 accumulator;
+// the dropped lo'.lo' term is 2^-22 relative (mars.py).
+//
+// Why a kernel of our own: as two library GEMMs (hi.W_hi and [hi | lo'].[W_lo' ; W_hi]) the `hi` activations are fetched
+// twice, the two products meet in a separate elementwise pass, and each GEMM is 1.7 waves of 256 x 256 tiles on 256 CUs.
+// Here a K-step stages the four operand tiles ONCE and issues THREE matrix instructions per pair of fragments (main += hi.W_hi,
+// corr += hi.W_lo', corr += lo'.W_hi): 1.5 MFMAs per fragment read from LDS instead of 0.5, half the activation traffic,
+// bias + merge + ReLU in the epilogue.
+//
+// Geometry: workgroup = 512 threads = 8 waves as 4 (M) x 2 (N), tile 256 (batch rows) x 128 (features), K-step 32; a wave owns
+// 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_f16 with TWO accumulator sets (main, corr: 128 VGPRs).  Operand tiles go
+// global -> LDS by the DMA path (global_load_lds, 16 B per lane, no staging registers) into buffers of 48 KB: A (256 rows x
+// 128 B = hi | lo') and W (128 rows x 128 B).  The LDS image of a tile is lane-linear (what the DMA writes), so the bank
+// swizzle is applied to the SOURCE address: 16-byte unit c of row r lives in slot r * 8 + (c ^ ((r >> 1) & 7)) -- the 16 lanes
+// the LDS serves together read 16 different bank groups.  Three such buffers form a ring: one raw barrier per K-step
+// with a counted vmcnt, two tiles' DMA in flight across it.
+// Rows are padded to the tile by the caller (mars.py allocates whole tiles; a pad row only feeds its own output row).
+// What bounds it (measured, 18 304 x 6144 x 1536): not the matrix cores -- with the DMA switched off the loop runs at 1320 TF
+// issued, with the MFMAs switched off the staging alone takes 0.88 of the 1.12 ms: the 8.1 GB a 256 x 128 tile moves from L2
+// to LDS (two accumulator sets cap the tile: 256 x 256 needs 256 accumulator registers per lane at 2 waves per SIMD).  The two
+// library GEMMs move the same bytes and take the same time.  Whole 128-byte lines per row (this layout) and an activation row
+// stride that is not a multiple of 4 KB (mars.py) are worth 6 % and 4 %.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmw {
+
+typedef _Float16 dh8 __attribute__((ext_vector_type(8)));
+typedef float df16 __attribute__((ext_vector_type(16)));
+
+namespace dense {
+constexpr int BM = 256, BN = 128, BK = 32, kThreads = 512;
+constexpr int kRowBytes = BK * 2 * 2;              // 128 B of a tile row: hi (64 B) | lo' (64 B)
+constexpr int kATile = BM * kRowBytes;             // 32 KB
+constexpr int kWTile = BN * kRowBytes;             // 16 KB
+constexpr int kBuf = kATile + kWTile;              // 48 KB per K-step
+constexpr int kStages = 3;                          // LDS ring: the tile in use + two in flight (144 KB)
+constexpr int kLds = kStages * kBuf;
+constexpr float kInvSplit = 1.0f / 2048.0f;
+
+// 16-byte unit (row, c) of a tile image -> byte offset (c = 0..7: the row's eight units, 0..3 = hi, 4..7 = lo')
+__device__ __forceinline__ int unit_off(int row, int c) { return (row * 8 + (c ^ ((row >> 1) & 7))) * 16; }
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0,
+                                     0);
+}
+}  // namespace dense
+
+using namespace dense;
+
+__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
+                                                             long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
+                                                             int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: workgroups are dealt to the eight XCDs round-robin; a group of consecutive LOGICAL tiles (one band of
+    // batch rows against all feature tiles) goes to one XCD, whose L2 then serves the band's activations to every tile of it
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long long m0 = (long long)tm * BM;
+    const int n0 = tn * BN;
+    // ---- this lane's share of a tile's DMA: unit u = chunk * 64 + lane of an operand tile; chunk = one wave instruction ----
+    // A: 32 chunks (8 waves x 4); W: 16 chunks (8 waves x 2).  A K-step advances every source by 64 halves (hi 32 | lo' 32).
+    const _Float16 *srcA[4], *srcW[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = (wave * 4 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+        srcA[i] = a2 + (m0 + row) * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int u = (wave * 2 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+        srcW[i] = w2 + (long long)(n0 + row) * ldw + c * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        char *b = lds + buf * kBuf;
+        const int k0 = kt * (2 * BK);
+#pragma unroll
+        for (int i = 0; i < 4; i++) glds16(srcA[i] + k0, b + (wave * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; i++) glds16(srcW[i] + k0, b + kATile + (wave * 2 + i) * 1024);
+    };
+    // ---- fragment addresses: lane (row = l & 31, k-group g = l >> 5) reads unit c = 2 kk + g (hi) and 4 + 2 kk + g (lo') ----
+    int offA[2][2], offW[2][2];   // [tile][kk]
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            offA[x][kk] = unit_off(wm * 64 + x * 32 + (lane & 31), kk * 2 + (lane >> 5));
+            offW[x][kk] = unit_off(wn * 64 + x * 32 + (lane & 31), kk * 2 + (lane >> 5));
+        }
+    df16 am[2][2], ac[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
+
+    // Three LDS buffers, ONE barrier per K-step: tile kt + 2 is requested into the buffer tile kt - 1 was read from, which every
+    // wave has left once it has passed this step's barrier; two tiles stay in flight behind the one in use (vmcnt(6) retires
+    // tile kt while tile kt + 1 is still landing).  The fragments of the next 16-deep half step are requested before the
+    // twelve MFMAs of the current one.
+    const int KT = K / BK;
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    int cur = 0;
+    for (int kt = 0; kt < KT; kt++) {
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt has landed (this wave's share)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                        // ... everyone's share; buffer of tile kt - 1 is free
+        asm volatile("" ::: "memory");
+        const int nxt2 = cur >= 1 ? cur - 1 : kStages - 1;                   // (cur + 2) % 3
+        if (kt + 2 < KT) issue(kt + 2, nxt2);
+        const char *b = lds + cur * kBuf;
+        dh8 ah[2][2], al[2][2], wh[2][2], wl[2][2];   // [kk][tile]
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                ah[kk][x] = *reinterpret_cast<const dh8 *>(b + offA[x][kk]);
+                wh[kk][x] = *reinterpret_cast<const dh8 *>(b + kATile + offW[x][kk]);
+                wl[kk][x] = *reinterpret_cast<const dh8 *>(b + kATile + (offW[x][kk] ^ 64));
+                al[kk][x] = *reinterpret_cast<const dh8 *>(b + (offA[x][kk] ^ 64));
+            }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int x = 0; x < 2; x++)
+#pragma unroll
+                for (int y = 0; y < 2; y++) {
+                    am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][x], wh[kk][y], am[x][y], 0, 0, 0);
+                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][x], wl[kk][y], ac[x][y], 0, 0, 0);
+                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk][x], wh[kk][y], ac[x][y], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+        cur = cur + 1 == kStages ? 0 : cur + 1;
+    }
+    // ---- epilogue: D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]; a register of the 64 lanes = two rows x 128 B ----
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+        const int col = n0 + wn * 64 + y * 32 + (lane & 31);
+        const float bv = bias[col];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (am[x][y][r] + ac[x][y][r] * kInvSplit) + bv;
+                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);   // relu that keeps NaN (as torch's)
+            }
+        }
+    }
+}
+
+// rows_padded: a multiple of 256; K a multiple of 32; N a multiple of 128
+int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
+                       hipStream_t stream)
+{
+    static bool prepared = false;
+    if (!prepared) {
+        if (hipFuncSetAttribute((const void *)k_mars_dense1, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return -1;
+        prepared = true;
+    }
+    const int tiles_m = rows_padded / BM, tiles_n = N / BN;
+    hipLaunchKernelGGL(k_mars_dense1, dim3(tiles_m * tiles_n), dim3(kThreads), kLds, stream, reinterpret_cast<const _Float16 *>(a2), lda,
+                       reinterpret_cast<const _Float16 *>(w2), ldw, bias, out, K, N, tiles_m, tiles_n);
+    return 0;
+}
+
+}  // namespace mmw

@@ -178,6 +178,20 @@ __device__ __forceinline__ void split16(float a, _Float16 &hi, _Float16 &lo)
     hi = (_Float16)a;
     lo = (_Float16)((a - (float)hi) * kSplitScale);
 }
+// The split holds a value exactly only inside fp16's range (|a| < 65 504; beyond it hi is inf and the sample's keypoints come
+// out inf / NaN or, through a ReLU, as wrong finite numbers): the kernel reports it (range_flag).  Inputs are tested one by
+// one (NaN and inf included); activations -- finite fp32 values as long as the inputs were -- by a running maximum of their
+// magnitudes, one instruction each in epilogues that are VALU-bound.
+__device__ __forceinline__ void split16(float a, _Float16 &hi, _Float16 &lo, bool &over)
+{
+    over |= !(fabsf(a) < 65504.0f);
+    split16(a, hi, lo);
+}
+__device__ __forceinline__ void split16(float a, _Float16 &hi, _Float16 &lo, float &amax)
+{
+    amax = fmaxf(amax, fabsf(a));
+    split16(a, hi, lo);
+}
 
 #ifdef MMW_STAMPS
 __device__ unsigned long long g_conv_stamps[8];
@@ -196,9 +210,12 @@ __device__ unsigned long long g_conv_stamps[8];
 template <int NZ>
 __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict__ feat, const float *__restrict__ w1,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
-                                                        const float *__restrict__ b2, _Float16 *__restrict__ out, int B)
+                                                        const float *__restrict__ b2, _Float16 *__restrict__ out, long long ld_out, int B,
+                                                        int32_t *__restrict__ range_flag)
 {
     using C = Conv16<NZ>;
+    bool over = false;   // an input outside fp16's range was split (range_flag) ...
+    float amax = 0.f;    // ... largest activation magnitude split so far
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- LDS carve-up ----
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
         for (int q = 0; q < PPL; q++) {
             h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < 5; c++) { _Float16 a, l2; split16(xin[q][c], a, l2); hi[c] = a; lo[c] = l2; }
+            for (int c = 0; c < 5; c++) { _Float16 a, l2; split16(xin[q][c], a, l2, over); hi[c] = a; lo[c] = l2; }
             const int pp = C::padded(q * 64 + lane);
             Xhi[pp] = hi; Xlo[pp] = lo;
         }
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                     float v = (am[u][r] + ac[u][r] * (1.0f / kSplitScale)) + bias1[r];
                     v = v > 0.f ? v : 0.f;
                     _Float16 a, l2;
-                    split16(v, a, l2);
+                    split16(v, a, l2, amax);
                     hi[r] = a; lo[r] = l2;
                 }
                 // channels 4g .. 4g+3 of the position: plane g >> 1, half (g & 1) of its 16-byte cell
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
         CSTAMP(2);  // conv1
         // ---- conv2: the two 32-position tiles of a plane at a time (the plane is uniform: taps that read a plane outside
         //      the volume are skipped at compile time); D[oc][pos] ----
-        _Float16 *o = out + (size_t)b * 2 * (C::kPos * 32);
+        _Float16 *o = out + (size_t)b * ld_out;
         const h8 *Hh = Hhi + h2 * CE, *Hl = Hlo + h2 * CE;   // this lane's channel plane
 #pragma unroll
         for (int d = 0; d < NZ; d++) {
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                         float v = (m + c * (1.0f / kSplitScale)) + bias2[qg * 4 + r];
                         v = v > 0.f ? v : 0.f;
                         _Float16 a, l2;
-                        split16(v, a, l2);
+                        split16(v, a, l2, amax);
                         hi[r] = a; lo[r] = l2;
                     }
                     const int oc0 = 8 * qg + 4 * (lane >> 5);
@@ -418,16 +435,22 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // columns 8k .. 8k+7 of the tile are row (2u + (k >> 1) + 4 (k & 1)) of the plane: 512 contiguous bytes of
-                // the output ([pos][oc]) each; 16 bytes per lane and pass, two rows per pass
+                // columns 8k .. 8k+7 of the tile are row (2u + (k >> 1) + 4 (k & 1)) of the plane: eight positions x 32 channels
+                // of the output; a position is one run of the interleaved layout [hi 32 | lo' 32] (k_dense.hip), 16 bytes per
+                // lane and pass, two rows per pass
                 const uint4 *sv = reinterpret_cast<const uint4 *>(stage);
 #pragma unroll
                 for (int ps = 0; ps < 2; ps++) {
                     const int k = ps * 2 + (lane >> 5);
                     const int row = 2 * u + (k >> 1) + 4 * (k & 1);
-                    const size_t e = ((size_t)(d * 64 + row * 8) * 32) + (size_t)(lane & 31) * 8;   // halfs
-                    *reinterpret_cast<uint4 *>(o + e) = sv[ps * 64 + lane];
-                    *reinterpret_cast<uint4 *>(o + C::kPos * 32 + e) = sv[128 + ps * 64 + lane];
+                    // a store instruction writes whole 128-byte lines: for each of its two rows, four positions x [hi 64 B | lo' 64 B]
+                    const int half = (lane >> 2) & 1, chunk = lane & 3;
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int p = i * 4 + ((lane & 31) >> 3);
+                        const size_t e = (size_t)(d * 64 + row * 8 + p) * 64 + half * 32 + chunk * 8;   // halves
+                        *reinterpret_cast<uint4 *>(o + e) = sv[half * 128 + ps * 64 + (lane >> 5) * 32 + p * 4 + chunk];
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -435,6 +458,8 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
             CSTAMP(4);  // conv2 epilogue + stores
         }
     }
+    over |= !(amax < 65504.0f);
+    if (range_flag && __any(over) && lane == 0) atomicOr(range_flag, 1);
 }
 #ifdef MMW_STAMPS
 extern "C" int mmw_diag_conv_stamps(unsigned long long *out /*[8]*/, int reset)
@@ -446,8 +471,8 @@ extern "C" int mmw_diag_conv_stamps(unsigned long long *out /*[8]*/, int reset)
 #endif
 
 template <int NZ>
-static void launch_conv16_t(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
-                            hipStream_t stream)
+static void launch_conv16_t(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
+                            int B, int32_t *range_flag, hipStream_t stream)
 {
     static bool prepared = false;
     if (!prepared) {
@@ -457,39 +482,15 @@ static void launch_conv16_t(const float *feat, const float *w1, const float *b1,
     int grid = (B + 3) / 4;
     if (grid > 256) grid = 256;  // one workgroup of four sample-waves per CU, persistent over samples
     hipLaunchKernelGGL(k_mars_conv16<NZ>, dim3(grid), dim3(256), Conv16<NZ>::kLds, stream, feat, w1, b1, w2, b2,
-                       reinterpret_cast<_Float16 *>(out16), B);
+                       reinterpret_cast<_Float16 *>(out16), ld_out, B, range_flag);
 }
 
-void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
-                        hipStream_t stream)
+void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
+                        int B, int32_t *range_flag, hipStream_t stream)
 {
     if (B <= 0) return;
-    if (nz == 3) launch_conv16_t<3>(feat, w1, b1, w2, b2, out16, B, stream);
-    else launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, B, stream);
-}
-
-// Dense-1's merge: h = relu(g1 + scale * g2) in place of g1 (the two partial GEMMs of the split product run side by side on
-// two streams, see mars.py; scale = 2^-11 is exact, so this is what beta = 1 accumulation in the second GEMM gave).
-__global__ __launch_bounds__(256) void k_add_scaled_relu(float4 *__restrict__ g1, const float4 *__restrict__ g2, float scale, long long n4)
-{
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        float4 a = g1[i];
-        const float4 b = g2[i];
-        a.x = fmaxf(a.x + b.x * scale, 0.f);
-        a.y = fmaxf(a.y + b.y * scale, 0.f);
-        a.z = fmaxf(a.z + b.z * scale, 0.f);
-        a.w = fmaxf(a.w + b.w * scale, 0.f);
-        g1[i] = a;
-    }
-}
-void launch_add_scaled_relu(float *g1, const float *g2, float scale, long long n, hipStream_t stream)
-{
-    const long long n4 = n / 4;
-    long long blocks = (n4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_add_scaled_relu, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<float4 *>(g1),
-                       reinterpret_cast<const float4 *>(g2), scale, n4);
+    if (nz == 3) launch_conv16_t<3>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, stream);
+    else launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, stream);
 }
 
 }  // namespace mmw

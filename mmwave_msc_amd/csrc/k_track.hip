@@ -314,14 +314,16 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         typedef const double __attribute__((address_space(4))) *gate_ptr;
         const int su = __builtin_amdgcn_readfirstlane(s), Tu = __builtin_amdgcn_readfirstlane(T);
         gate_ptr gb = (gate_ptr)(st.gate_buf + (size_t)su * cfg.t_cap * kGateRec);
-        // (PRED: the records were written by this launch.  The constant address space promises the compiler memory that does
-        //  not change, so the pointer itself is made opaque HERE, behind the invalidate: no load through it can be moved above
-        //  this statement)
-        asm volatile("" : "+s"(gb) : : "memory");
-        {
+        if constexpr (PRED) {
+            // The records were written by this launch.  The constant address space promises the compiler memory that does not
+            // change, so the pointer itself is made opaque HERE, behind the invalidate: no load through it can be moved above
+            // this statement.
+            asm volatile("" : "+s"(gb) : : "memory");
             // Warm the scalar cache: one dword of every 64-byte line of the scene's gate records, all requests in flight
             // together.  The loop below then takes its records (six s_loads per track, waited for as a batch) from the
-            // scalar cache instead of paying an L2 round trip per track -- with two workgroups per CU nothing hides that.
+            // scalar cache instead of paying an L2 round trip per track -- with two or three workgroups per CU nothing hides
+            // that (19.7 k -> 15.4 k cycles for eight tracks).  (Not in the bulk instantiations: five workgroups per CU hide
+            // it, and their 96-register budget has no room for the sixteen addresses.)
             typedef const int __attribute__((address_space(4))) *line_ptr;
             const unsigned long long a0 = (unsigned long long)gb & ~63ULL;
             const int lines = (int)((((unsigned long long)gb + (unsigned long long)Tu * kGateRec * 8 + 63ULL) & ~63ULL) - a0) >> 6;

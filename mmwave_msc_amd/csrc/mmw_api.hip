@@ -55,9 +55,10 @@ void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
                       hipStream_t stream);
-void launch_add_scaled_relu(float *g1, const float *g2, float scale, long long n, hipStream_t stream);
-void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, int B,
-                        hipStream_t stream);
+int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
+                       hipStream_t stream);
+void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
+                        int B, int32_t *range_flag, hipStream_t stream);
 }  // namespace mmw
 
 using namespace mmw;
@@ -881,24 +882,28 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
 }
 
 int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
-                        const float *b2, void *out16, int32_t n)
+                        const float *b2, void *out16, int64_t ld_out, int32_t n, int32_t *range_flag)
 {
-    if ((frames != 3 && frames != 1) || n < 0 || (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out16)))
-        return fail(nullptr, MMW_E_ARG, "mmw_mars_conv_split: bad argument (frames must be 3 or 1)");
-    launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, n, (hipStream_t)hip_stream);
+    if ((frames != 3 && frames != 1) || n < 0 || ld_out < 2 * (int64_t)frames * 2048 || (ld_out & 7) != 0 || ((uintptr_t)out16 & 15) != 0 ||
+        (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out16)))
+        return fail(nullptr, MMW_E_ARG, "mmw_mars_conv_split: bad argument (frames must be 3 or 1, ld_out >= 2 * frames * 2048 and a multiple of 8)");
+    launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, ld_out, n, range_flag, (hipStream_t)hip_stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv_split launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 
-int mmw_mars_add_scaled_relu(void *hip_stream, float *g1, const float *g2, float scale, int64_t n)
+int mmw_mars_dense1_split(void *hip_stream, const void *a2, int64_t lda, const void *w2, int64_t ldw, const float *bias, float *out,
+                          int32_t rows_padded, int32_t k, int32_t n)
 {
-    if (n < 0 || (n & 3) != 0 || (n > 0 && (!g1 || !g2)) || (((uintptr_t)g1 | (uintptr_t)g2) & 15) != 0)
-        return fail(nullptr, MMW_E_ARG, "mmw_mars_add_scaled_relu: n must be a multiple of 4, pointers 16-byte aligned");
-    if (n == 0) return MMW_OK;
-    launch_add_scaled_relu(g1, g2, scale, (long long)n, (hipStream_t)hip_stream);
+    if (rows_padded < 0 || (rows_padded & 255) != 0 || k < 32 || (k & 31) != 0 || n < 128 || (n & 127) != 0 || lda < 2 * (int64_t)k || ldw < 2 * (int64_t)k ||
+        ((lda | ldw) & 7) != 0 || (rows_padded > 0 && (!a2 || !w2 || !bias || !out)) || (((uintptr_t)a2 | (uintptr_t)w2) & 15) != 0)
+        return fail(nullptr, MMW_E_ARG, "mmw_mars_dense1_split: rows_padded must be a multiple of 256, k of 32, n of 128; fp16 operands 16-byte aligned with leading dimensions >= 2 k that are multiples of 8");
+    if (rows_padded == 0) return MMW_OK;
+    if (launch_mars_dense1(a2, lda, w2, ldw, bias, out, rows_padded, k, n, (hipStream_t)hip_stream) != 0)
+        return fail(nullptr, MMW_E_HIP, "mmw_mars_dense1_split: hipFuncSetAttribute failed");
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_add_scaled_relu launch -> %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_dense1_split launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 

@@ -27,6 +27,23 @@ import torch.nn.functional as F
 BN_EPS = 1e-3
 N_KEYPOINTS = 57
 SPLIT_SCALE = 2048.0   # 2^11: fp16 keeps 11 significant bits (csrc/k_mars.hip: kSplitScale)
+FP16_SAFE_MAX = 6.0e4  # weights at or above this magnitude do not go through the split-fp16 arithmetic (fp16 max = 65 504)
+
+
+def interleave_split(m32: torch.Tensor) -> torch.Tensor:
+    """(R, K) fp32 -> (R, 2K) fp16: every value split a = hi + 2^-11 lo' and stored in runs of 32, [hi 0..31 | lo' 0..31 |
+    hi 32..63 | ...] -- the operand layout of k_mars_dense1 (csrc/k_dense.hip); K must be a multiple of 32."""
+    hi = m32.half()
+    lo = ((m32 - hi.float()) * SPLIT_SCALE).half()
+    r, k = m32.shape
+    return torch.stack([hi.reshape(r, k // 32, 32), lo.reshape(r, k // 32, 32)], 2).reshape(r, 2 * k)
+
+
+def deinterleave_split(a2: torch.Tensor):
+    """(R, >= 2K) interleaved fp16 -> (hi, lo') as (R, K) views' copies (tests, diagnostics)."""
+    r = a2.shape[0]
+    v = a2.reshape(r, -1, 2, 32)
+    return v[:, :, 0, :].reshape(r, -1), v[:, :, 1, :].reshape(r, -1)
 
 
 def random_keras_weights(seed: int = 0, frames: int = 3) -> dict:
@@ -61,15 +78,19 @@ class MarsCNN(nn.Module):
         "f32"   on the fp32 matrix cores: the fused conv kernel k_mars_conv (3-frame model; torch convolutions for the
                 single-frame one) and one fp32 GEMM (hipBLASLt through torch);
         "f16x3" every fp32 operand split as a = hi + 2^-11 lo' (hi, lo' fp16) and a.w = hi.w_hi + 2^-11 (hi.w_lo' + lo'.w_hi)
-                on the fp16 matrix cores with fp32 accumulation (k_mars_conv16 + two fp16 GEMMs): every partial product is
-                exact, the dropped lo'.lo' term is 2^-22 relative, and the result is CLOSER to the fp64 oracle than fp32
-                arithmetic (Dense-1 outputs: 1.2e-6 vs 2.5e-6 max error, scripts/exp_split_gemm.py).  Not a
-                reduced-precision mode: fp16 storage never holds a value that is not re-completed by its lo' half."""
+                on the fp16 matrix cores with fp32 accumulation (k_mars_conv16 + k_mars_dense1, both this package's kernels):
+                every partial product is exact, the dropped lo'.lo' term is 2^-22 relative, and the result is CLOSER to the
+                fp64 oracle than fp32 arithmetic (Dense-1 outputs: 1.2e-6 vs 2.5e-6 max error, scripts/exp_split_gemm.py).
+                Not a reduced-precision mode: fp16 storage never holds a value that is not re-completed by its lo' half --
+                WITHIN fp16's range: |a| < 65 504.  Weights outside it make from_keras_weights fall back to "f32"; an input
+                or activation outside it raises the conv kernel's range word (range_overflow(): that sample's outputs are
+                meaningless then), and predict() -- synchronous anyway -- computes such a batch again in fp32."""
         super().__init__()
         if arith not in ("f32", "f16x3"):
             raise ValueError(arith)
         self.arith = arith
-        self._side_streams = {}   # device index -> the stream the second Dense-1 GEMM runs on
+        self.arith_fallback = None   # why a model asked for as "f16x3" runs "f32" (from_keras_weights: weights beyond fp16's range)
+        self.range_fallbacks = 0     # predict() calls recomputed in fp32 because an input / activation left fp16's range
         self.frames = int(frames)
         self.three_d = self.frames > 1
         conv = nn.Conv3d if self.three_d else nn.Conv2d
@@ -90,17 +111,13 @@ class MarsCNN(nn.Module):
         self.register_buffer("k_w2", torch.zeros(kt * 16 * 32))
         self.register_buffer("k_b2", torch.zeros(32))
         self.dense1_dhwc = nn.Linear(flat, hidden)
-        # the same matrix split for the fp16 matrix cores: W_hi (K, N) and [W_lo' ; W_hi] (2K, N), both stored transposed
-        # (K contiguous: hipBLASLt's faster operand layout for these shapes, scripts/exp_gemm_layouts.py)
-        self.register_buffer("d1_w_hi_t", torch.zeros((hidden, flat), dtype=torch.float16))
+        # the same matrix split for the fp16 matrix cores, transposed (K contiguous) with the halves interleaved in runs of 32,
+        # [hi 0..31 | lo' 0..31 | hi 32..63 | ...]: the layout k_mars_dense1 stages (csrc/k_dense.hip)
         self.register_buffer("d1_w2_t", torch.zeros((hidden, 2 * flat), dtype=torch.float16))
+        # one word the split conv kernel raises when it splits an input or activation outside fp16's range (range_overflow())
+        self.register_buffer("range_flag", torch.zeros(1, dtype=torch.int32))
         for p in self.parameters():
             p.requires_grad_(False)
-
-    def __getstate__(self):   # (streams are process-local: a pickled / deep-copied model makes its own)
-        d = dict(self.__dict__)
-        d["_side_streams"] = {}
-        return d
 
     @classmethod
     def from_keras_weights(cls, w: dict, arith: str = "f16x3") -> "MarsCNN":
@@ -129,10 +146,12 @@ class MarsCNN(nn.Module):
         m.dense1_dhwc.weight.copy_(torch.from_numpy(wk.T.copy()).float())
         m.dense1_dhwc.bias.copy_(torch.from_numpy(b1).float())
         w32 = torch.from_numpy(wk.copy()).float()                    # (K, N), what the fp32 GEMM multiplies with
-        w_hi = w32.half()
-        w_lo = ((w32 - w_hi.float()) * SPLIT_SCALE).half()
-        m.d1_w_hi_t.copy_(w_hi.t())
-        m.d1_w2_t.copy_(torch.cat([w_lo, w_hi], 0).t())
+        m.d1_w2_t.copy_(interleave_split(w32.t().contiguous()))
+        # fp16's range is the split arithmetic's: a folded weight outside it would become inf in its hi half
+        wmax = max(float(np.abs(f64[k]).max()) for k in ("conv1_w", "conv2_w", "conv1_b", "conv2_b"))
+        if m.arith == "f16x3" and max(wmax, float(w32.abs().max())) >= FP16_SAFE_MAX:
+            m.arith = "f32"
+            m.arith_fallback = f"a weight of magnitude {max(wmax, float(w32.abs().max())):.3g} does not fit fp16: fp32 matrix cores instead"
         m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
         m.dense1.bias.copy_(torch.from_numpy(b1).float())
         a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
@@ -171,56 +190,65 @@ class MarsCNN(nn.Module):
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return out
 
+    # the activation's row stride: 2 * flat values + 256: whole rows then start 24.25 / 8.25 KB apart instead of a multiple
+    # of 4 KB, which spreads a tile's rows over the L2 channels (k_mars_dense1 1.144 -> 1.093 ms at 18 k rows)
+    ROW_PAD = 256
+
     def _hip_convs_split(self, x: torch.Tensor) -> torch.Tensor:
         """The conv pair on the fp16 matrix cores with split operands (mmw_mars_conv_split), the activation already split
-        for Dense-1: (B, 2 * flat) fp16 = [hi | lo'], flat = frames * 2048 in (d,h,w,c) order."""
+        for Dense-1: (B, 2 * flat) fp16, halves interleaved in runs of 32 (interleave_split), flat = frames * 2048 in (d,h,w,c)
+        order.  The result is a VIEW: its rows are 2 * flat + ROW_PAD apart and the storage holds whole 256-row tiles (the rows
+        past B are never written: Dense-1's kernel reads them, into rows nobody reads)."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
         flat = self.frames * 2048
-        out = torch.empty((x.shape[0], 2 * flat), dtype=torch.float16, device=x.device)
+        rows = (x.shape[0] + 255) // 256 * 256
+        ld = 2 * flat + self.ROW_PAD
+        out = torch.empty((rows, ld), dtype=torch.float16, device=x.device)
         rc = L.mmw_mars_conv_split(torch.cuda.current_stream(x.device).cuda_stream, self.frames, x.data_ptr(), self.k_w1.data_ptr(),
-                                   self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), x.shape[0])
+                                   self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), ld, x.shape[0],
+                                   self.range_flag.data_ptr())
         if rc != 0:
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
-        return out
+        return out[: x.shape[0], : 2 * flat]
 
-    # a batch below this many rows leaves the chip mostly idle either way: one stream, no merge kernel
-    SIDE_BY_SIDE_MIN_ROWS = 2048
-
-    def _dense1_split_relu(self, a2: torch.Tensor) -> torch.Tensor:
-        """relu(bias + hi.W_hi + 2^-11 [hi | lo'].[W_lo' ; W_hi]): two fp16 GEMMs with fp32 accumulation and output.
-        Large batches run the two GEMMs SIDE BY SIDE on two streams -- each is 1.7 waves of 256x256 tiles on 256 CUs, together
-        3.4 instead of 2 + 2 -- and merge them with one elementwise pass (mmw_mars_add_scaled_relu; 2^-11 is exact, so the
-        result is bit for bit what accumulating the second GEMM onto the first gives): 1.22 -> 1.09 ms at 18 k rows."""
-        k = a2.shape[1] // 2
-        if a2.shape[0] < self.SIDE_BY_SIDE_MIN_ROWS:
-            g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi_t.t(), out_dtype=torch.float32)
-            return F.relu_(torch.addmm(g1, a2, self.d1_w2_t.t(), out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE))
+    def _dense1_split(self, a2: torch.Tensor) -> torch.Tensor:
+        """relu(bias + hi.W_hi + 2^-11 (hi.W_lo' + lo'.W_hi)) in one kernel (mmw_mars_dense1_split, csrc/k_dense.hip) on the view
+        _hip_convs_split returns (any other (B, 2 flat) interleaved fp16 tensor is copied into a padded buffer first)."""
         from . import _lib
         L = _lib.load()
-        cur = torch.cuda.current_stream(a2.device)
-        side = self._side_streams.get(a2.device.index)
-        if side is None:
-            side = self._side_streams[a2.device.index] = torch.cuda.Stream(device=a2.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            g2 = torch.mm(a2, self.d1_w2_t.t(), out_dtype=torch.float32)
-        g1 = torch.addmm(self.dense1_dhwc.bias, a2[:, :k], self.d1_w_hi_t.t(), out_dtype=torch.float32)
-        cur.wait_stream(side)
-        g2.record_stream(cur)
-        a2.record_stream(side)
-        rc = L.mmw_mars_add_scaled_relu(cur.cuda_stream, g1.data_ptr(), g2.data_ptr(), 1.0 / SPLIT_SCALE, g1.numel())
+        B, k2 = a2.shape
+        rows = (B + 255) // 256 * 256
+        ld = a2.stride(0)
+        if a2.stride(1) != 1 or ld < k2 or (ld & 7) or a2.untyped_storage().nbytes() < (a2.storage_offset() + (rows - 1) * ld + k2) * 2:
+            buf = torch.zeros((rows, k2 + self.ROW_PAD), dtype=torch.float16, device=a2.device)
+            buf[:B, :k2] = a2
+            a2, ld = buf[:B, :k2], k2 + self.ROW_PAD
+        n = self.d1_w2_t.shape[0]
+        h = torch.empty((rows, n), dtype=torch.float32, device=a2.device)
+        rc = L.mmw_mars_dense1_split(torch.cuda.current_stream(a2.device).cuda_stream, a2.data_ptr(), ld, self.d1_w2_t.data_ptr(), k2,
+                                     self.dense1_dhwc.bias.data_ptr(), h.data_ptr(), rows, k2 // 2, n)
         if rc != 0:
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
-        return g1
+        return h[:B]
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it."""
-        if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32 and (self.arith == "f16x3" or self.use_hip_conv_f32):
+    def range_overflow(self, clear: bool = True) -> bool:
+        """True when a split-arithmetic forward since the last call met an input or activation outside fp16's range (that
+        sample's keypoints are meaningless; the other samples are not affected).  Reads one device word: synchronises."""
+        hit = bool(int(self.range_flag.item()))
+        if hit and clear:
+            self.range_flag.zero_()
+        return hit
+
+    def forward(self, x: torch.Tensor, arith: str | None = None) -> torch.Tensor:
+        """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it.  `arith` overrides the model's for
+        this call."""
+        arith = arith or self.arith
+        if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32 and (arith == "f16x3" or self.use_hip_conv_f32):
             with torch.cuda.device(x.device):
-                if self.arith == "f16x3":
-                    h = self._dense1_split_relu(self._hip_convs_split(x))
+                if arith == "f16x3":
+                    h = self._dense1_split(self._hip_convs_split(x))
                 else:
                     h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
             return self.dense2(h)
@@ -235,9 +263,15 @@ class MarsCNN(nn.Module):
 
     @torch.no_grad()
     def predict_numpy(self, feat: np.ndarray) -> np.ndarray:
+        """Keras' model.predict: synchronous, so the range check costs nothing here -- a batch that left fp16's range under the
+        split arithmetic is computed again on the fp32 path (Keras' fp32 has no such limit)."""
         dev = next(self.parameters()).device
         x = torch.from_numpy(np.ascontiguousarray(feat, dtype=np.float32)).to(dev)
-        return self(x).float().cpu().numpy()
+        out = self(x).float().cpu().numpy()
+        if self.arith == "f16x3" and x.is_cuda and self.range_overflow():
+            self.range_fallbacks += 1
+            out = self(x, arith="f32").float().cpu().numpy()
+        return out
 
     def predict(self, feat, verbose=0):  # Keras-style entry used by estimate_posture (Tracking.py:732)
         return self.predict_numpy(np.asarray(feat))

@@ -34,10 +34,12 @@ class PosturePipeline:
         self.B = (cnn_stream if cnn_stream is not None else torch.cuda.Stream(device=self.dev)) if overlap else self.A
         sb.follow_torch_stream(self.A)
         # with the CNN on its own stream beside the tracker, the tracker's own side-stream workers (k_chain) only take
-        # compute units from the statically tiled GEMMs: off in that schedule, the context's default in the serial one
-        self._side_default = bool(sb.cfg.chain_side_stream > 0 or (sb.cfg.chain_side_stream == 0 and sb.S >= 1024)) and not sb.cfg.seek_inner
-        if self._side_default:
-            sb.set_chain_side_stream(self.B is self.A)
+        # compute units from the statically tiled matrix kernels: off in that schedule -- if the library had them on
+        # (mmw_side_workers; its choice, not re-derived here) --, and back on when the pipeline is drained
+        self._side_was_on = sb.side_workers() != 0
+        if self._side_was_on and self.B is not self.A:
+            sb.set_chain_side_stream(False)
+        self.range_overflowed = False   # the split-fp16 CNN met an input / activation outside fp16's range (see drain())
         shape = (self.cap, sb.ring, 8, 8, 5) if sb.ring > 1 else (self.cap, 8, 8, 5)
         with torch.cuda.stream(self.A):
             self.feat = [torch.zeros(shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
@@ -100,3 +102,12 @@ class PosturePipeline:
         self.f = 0
         self.A.synchronize()
         self.B.synchronize()
+        if self._side_was_on and self.B is not self.A:
+            self.sb.set_chain_side_stream(True)
+            self._side_was_on = False
+        # the asynchronous path cannot recompute a frame that is long scattered: it reports (mars.MarsCNN.range_overflow)
+        if getattr(self.model, "arith", None) == "f16x3" and hasattr(self.model, "range_overflow") and self.model.range_overflow():
+            import warnings
+            self.range_overflowed = True
+            warnings.warn("MarsCNN (split-fp16 arithmetic): an input or activation left fp16's range during this run; the keypoints of "
+                          "the samples concerned are meaningless -- use MarsCNN(arith='f32') for such data", RuntimeWarning, stacklevel=2)

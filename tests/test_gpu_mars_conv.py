@@ -69,7 +69,7 @@ def test_split_fp16_cnn_holds_the_fp32_tolerance(frames, n):
     oracle: keypoints within 1e-4 (SURVEY.md §8c) and not worse than twice the fp32 arithmetic's error (measured: better);
     the split activation re-completes to the fp64 convolution within a few 2^-22."""
     import torch
-    from mmwave_msc_amd.mars import MarsCNN, SPLIT_SCALE, random_keras_weights
+    from mmwave_msc_amd.mars import MarsCNN, SPLIT_SCALE, deinterleave_split, random_keras_weights
     from oracle.mars_np import _conv_same, mars_forward_np
     w = random_keras_weights(7, frames)
     feat = _inputs(max(n, 8), frames, 3)[:max(n, 8)]
@@ -80,7 +80,7 @@ def test_split_fp16_cnn_holds_the_fp32_tolerance(frames, n):
     assert m16.arith == "f16x3" and m32.arith == "f32" and m16.use_hip_conv
     with torch.no_grad():
         k16, k32 = m16(x[:n]).double().cpu().numpy(), m32(x[:n]).double().cpu().numpy()
-        a2 = m16._hip_convs_split(x).double().cpu().numpy()
+        a_hi, a_lo = (t.double().cpu().numpy() for t in deinterleave_split(m16._hip_convs_split(x)))
     scale = np.maximum(1.0, np.abs(want[:n]))
     e16, e32 = float((np.abs(k16 - want[:n]) / scale).max()), float((np.abs(k32 - want[:n]) / scale).max())
     assert e32 <= 1e-4 and e16 <= 1e-4, (e16, e32)
@@ -88,8 +88,79 @@ def test_split_fp16_cnn_holds_the_fp32_tolerance(frames, n):
     f64 = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
     h = np.maximum(_conv_same(feat.astype(np.float64), f64["conv1_w"], f64["conv1_b"]), 0.0)
     h = np.maximum(_conv_same(h, f64["conv2_w"], f64["conv2_b"]), 0.0).reshape(len(feat), -1)
-    flat = h.shape[1]
-    rec = a2[:, :flat] + a2[:, flat:] / SPLIT_SCALE
+    rec = a_hi + a_lo / SPLIT_SCALE
     err = np.abs(rec - h) / np.maximum(1.0, np.abs(h))
     assert float(err.max()) <= 2e-5, float(err.max())
-    assert float(np.abs(a2[:, flat:]).max()) <= 1.0 + float(np.abs(h).max())   # lo' stays within hi's magnitude: no overflow of the scaled half
+    assert float(np.abs(a_lo).max()) <= 1.0 + float(np.abs(h).max())   # lo' stays within hi's magnitude: no overflow of the scaled half
+    assert not m16.range_overflow()
+
+
+@pytest.mark.parametrize("frames,n", [(3, 700), (3, 256), (1, 1000), (1, 3)])
+def test_fused_dense1_kernel_vs_two_gemms_and_fp64(frames, n):
+    """Dense-1 of the split arithmetic as ONE kernel (mmw_mars_dense1_split, csrc/k_dense.hip: train.py:49,87 with BN folded in)
+    against the two-GEMM formulation it replaces (hi.W_hi and [hi | lo'].[W_lo' ; W_hi] through torch / hipBLASLt) and against
+    fp64 numpy on the SAME split operands: every partial product is exact in all three, so they differ by fp32 summation order
+    only; rows past the batch in the last 256-row tile are never read back, and a NaN row stays in its own output row."""
+    import torch
+    from mmwave_msc_amd.mars import MarsCNN, SPLIT_SCALE, deinterleave_split, random_keras_weights
+    w = random_keras_weights(11, frames)
+    feat = _inputs(max(n, 8), frames, 5)[:n]
+    x = torch.from_numpy(feat).to("cuda:0")
+    mk = MarsCNN.from_keras_weights(w).to("cuda:0")
+    with torch.no_grad():
+        a2 = mk._hip_convs_split(x)
+        hk = mk._dense1_split(a2)
+        hi, lo = deinterleave_split(a2)
+        w_hi, w_lo = (t.t() for t in deinterleave_split(mk.d1_w2_t))          # (K, N)
+        bias = mk.dense1_dhwc.bias
+        g1 = torch.addmm(bias, hi, w_hi, out_dtype=torch.float32)
+        hg = torch.relu(torch.addmm(g1, torch.cat([hi, lo], 1), torch.cat([w_lo, w_hi], 0), out_dtype=torch.float32, alpha=1.0 / SPLIT_SCALE))
+        want = torch.relu(bias.double() + hi.double() @ w_hi.double() + (hi.double() @ w_lo.double() + lo.double() @ w_hi.double()) / SPLIT_SCALE)
+    assert hk.shape == (n, mk.d1_w2_t.shape[0]) and hk.dtype == torch.float32
+    scale = want.abs().clamp(min=1.0)
+    ek, eg = float(((hk.double() - want).abs() / scale).max()), float(((hg.double() - want).abs() / scale).max())
+    # (fp32 accumulation over K = 2048 / 6144 terms with cancellation: ~1e-5 of the result in either formulation)
+    assert ek <= 5e-5 and ek <= 2.0 * eg + 5e-7, (ek, eg)
+    # a poisoned row: NaN in, NaN out, in that row only (a compact copy: _dense1_split pads it itself)
+    a3 = a2.clone()
+    a3[1, 7] = float("nan")
+    with torch.no_grad():
+        hp = mk._dense1_split(a3)
+    assert bool(torch.isnan(hp[1]).all()) and not bool(torch.isnan(hp[0]).any()) and (n < 3 or torch.equal(hp[2:], hk[2:]))
+
+
+def test_split_arithmetic_knows_fp16s_range():
+    """fp16 holds |a| < 65 504: a weight beyond it sends the whole model to the fp32 kernels at load time; an input or an
+    activation beyond it raises the conv kernel's range word (that sample's raw outputs are then meaningless; the others'
+    are untouched) and makes the synchronous Keras-style entry -- TrackBuffer.estimate_posture's model.predict, Tracking.py:732 -- compute the
+    batch again in fp32, within the usual 1e-4 of the fp64 oracle.  train.py:33-106 (Keras fp32) has no such limit."""
+    import torch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from oracle.mars_np import mars_forward_np
+    w = random_keras_weights(3, 3)
+    feat = _inputs(64, 3, 9)
+    feat[11] *= 1e5                      # inputs of magnitude ~3e5: hi would be inf
+    want = mars_forward_np(w, feat.astype(np.float64))
+    m = MarsCNN.from_keras_weights(w).to("cuda:0")
+    assert m.arith == "f16x3" and m.arith_fallback is None
+    x = torch.from_numpy(feat).to("cuda:0")
+    with torch.no_grad():
+        raw = m(x).float().cpu().numpy()
+    assert m.range_overflow() and not m.range_overflow()            # raised once, cleared by the read
+    scale = np.maximum(1.0, np.abs(want))
+    assert float((np.abs(np.delete(raw, 11, 0) - np.delete(want, 11, 0)) / np.delete(scale, 11, 0)).max()) <= 1e-4
+    got = m.predict(feat)
+    assert m.range_fallbacks == 1
+    assert float((np.abs(got - want) / scale).max()) <= 1e-4
+    # a huge BN-folded Dense-1 row (tiny moving variance x large gamma): fp32 from the start
+    w2 = dict(w)
+    w2["bn1_gamma"] = w["bn1_gamma"].copy(); w2["bn1_var"] = w["bn1_var"].copy()
+    w2["bn1_gamma"][4] = 3.0e6; w2["bn1_var"][4] = 1e-9
+    m2 = MarsCNN.from_keras_weights(w2).to("cuda:0")
+    assert m2.arith == "f32" and "fp16" in m2.arith_fallback
+    small = _inputs(32, 3, 10)
+    want2 = mars_forward_np(w2, small.astype(np.float64))
+    got2 = m2.predict(small)
+    # (keypoints of magnitude 1e8 out of cancelling 1e9 terms: the error is measured against each sample's largest output)
+    e2 = float((np.abs(got2 - want2) / np.maximum(1.0, np.abs(want2).max(axis=1, keepdims=True))).max())
+    assert e2 <= 1e-4 and m2.range_fallbacks == 0, (e2, float(np.abs(want2).max()))
