@@ -156,6 +156,13 @@ int mmw_destroy(mmw_ctx *ctx);
 const char *mmw_last_error(const mmw_ctx *ctx);
 /* Fresh TrackBuffer/BatchedData for every scene. */
 int mmw_reset(mmw_ctx *ctx);
+/* ... for the scenes whose flag is non-zero only (host array of n_scenes words): how a batched caller recovers ONE scene --
+ * e.g. after MMW_E_CAPACITY, which names the scene; the error bits are per scene and the other scenes' state stays valid. */
+int mmw_reset_scenes(mmw_ctx *ctx, const int32_t *scene_flags);
+/* The sticky error bits of every scene (host array of n_scenes words; 0 = none): 1 singular 6x6 matrix, 2 division by zero
+ * in _get_Rc, 4 more tracks than track_cap (the tracks that did not fit were dropped: this scene differs from the reference
+ * from then on), 8 a point count the context was not sized for.  mmw_check reports the first one as its return code. */
+int mmw_get_errors(mmw_ctx *ctx, int32_t *err_bits);
 /* BatchedData.pop_frame() (Tracking.py:66-71; its caller is preprocessing.py:264): drop the oldest frame of the global
  * ring of every scene whose flag is non-zero (host array of n_scenes words; NULL = every scene). */
 int mmw_pop_frame(mmw_ctx *ctx, const int32_t *scene_flags);

@@ -118,6 +118,12 @@ class SceneBatch:
         queue with the context's stream), 1 = in use, 2 = configured but no step has checked the streams yet."""
         return int(self.L.mmw_side_workers(self.h))
 
+    def diag_queue(self) -> np.ndarray:
+        """mmw_diag_queue: the 32 words of the DBSCAN work queues ([4] = bounded waits given up, also reported by check())."""
+        out = np.zeros(32, dtype=np.int32)
+        self._chk(self.L.mmw_diag_queue(self.h, out.ctypes.data))
+        return out
+
     def step_kind(self) -> int:
         """mmw_step_kind: 1 = the one-workgroup step (k_scene), 2 = two launches, 4 = the bulk kernels."""
         return int(self.L.mmw_step_kind(self.h))
@@ -150,6 +156,17 @@ class SceneBatch:
 
     def reset(self):
         self._chk(self.L.mmw_reset(self.h))
+
+    def reset_scenes(self, mask):
+        """Fresh TrackBuffer / BatchedData for the scenes where `mask` is true (mmw_reset_scenes); the others keep their state."""
+        m = np.ascontiguousarray(np.asarray(mask).astype(np.int32).reshape(self.S))
+        self._chk(self.L.mmw_reset_scenes(self.h, m.ctypes.data))
+
+    def errors(self) -> np.ndarray:
+        """Sticky error bits per scene (mmw_get_errors): 1 singular, 2 division by zero, 4 capacity, 8 bad point count."""
+        out = np.zeros(self.S, dtype=np.int32)
+        self._chk(self.L.mmw_get_errors(self.h, out.ctypes.data))
+        return out
 
     def check(self):
         self._chk(self.L.mmw_check(self.h))

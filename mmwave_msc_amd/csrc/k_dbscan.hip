@@ -1258,7 +1258,11 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
 // correctness never depends on k_chain having run.  `epoch` = this step's number: k_post raises q[kQStop] to it when it
 // starts, i.e. when no more pushes can come.  Every wait is bounded.
 constexpr int kChainBlocks = 8;
-constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: ~80 ms (waits that MUST succeed: an entry behind its count, the end of a claimed item)
+constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: how long a side-stream worker keeps trying to claim from a non-empty queue
+// Waits that MUST succeed (an entry behind its count: a few instructions in the pushing workgroup; the end of a claimed item: one
+// BallTree chain) are bounded by TIME, not by iterations -- the 100 MHz s_memrealtime counter; a slow clock or a profiler that
+// serialises kernels must not turn into a spurious give-up: 0.2 s for an entry, 2 s for the end of the claimed items
+constexpr unsigned long long kMustWaitTicks = 20000000ULL, kDoneWaitTicks = 200000000ULL;
 // ... and how long a side-stream worker polls EMPTY queues before it leaves (~3 ms; k_post / k_dbscan_big take whatever comes
 // later).  Short on purpose: should the context's stream ever sit behind a polling worker in one hardware queue -- two
 // contexts whose streams share queues crosswise can do that, the probe only sees its own pair -- the damage is these 3 ms.
@@ -1296,7 +1300,7 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
             if (h >= 0) {
                 int32_t *e = ring + h;
                 int v = 0;
-                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                for (const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); (v = q_load(e)) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < kMustWaitTicks;) __builtin_amdgcn_s_sleep(2);
                 if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&q[kQDone], 1); }
                 else {
                     __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1372,7 +1376,7 @@ __device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevStat
             if (h >= 0) {
                 int32_t *e = ring + h;
                 int v = 0;
-                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                for (const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); (v = q_load(e)) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < kMustWaitTicks;) __builtin_amdgcn_s_sleep(2);
                 if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&q[kQDone], 1); }
                 else {
                     __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1402,8 +1406,7 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
 {
     const int32_t *qp = st.q + kQBig + parity * 8;
     const int want = q_load(&qp[kQCount]);
-    long long spins = 0;
-    while (q_load(&qp[kQDone]) < want && spins < (1LL << 23)) { __builtin_amdgcn_s_sleep(8); spins++; }
+    for (const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); q_load(&qp[kQDone]) < want && __builtin_amdgcn_s_memrealtime() - t0 < kDoneWaitTicks;) __builtin_amdgcn_s_sleep(8);
     if (q_load(&qp[kQDone]) < want) atomicAdd(&st.q[kQTimeout], 1);
     q_acquire();
 }
@@ -1498,8 +1501,7 @@ __global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const 
             // launches read what the spawn writes.  Bounded: ~2 s, then a sticky error.
             const int32_t *qp = st.q + parity * 8;
             const int want = q_load(&qp[kQCount]);
-            long long spins = 0;
-            while (q_load(&qp[kQDone]) < want && spins < (1LL << 23)) { __builtin_amdgcn_s_sleep(8); spins++; }
+            for (const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); q_load(&qp[kQDone]) < want && __builtin_amdgcn_s_memrealtime() - t0 < kDoneWaitTicks;) __builtin_amdgcn_s_sleep(8);
             if (q_load(&qp[kQDone]) < want) atomicAdd(&st.q[kQTimeout], 1);
             q_acquire();
         }
@@ -1558,7 +1560,7 @@ __global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, 
                 // the entry follows its count by a few instructions in the pushing workgroup
                 int32_t *e = st.db_list + (kind == 2 ? cfg.n_scenes : 0) + h;
                 int v = 0;
-                for (int w2 = 0; w2 < kSpinLimit && (v = q_load(e)) == 0; w2++) __builtin_amdgcn_s_sleep(2);
+                for (const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); (v = q_load(e)) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < kMustWaitTicks;) __builtin_amdgcn_s_sleep(2);
                 if (v == 0) { atomicAdd(&st.q[kQTimeout], 1); atomicAdd(&(kind == 2 ? qb : qs)[kQDone], 1); }
                 else {
                     __hip_atomic_store(e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

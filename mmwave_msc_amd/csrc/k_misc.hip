@@ -308,10 +308,12 @@ __global__ void k_table(DevCfg cfg, DevState st, mmw_track_summary *__restrict__
     o->fade_size = (float)size;
 }
 
-__global__ void k_reset(DevCfg cfg, DevState st)
+// flags == nullptr: every scene (mmw_reset); else only the scenes whose flag is non-zero (mmw_reset_scenes), and nothing of the
+// context-wide schedules
+__global__ void k_reset(DevCfg cfg, DevState st, const int32_t *__restrict__ flags)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < cfg.n_scenes) {
+    if (g < cfg.n_scenes && (!flags || flags[g])) {
         SceneHdr *h = st.hdr + g;
         h->n_tracks = 0;
         h->g_len = 1;  // BatchedData() starts with ONE empty frame (Utils.py:35-41, Tracking.py:38-41)
@@ -321,12 +323,18 @@ __global__ void k_reset(DevCfg cfg, DevState st)
         h->db_u = 0;
         h->next_uid = 0;
         h->n_upd = 0;
-        h->skipped = 0;
-        st.perm[g] = g;
-        st.perm[cfg.n_scenes + g] = g;
+        h->skipped = flags ? 1 : 0;  // (a scene reset on its own is in no update list: the next k_predict looks at its header)
+        if (!flags) {
+            st.perm[g] = g;
+            st.perm[cfg.n_scenes + g] = g;
+        } else {
+            for (int k = 0; k < cfg.t_cap; k++) st.order[(size_t)g * cfg.t_cap + k] = k;
+        }
     }
+    if (flags) return;
     for (int e = g; e < 2 * (cfg.t_cap + 1); e += gridDim.x * blockDim.x) st.upd_count[e] = 0;
     if (g < 2) st.spc_count[g] = 0;
+    if (g == 0) st.q[kQTimeout] = 0;   // (a bounded wait that gave up is reported by mmw_check until the context is reset)
     const size_t tot = (size_t)cfg.n_scenes * cfg.t_cap;
     for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);
 }
@@ -404,9 +412,9 @@ void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags
     hipLaunchKernelGGL(k_pop_frame, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, flags);
 }
 
-void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st)
+void launch_reset(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_reset, dim3((cfg.n_scenes + 255) / 256 > 0 ? (cfg.n_scenes + 255) / 256 : 1), dim3(256), 0, st, cfg, s);
+    hipLaunchKernelGGL(k_reset, dim3((cfg.n_scenes + 255) / 256 > 0 ? (cfg.n_scenes + 255) / 256 : 1), dim3(256), 0, st, cfg, s, flags);
 }
 
 // Do kernels of stream B run while a kernel of stream A is spinning?  Streams are multiplexed onto a few hardware queues, and

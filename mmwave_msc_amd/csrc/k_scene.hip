@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
         gate_ptr gb = (gate_ptr)(st.gate_buf + (size_t)su * cfg.t_cap * kGateRec);
         // (the constant address space promises the compiler memory that does not change: the pointer is made opaque HERE,
         //  behind the invalidate, so that no load through it can be moved above this statement)
-        asm volatile("" : "+s"(gb) : : "memory");
+        asm volatile("; mmw: gate pointer opaque from here" : "+s"(gb) : : "memory");
         {   // warm the scalar cache: one dword of every 64-byte line of the records, all requests in flight together
             const unsigned long long a0 = (unsigned long long)gb & ~63ULL;
             const int lines = (int)((((unsigned long long)gb + (unsigned long long)Tu * kGateRec * 8 + 63ULL) & ~63ULL) - a0) >> 6;

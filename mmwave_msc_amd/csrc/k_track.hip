@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             // The records were written by this launch.  The constant address space promises the compiler memory that does not
             // change, so the pointer itself is made opaque HERE, behind the invalidate: no load through it can be moved above
             // this statement.
-            asm volatile("" : "+s"(gb) : : "memory");
+            asm volatile("; mmw: gate pointer opaque from here" : "+s"(gb) : : "memory");
             // Warm the scalar cache: one dword of every 64-byte line of the scene's gate records, all requests in flight
             // together.  The loop below then takes its records (six s_loads per track, waited for as a batch) from the
             // scalar cache instead of paying an L2 round trip per track -- with two or three workgroups per CU nothing hides

@@ -48,7 +48,7 @@ void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t
 void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st);
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
-void launch_reset(const DevCfg &cfg, const DevState &s, hipStream_t st);
+void launch_reset(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
 void launch_probe_wait(int32_t *w, int slot, int polls, hipStream_t st);
 void launch_probe_set(int32_t *w, hipStream_t st);
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
@@ -172,6 +172,8 @@ static void prof_end(mmw_ctx *c, EventPair &ep)
     if (c->pending.size() >= 2048) prof_fold(c);
 }
 
+static int read_headers(mmw_ctx *c, std::vector<SceneHdr> &h);
+
 extern "C" {
 
 const char *mmw_version(void) { return "mmw-hip 0.1 (gfx950)"; }
@@ -242,6 +244,7 @@ static int probe_side_streams(mmw_ctx *c)
     for (int attempt = 0; ok == 0 && attempt < 6; attempt++) {  // the next stream lands on the next hardware queue
         hipStream_t fresh = nullptr;
         if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) return -1;
+        hipStreamSynchronize(c->side_stream);
         hipStreamDestroy(c->side_stream);
         c->side_stream = fresh;
         ok = probe_one(c, fresh, c->stream);
@@ -398,7 +401,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap, cfg->db_min_samples);
     if (e1 == hipSuccess && scene_lds_bytes(d) <= 160 * 1024) e1 = prepare_scene(d);
     if (e1 != hipSuccess || e2 != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
-    launch_reset(d, c->st, c->stream);
+    launch_reset(d, c->st, nullptr, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "reset kernel failed: %s", hipGetErrorString(hipGetLastError())); }
     *out = c;
     return MMW_OK;
@@ -408,7 +411,11 @@ int mmw_destroy(mmw_ctx *c)
 {
     if (!c) return MMW_OK;
     hipSetDevice(c->device);
-    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    // nothing of this context may still be running when its memory goes: the context's stream (the caller's or our own) and
+    // the chain workers' side stream, which can poll the queues for a few ms after the last step
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
+    if (c->side_stream) hipStreamSynchronize(c->side_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
@@ -416,7 +423,7 @@ int mmw_destroy(mmw_ctx *c)
     for (void *p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
     if (c->h_rows) hipHostFree(c->h_rows);
-    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->side_gate) hipEventDestroy(c->side_gate);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -427,11 +434,33 @@ int mmw_reset(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    launch_reset(c->dc, c->st, c->stream);
+    launch_reset(c->dc, c->st, nullptr, c->stream);
     HIPCHK(c, hipGetLastError());
     c->dc.var_ring = 0;   // fresh BatchedData objects: default sizes again
     c->dc.fused = (c->fused_wanted && !c->dc.side_worker) ? 1 : 0;
     c->ring_frames_bound = 0;
+    return MMW_OK;
+}
+
+int mmw_reset_scenes(mmw_ctx *c, const int32_t *scene_flags)
+{
+    if (!c || !scene_flags) return fail(c, MMW_E_ARG, "mmw_reset_scenes: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    // (staged in the feature-offset scratch: S + 1 words, not live between calls)
+    HIPCHK(c, hipMemcpyAsync(c->d_row_off, scene_flags, sizeof(int32_t) * c->dc.n_scenes, hipMemcpyHostToDevice, c->stream));
+    launch_reset(c->dc, c->st, c->d_row_off, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's array may go away
+    return MMW_OK;
+}
+
+int mmw_get_errors(mmw_ctx *c, int32_t *err_bits)
+{
+    if (!c || !err_bits) return MMW_E_ARG;
+    std::vector<SceneHdr> h;
+    int rc = read_headers(c, h);
+    if (rc) return rc;
+    for (size_t s = 0; s < h.size(); s++) err_bits[s] = h[s].err;
     return MMW_OK;
 }
 

@@ -97,3 +97,35 @@ def test_step_kernels_compile_without_scratch():
             body = asm[asm.index("\n" + n + ":"):]
             body = body[: body.index("s_endpgm")]
             assert not re.search(r"\bscratch_|buffer_(load|store)\S* .*offen", body), n
+
+
+def test_gate_records_are_not_read_before_the_scalar_cache_invalidate():
+    """k_track's PRED instantiations and k_scene write the gate records (C^-1, log det, Hx per track) in the SAME launch that
+    reads them back through the scalar cache (constant address space, s_load).  The compiler may treat such memory as
+    unchanging, so the pointer is laundered through an asm statement behind the s_dcache_inv; this reads the ISA: the
+    invalidate precedes the marker, the wide scalar loads of the gate loop follow it, and none of them sits in front of
+    the invalidate (k_scene loads its 64-byte scene header with one s_load_dwordx16 there: exactly one is allowed)."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmwave_msc_amd", "csrc")
+    for src, pat, allowed_before in (("k_track.hip", r"^(_ZN3mmw7k_trackILi\dELb[01]ELb1EE\S*):", 0), ("k_scene.hip", r"^(_ZN3mmw7k_sceneILi\dELi\dEE\S*):", 1)):
+        asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S",
+                              "-c", os.path.join(root, src), "-o", "-"], capture_output=True, text=True, timeout=900).stdout
+        names = re.findall(pat, asm, flags=re.M)
+        assert len(names) >= 6, (src, names)
+        for n in names:
+            body = asm[asm.index("\n" + n + ":"):]
+            body = body[: body.index("s_endpgm")]
+            inv, mark = body.find("s_dcache_inv"), body.find("; mmw: gate pointer opaque from here")
+            assert 0 < inv < mark, (n, inv, mark)
+            kern = re.search(r"s_load_dword\S* \S+ (s\[\d+:\d+\]), 0x", body).group(1)   # first scalar load: the kernel arguments
+            wide = [(m.start(), m.group(1)) for m in re.finditer(r"s_load_dwordx16 \S+ (s\[\d+:\d+\]),", body)]
+            before = [w for w in wide if w[0] < inv and w[1] != kern]
+            after = [w for w in wide if w[0] > mark and w[1] != kern]
+            assert len(before) <= allowed_before and len(after) >= 5, (n, len(before), len(after))

@@ -361,6 +361,64 @@ def test_error_paths_are_loud():
     sb.close()
 
 
+def test_capacity_overflow_is_per_scene_and_recoverable():
+    """A scene whose clusters do not fit its track list (Tracking.py:576-589 has no cap; here track_cap) gets the sticky capacity
+    bit and MMW_E_CAPACITY names it; the OTHER scenes of the context are not touched -- they keep matching their oracles -- and
+    mmw_reset_scenes gives the one scene a fresh TrackBuffer / BatchedData from which it matches a fresh oracle again."""
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    S, N, F = 6, 256, 12
+    kw = dict(tr_max_tracks=4, track_cap=2)
+    sb = _mk(S, N, **kw)
+    cfg = co.default_config(**kw)
+    pts = np.zeros((F, S, N, 8), np.float32); cnt = np.zeros((F, S), np.int32); dts = np.zeros((F, S))
+    targets = [1, 2, 3, 1, 2, 1]                      # scene 2 holds three targets: one more than track_cap
+    for s in range(S):
+        p, c, d = make_batch([900 + s], F, N, targets[s])
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    orc = [co.OracleScene(cfg, N) for _ in range(S)]
+    good = [s for s in range(S) if s != 2]
+    raised = False
+    for f in range(6):
+        try:
+            sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        except _lib.MmwError as e:
+            assert e.code == _lib.E_CAPACITY and "scene 2" in str(e)
+            raised = True
+        for s in good:
+            orc[s].track(pts[f, s, : cnt[f, s]].astype(np.float64), dts[f, s])
+    assert raised
+    err = sb.errors()
+    assert err[2] & 4 and not err[good].any()
+    ntr, trk = sb.num_tracks(), sb.tracks(cap=4)
+    for s in good:
+        want = orc[s].tracks()
+        assert ntr[s] == len(want)
+        for name in ("x", "P", "centroid", "lifetime", "point_num", "ring_n"):
+            assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
+    # recover scene 2 alone: from here on it is a fresh scene fed ONE target (which fits)
+    mask = np.zeros(S, bool); mask[2] = True
+    sb.reset_scenes(mask)
+    assert not sb.errors().any()
+    sb.check()
+    orc[2] = co.OracleScene(cfg, N)
+    p2, c2, d2 = make_batch([990], F, N, 1)
+    pts[6:, 2], cnt[6:, 2], dts[6:, 2] = p2[6:, 0], c2[6:, 0], d2[6:, 0]
+    for f in range(6, F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        for s in range(S):
+            oa, ol = orc[s].track(pts[f, s, : cnt[f, s]].astype(np.float64), dts[f, s])
+            assert np.array_equal(assoc[s, : cnt[f, s]], oa), (f, s)
+    ntr, trk = sb.num_tracks(), sb.tracks(cap=4)
+    for s in range(S):
+        want = orc[s].tracks()
+        assert ntr[s] == len(want), s
+        for name in ("x", "P", "centroid", "lifetime", "point_num", "ring_n"):
+            assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
+    sb.close()
+
+
 def test_seek_inner_many_scenes_vs_oracle():
     """ClusterTrack.seek_inner_clusters (Tracking.py:409-448, call site Tracking.py:656 active) over a batch: pairs of
     people one outer cluster wide split into two tracks, standing pairs take the FB_FRAMES_BATCH_STATIC ring size, scenes
