@@ -246,8 +246,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (tracker + features + CNN every frame) leg")
     ap.add_argument("--no-e2e-parity", action="store_true", help="skip the configs[3] end-to-end parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")
-    ap.add_argument("--chain-side-stream", type=int, default=0, choices=(-1, 0, 1),
-                    help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1536 scenes), 1 = on, -1 = off")
+    ap.add_argument("--chain-side-stream", type=int, default=0, choices=(-1, 0, 1, 2),
+                    help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1536 scenes), 1 = on, -1 = off, "
+                         "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
     ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
     ap.add_argument("--fused-step", type=int, default=0, choices=(-1, 0, 1),
@@ -574,7 +575,11 @@ def main():
                 # separate rocprofv3 --pmc run of this workload (profiles/README.md)
                 traffic = ent.get("hbm_bytes_per_launch_fetch_x2") if isinstance(ent, dict) else ent
                 if traffic is not None:
-                    traffic_src = f"profiles/traffic.json[{key}] ({tj.get('source', 'separate rocprofv3 --pmc passes')}); not measured in this run"
+                    import hashlib
+                    raw = open(tpath, "rb").read()
+                    blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]   # = git hash-object: a stale file is visible
+                    traffic_src = (f"profiles/traffic.json[{key}] (git blob {blob}; {tj.get('source', 'separate rocprofv3 --pmc passes')}); "
+                                   f"not measured in this run")
             except Exception:
                 traffic = None
         # B_trk = 64N + 4N + 4U + 2*T*1200 + 64*U_new per scene-frame, with the run's own means

@@ -88,7 +88,9 @@ typedef struct mmw_config {
     int32_t chain_side_stream;      /* not a reference constant: where the small-cloud DBSCAN (pair-count screen, BallTree chain) of a
                                        frame runs.  0 = automatic (contexts of >= 1536 scenes: worker blocks on a second stream beside
                                        the association kernel, whatever they have not taken by its end in the post kernel), -1 = post
-                                       kernel only, 1 = always with the side stream (tests run both) */
+                                       kernel only, 1 = always with the side stream (tests run both), 2 = as 1 without the check that
+                                       the side stream really runs beside the context's (profilers that serialise kernels fail it: the
+                                       workers then start, find nothing to claim in time and leave -- correct, and visible as a launch) */
     double db_spread_thres;         /* DB_SPREAD_THRES :77 */
     double db_inner_eps;            /* DB_INNER_EPS :78 */
     double m_x, m_y, m_z;           /* M_X, M_Y, M_Z :31-33  monitoring point (calc_projection_points, Utils.py:180-219) */

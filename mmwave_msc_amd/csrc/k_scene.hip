@@ -220,8 +220,8 @@ __device__ __forceinline__ void update_round(const Lds &L, TrackRec *trk, int j0
 
 using namespace scene;
 
-template <int PPT, int DX>
-__global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, const double *__restrict__ pts_all, const int32_t *__restrict__ n_pts,
+template <int NT, int PPT, int DX>
+__global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st, const double *__restrict__ pts_all, const int32_t *__restrict__ n_pts,
                                                        const double *__restrict__ dt_all, int32_t *__restrict__ assoc_out,
                                                        int32_t *__restrict__ db_n_out, int32_t *__restrict__ db_labels_out, int UM_out, int parity)
 {
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     const double dt = dt_all[s];
     const int my_slot = tid < cfg.t_cap ? order[tid] : 0;
     // (the lanes per Kalman filter depend on the track count, which is in flight: the slot for each grouping)
-    const int slot64 = order[tid >> 6], slot32 = (tid >> 5) < cfg.t_cap ? order[tid >> 5] : 0, slot16 = (tid >> 4) < cfg.t_cap ? order[tid >> 4] : 0;
+    const int slot64 = (tid >> 6) < cfg.t_cap ? order[tid >> 6] : 0, slot32 = (tid >> 5) < cfg.t_cap ? order[tid >> 5] : 0,
+              slot16 = (tid >> 4) < cfg.t_cap ? order[tid >> 4] : 0;
     double2 pr[PPT][4];
     // (the frame's rows: 64 B per thread and point, the bulk of the step's traffic.  They are requested BEHIND the track
     //  records -- the Kalman prediction is the head of the chain and the gate needs the rows only after it --, without
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
         const double2 *src2 = reinterpret_cast<const double2 *>(pts_all + (size_t)s * NP * 8);
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
-            const int i = q * kThreads + tid;
+            const int i = q * NT + tid;
 #pragma unroll
             for (int u = 0; u < 4; u++) pr[q][u] = (i < NP) ? src2[i * 4 + u] : double2{0.0, 0.0};
         }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;
     if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = 0;
     if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
-    if (s == 0 && tid == kThreads - 1) st.spc_count[parity ^ 1] = 0;
+    if (s == 0 && tid == NT - 1) st.spc_count[parity ^ 1] = 0;
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
@@ -276,9 +277,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     }
     int T = hv.n_tracks;
     const int Tin = T, Tres = T < kRes ? T : kRes;
-    // lanes per Kalman filter (uniform): every track of the scene in ONE round of the four waves when it holds <= 16
-    const int lp = T <= 4 ? 64 : (T <= 8 ? 32 : 16);
-    const int per_round = kThreads / lp;
+    // lanes per Kalman filter (uniform): every track of the scene in ONE round of the workgroup's waves when it holds <= 16
+    const int lp = T <= NT / 64 ? 64 : (T <= NT / 32 ? 32 : 16);
+    const int per_round = NT / lp;
     const int grp_slot = lp == 64 ? slot64 : (lp == 32 ? slot32 : slot16);
     int err = 0;
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
             gate_ptr G = gb + j * kGateRec;
 #pragma unroll
             for (int q = 0; q < PPT; q++) {
-                const int i = q * kThreads + tid;
-                if (q * kThreads < n) {  // wave-uniform
+                const int i = q * NT + tid;
+                if (q * NT < n) {  // wave-uniform
                     const double y0 = pr[q][0].x - G[37], y1 = pr[q][0].y - G[38], y2 = pr[q][1].x - G[39], y3 = pr[q][1].y - G[40],
                                  y4 = pr[q][2].x - G[41], y5 = pr[q][2].y - G[42];
                     double v[6];
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     int cls[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; q++) {
-        const int i = q * kThreads + tid, blk = q * kWaves + wave;
+        const int i = q * NT + tid, blk = q * (NT / 64) + wave;
         mybal[q] = 0;
         cls[q] = (i < n) ? bestj[q] + 1 : -1;
         if (blk < NB) {  // wave-uniform
@@ -454,13 +455,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
 #pragma unroll
         for (int q = 0; q < PPT; q++) pre[q] = 0;
         if (lane <= T) {
-            int v[PPT * kWaves];
+            int v[PPT * (NT / 64)];
 #pragma unroll
-            for (int b = 0; b < PPT * kWaves; b++) v[b] = b < NB ? L.cnt[b * CLS + lane] : 0;
+            for (int b = 0; b < PPT * (NT / 64); b++) v[b] = b < NB ? L.cnt[b * CLS + lane] : 0;
 #pragma unroll
-            for (int b = 0; b < PPT * kWaves; b++) {
+            for (int b = 0; b < PPT * (NT / 64); b++) {
 #pragma unroll
-                for (int q = 0; q < PPT; q++) if (b < q * kWaves + wave) pre[q] += v[b];
+                for (int q = 0; q < PPT; q++) if (b < q * (NT / 64) + wave) pre[q] += v[b];
                 tot += v[b];
             }
         }
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
         if (tid == 0) L.cls_off[T + 1] = run;
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
-            const int i = q * kThreads + tid;
+            const int i = q * NT + tid;
             const int cc = cls[q] < 0 ? 0 : cls[q];
             const int rank = __popcll(mybal[q] & lanemask_lt());  // rank inside its cloud's share of the block
             const int local_q = local[q] + rank, pos_q = pos[q] + rank;
@@ -539,36 +540,31 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     //      wins only if strictly smaller / larger") of tracks j = wave + 2 (mod 4): a lone large cloud has its sums on one
     //      wave and its min / max on another ----
     {
+        // (eight waves: the sums on waves 0..3, the min / max passes on waves 4..7; four waves: both on every wave)
+        const bool sum_wave = NT == 256 || wave < 4, mm_wave = NT == 256 || wave >= 4;
         const int grp = lane / 6, m = lane - grp * 6;
-        for (int jb = 0; jb < T; jb += 40) {
-            const int j = jb + grp * 4 + wave;
+        for (int jb = 0; sum_wave && jb < T; jb += 40) {
+            const int j = jb + grp * 4 + (wave & 3);
             const bool valid = lane < 60 && j < T;
             const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
             if (nj > 0) {
                 const double *col = p6 + m * NPs + off;
                 double sum = 0.0;
                 int r = 0;
-                double v[16], w[16];
-                if (nj >= 16) {
+                double v[8], w[8];
+                if (nj >= 8) {  // eight rows in flight, the next eight requested before these are added
 #pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = col[u];
-                    for (r = 16; r + 16 <= nj; r += 16) {
+                    for (int u = 0; u < 8; u++) v[u] = col[u];
+                    for (r = 8; r + 8 <= nj; r += 8) {
 #pragma unroll
-                        for (int u = 0; u < 16; u++) w[u] = col[r + u];
+                        for (int u = 0; u < 8; u++) w[u] = col[r + u];
 #pragma unroll
-                        for (int u = 0; u < 16; u++) sum += v[u];
+                        for (int u = 0; u < 8; u++) sum += v[u];
 #pragma unroll
-                        for (int u = 0; u < 16; u++) v[u] = w[u];
+                        for (int u = 0; u < 8; u++) v[u] = w[u];
                     }
 #pragma unroll
-                    for (int u = 0; u < 16; u++) sum += v[u];
-                }
-                if (r + 8 <= nj) {
-#pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = col[r + u];
-#pragma unroll
                     for (int u = 0; u < 8; u++) sum += v[u];
-                    r += 8;
                 }
                 {   // up to seven left
                     const int left = nj - r;
@@ -583,7 +579,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
         PROBE(10);
         // min / max: 24 lanes per track (six columns x four slices), two tracks per pass: tracks j = wave + 2 (mod 4)
         const int half = lane >= 32 ? 1 : 0, l5 = lane & 31, pi = l5 >> 2, slice = l5 & 3;  // (lanes 24..31 of a half idle)
-        for (int jb = (wave + 2) & 3; jb < T; jb += 8) {
+        for (int jb = NT == 256 ? (wave + 2) & 3 : wave - 4; mm_wave && jb < T; jb += 8) {
             const int j = jb + 4 * half;
             const bool valid = j < T && pi < 6;
             const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
@@ -647,7 +643,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     lds_barrier();
     PROBE(12);
     // ---- ... N_est, spread_est (Tracking.py:232-268), update_lifetime (400-407): a thread per (track, column) ----
-    for (int it = tid; it < T * 6; it += kThreads) {
+    for (int it = tid; it < T * 6; it += NT) {
         const int j = it / 6, m = it - j * 6;
         const int nj = L.cls_n[j + 1];
         TrackRec *rec = trk + L.slot[j];
@@ -702,7 +698,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     // status: sqrt(sum(centroid[3:6]^2)) < TR_VEL_THRES (Tracking.py:132-136) and BatchedData.add_frame on the track ring
     // (Tracking.py:43-51; the rows were written above): the LAST wave's threads, a track each -- the dispersion items below
     // fill the waves from the front
-    for (int j = kThreads - 1 - tid; j < T; j += kThreads) {
+    for (int j = NT - 1 - tid; j < T; j += NT) {
         const int nj = L.cls_n[j + 1];
         if (nj > 0) {
             TrackRec *rec = trk + L.slot[j];
@@ -754,7 +750,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
             rec_st(L, rec, j, rGd + a * 6 + b, (1 - al) * g_ab + al * D);
             if (a != b) rec_st(L, rec, j, rGd + b * 6 + a, (1 - al) * g_ba + al * D);
         };
-        for (int it = tid; it < (T + nleaf) * 21; it += kThreads) {
+        for (int it = tid; it < (T + nleaf) * 21; it += NT) {
             const int u = it / 21;
             int a, b;
             entry(it - u * 21, a, b);
@@ -772,7 +768,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
         }
         if (ncloud > 0) {  // uniform
             lds_barrier();
-            for (int it = tid; it < ncloud * 21; it += kThreads) {
+            for (int it = tid; it < ncloud * 21; it += NT) {
                 const int c = it / 21, e = it - c * 21;
                 int a, b;
                 entry(e, a, b);
@@ -851,7 +847,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
     int *grid = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 4096);
     unsigned long long *mm = reinterpret_cast<unsigned long long *>(grid + kCloudGrid);
     if (need) {  // uniform
-        for (int i = tid; i < kCloudGrid; i += kThreads) grid[i] = 0;
+        for (int i = tid; i < kCloudGrid; i += NT) grid[i] = 0;
         if (tid == 0) { grid[kCloudGrid] = 0; grid[kCloudGrid + 1] = 0; L.misc[12] = 0; }  // (mm[0] behind the grid)
         lds_barrier();
         // ---- apply_DBscan, first stage (Tracking.py:697, Utils.py:250-291): see k_track.hip ----
@@ -868,7 +864,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
             src.c1 = g_len > 1 ? gn[0] : big;
             src.c2 = g_len > 2 ? gn[0] + gn[1] : big;
             src.c3 = g_len > 3 ? gn[0] + gn[1] + gn[2] : big;
-            listed = !cloud_cells_prove_no_core_rows(cfg, src, U, mm, &L.misc[12], grid);
+            listed = !cloud_cells_prove_no_core_rows<NT>(cfg, src, U, mm, &L.misc[12], grid);
         }
         if (listed && U <= 256) {
             // second stage, the exact pair count (k_post does it for the bulk kernels): this thread still holds its point of
@@ -876,7 +872,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
             float4 *P4 = reinterpret_cast<float4 *>(L.work);                        // [256]
             int *pcnt = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 12288);  // [256], behind the grid
             unsigned long long *mm2 = reinterpret_cast<unsigned long long *>(pcnt + 256);   // [3]
-            listed = !cloud_pairs_prove_no_core_xyz<kThreads>(cfg, U, sx, sy, sz, P4, pcnt, mm2, &L.misc[11]);
+            listed = !cloud_pairs_prove_no_core_xyz<NT>(cfg, U, sx, sy, sz, P4, pcnt, mm2, &L.misc[11]);
         }
         if (listed) {
             // work list 3 = clouds <= 256 points (BallTree + _add_tracks), queue 1 = the larger ones: k_post's worker blocks
@@ -909,32 +905,34 @@ __global__ __launch_bounds__(kThreads, 2) void k_scene(DevCfg cfg, DevState st, 
 
 size_t scene_lds_bytes(const DevCfg &c) { return lds_layout<false>(c, nullptr, nullptr); }
 
-template <int PPT>
+template <int NT, int PPT>
 static void launch_scene_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc,
                            int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
     if (cfg.dx == 9)
-        mmw_launch(k_scene<PPT, 9>, dim3(cfg.n_scenes), dim3(kThreads), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
+        mmw_launch(k_scene<NT, PPT, 9>, dim3(cfg.n_scenes), dim3(NT), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
                    UM, parity);
     else
-        mmw_launch(k_scene<PPT, 6>, dim3(cfg.n_scenes), dim3(kThreads), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
+        mmw_launch(k_scene<NT, PPT, 6>, dim3(cfg.n_scenes), dim3(NT), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
                    UM, parity);
 }
 
+// (NT = 256: eight waves per scene were tried -- one point per thread, a wave per Kalman filter, sums and min / max on different
+//  waves.  Two such workgroups per CU leave 128 VGPRs per lane: the kernel spills 80 of them and ran 57 us instead of 45.)
 void launch_scene(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc,
                   int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
-    const int ppt = (cfg.max_pts + kThreads - 1) / kThreads;
-    if (ppt <= 1) launch_scene_t<1>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
-    else if (ppt == 2) launch_scene_t<2>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
-    else launch_scene_t<4>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    const int ppt = (cfg.max_pts + 255) / 256;
+    if (ppt <= 1) launch_scene_t<256, 1>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else if (ppt == 2) launch_scene_t<256, 2>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else launch_scene_t<256, 4>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
 }
 
 hipError_t prepare_scene(const DevCfg &cfg)
 {
     const int lds = (int)scene_lds_bytes(cfg);
-    const void *fns[6] = {(const void *)k_scene<1, 9>, (const void *)k_scene<2, 9>, (const void *)k_scene<4, 9>,
-                          (const void *)k_scene<1, 6>, (const void *)k_scene<2, 6>, (const void *)k_scene<4, 6>};
+    const void *fns[6] = {(const void *)k_scene<256, 1, 9>, (const void *)k_scene<256, 2, 9>, (const void *)k_scene<256, 4, 9>,
+                          (const void *)k_scene<256, 1, 6>, (const void *)k_scene<256, 2, 6>, (const void *)k_scene<256, 4, 6>};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;

@@ -78,6 +78,7 @@ struct mmw_ctx {
     hipEvent_t side_gate = nullptr;      // recorded on the context's stream at the head of a step: k_chain does not start before it
     int side_wanted = 0;                 // what the configuration / mmw_set_chain_side_stream asked for
     int fused_wanted = 0;                // the one-workgroup step (k_scene) is what this context runs unless a ring was resized or the side workers were asked for
+    int side_trusted = 0;                // mmw_config.chain_side_stream == 2: the side stream is used without the concurrency check
     int side_probed = 0;                 // the side streams have been checked against the current context stream (probe_side_streams)
     int32_t *d_probe = nullptr;          // [4] flag + results of that check
     int epoch = 0;                       // step number (queue protocol of list 3, k_dbscan.hip)
@@ -388,6 +389,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     }
     c->stream = c->own_stream;
     c->side_wanted = d.side_worker;
+    c->side_trusted = (d.side_worker && cfg->chain_side_stream >= 2) ? 1 : 0;   // 2: taken on trust (counter collection serialises kernels: the probe would say no)
+    c->side_probed = c->side_trusted;
     if (d.side_worker && create_side_streams(c) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     size_t lds_b = dbscan_only_lds_bytes(c->UM);
     for (int k = 0; k < 3; k++) { const size_t v = dbscan_lds_bytes(k, c->UM, cap, cfg->db_min_samples); if (v > lds_b) lds_b = v; }
@@ -526,7 +529,7 @@ int mmw_set_chain_side_stream(mmw_ctx *c, int32_t on)
     if (on && !c->side_stream) HIPCHK(c, create_side_streams(c));
     c->dc.side_worker = c->side_wanted = on ? 1 : 0;   // takes effect with the next mmw_step (the queues are empty between steps)
     c->dc.fused = (c->fused_wanted && !on && !c->dc.var_ring) ? 1 : 0;   // the workers claim scenes while k_track runs: the bulk kernels' step
-    c->side_probed = 0;
+    c->side_probed = c->side_trusted;
     return MMW_OK;
 }
 
@@ -537,7 +540,7 @@ int mmw_set_stream(mmw_ctx *c, void *s)
     hipStreamSynchronize(c->stream);
     c->stream = s ? (hipStream_t)s : c->own_stream;
     c->dc.side_worker = c->side_wanted;   // (checked against the new stream by the next mmw_step)
-    c->side_probed = 0;
+    c->side_probed = c->side_trusted;
     return MMW_OK;
 }
 

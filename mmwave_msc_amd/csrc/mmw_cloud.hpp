@@ -156,9 +156,10 @@ __device__ __forceinline__ bool cloud_cells_prove_no_core(const DevCfg &cfg, int
     return *flag == 0;
 }
 
-// Stage 1 for clouds of more than 256 points (up to 8 per thread: U <= 2048), rows read from the scene's global
+// Stage 1 for clouds of more than 256 points (U <= 2048; NT = threads of the workgroup), rows read from the scene's global
 // ring: a scene without tracks keeps three full frames of clutter in the ring, and without this its apply_DBscan
 // would pay the O(U^2) pair count of dbscan_core in every frame.  Same contract as above.
+template <int NT = 256>
 __device__ __forceinline__ bool cloud_cells_prove_no_core_rows(const DevCfg &cfg, const RowSrc src, int U, unsigned long long *mm,
                                                                int *flag, int *grid)
 {
@@ -168,7 +169,7 @@ __device__ __forceinline__ bool cloud_cells_prove_no_core_rows(const DevCfg &cfg
     if (!(min_samples > 1 && zw >= 0.0 && eps >= 0.0) || U > 8 * 256) return false;
     const double sqzw = sqrt(zw);
     double mag = 0.0;
-    for (int p = tid; p < U; p += 256) {
+    for (int p = tid; p < U; p += NT) {
         const double *r = src.row(p);
         const double2 a = *reinterpret_cast<const double2 *>(r);
         double m = fmax(fmax(fabs(a.x), fabs(a.y)), fabs(r[2] * sqzw));
@@ -185,14 +186,14 @@ __device__ __forceinline__ bool cloud_cells_prove_no_core_rows(const DevCfg &cfg
     const double h = 0.5 * R * (1.0 + 1e-3);
     if (!(h > 0.0) || !(M / h < 1e4)) return false;
     const float invh = (float)(1.0 / h);
-    for (int p = tid; p < U; p += 256) {
+    for (int p = tid; p < U; p += NT) {
         const double2 a = *reinterpret_cast<const double2 *>(src.row(p));
         const int cx = (int)floorf((float)a.x * invh) & 31, cy = (int)floorf((float)a.y * invh) & 31;
         atomicAdd(&grid[cy * 32 + cx], 1);
     }
     lds_barrier();
     bool maybe = false;
-    for (int p = tid; p < U; p += 256) {  // (rows again: they are in L2, and eight cell indices per thread would spill)
+    for (int p = tid; p < U; p += NT) {  // (rows again: they are in L2, and eight cell indices per thread would spill)
         const double2 a = *reinterpret_cast<const double2 *>(src.row(p));
         const int cx = (int)floorf((float)a.x * invh) & 31, cy = (int)floorf((float)a.y * invh) & 31;
         int c = 0;

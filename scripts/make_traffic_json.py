@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json (what bench.py quotes as roofline.traffic) from the PMC summaries of scripts/gpu_round.sh pmc / pmc512:
+    python scripts/make_traffic_json.py profiles/r03a_pmc_summary.json profiles/r03a_pmc512_summary.json > profiles/traffic.json"""
+import json
+import sys
+
+KEYS = {"k_track": "k_track", "k_scene": "k_track", "k_predict": "k_predict", "k_post": "k_post", "k_dbscan_big": "k_dbscan_big", "k_chain": "k_chain"}
+
+
+def table(path):
+    out = {}
+    for name, v in json.load(open(path)).items():
+        base = name.split("<")[0]
+        if base not in KEYS:
+            continue
+        ent = {"hbm_bytes_per_launch_raw": v["hbm_bytes_per_launch_raw"], "hbm_bytes_per_launch_fetch_x2": v["hbm_bytes_per_launch_x2"],
+               "fetch_raw": v["fetch_bytes_per_launch_raw"], "write": v["write_bytes_per_launch"], "kernel": name}
+        out[KEYS[base]] = ent   # (bench.py asks by the profile id's name: k_scene is timed under K_TRACK)
+    return out
+
+
+big, small = sys.argv[1], sys.argv[2]
+res = {"4096x512x8": table(big), "512x512x8": table(small),
+       "source": f"{big} / {small}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --no-cpu --no-e2e --no-e2e-parity "
+                 f"--no-cold --no-shards --no-full --steps 10 --warmup 10 (--chain-side-stream 2 at 4096 scenes, --scenes 512 for the shard)",
+       "_note": "KiB -> bytes; read side given raw and x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads: MI355X_MICROARCH.md). "
+                "Counter collection serialises the dispatches: with --chain-side-stream 2 the chain workers are launched all the same (k_chain has its "
+                "entry) but, alone on the chip, find nothing to claim and leave after their idle polls -- the DBSCAN bytes they move in the benchmarked "
+                "schedule are k_post's / k_dbscan_big's here; the step's total does not depend on who moves them, and k_track, the roofline kernel, "
+                "runs the same code with or without their company."}
+print(json.dumps(res, indent=1))

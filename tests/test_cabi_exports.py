@@ -114,7 +114,7 @@ def test_gate_records_are_not_read_before_the_scalar_cache_invalidate():
         import pytest
         pytest.skip("hipcc not available")
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmwave_msc_amd", "csrc")
-    for src, pat, allowed_before in (("k_track.hip", r"^(_ZN3mmw7k_trackILi\dELb[01]ELb1EE\S*):", 0), ("k_scene.hip", r"^(_ZN3mmw7k_sceneILi\dELi\dEE\S*):", 1)):
+    for src, pat, allowed_before in (("k_track.hip", r"^(_ZN3mmw7k_trackILi\dELb[01]ELb1EE\S*):", 0), ("k_scene.hip", r"^(_ZN3mmw7k_sceneILi\d+ELi\dELi\dEE\S*):", 1)):
         asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S",
                               "-c", os.path.join(root, src), "-o", "-"], capture_output=True, text=True, timeout=900).stdout
         names = re.findall(pat, asm, flags=re.M)
