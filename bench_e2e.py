@@ -75,10 +75,10 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
         peak = MFMA_FP16_PEAK_TF if split else MFMA_FP32_PEAK_TF
         res = {
             "value": round(S * world * K / el, 1), "unit": "scene-frames/s", "ms_per_step": round(el / K * 1e3, 4),
-            "samples_per_step": round(rows / max(K, 1), 1), "samples_per_s": round(rows / el, 1),
+            "samples_per_step": round(rows / max(K, 1), 1), "samples_per_s": round(rows / el, 1), "streams": pipe.overlap_note,
             "cnn_ms_per_step": round(cnn_ms, 4) if cnn_ms is not None else None,
             "cnn_arith": ("f32 results from fp16 matrix cores: every fp32 operand split hi + 2^-11 lo' (fp16 halves), each product = 3 "
-                          "exact partial products, fp32 accumulation (k_mars_conv16 + two fp16 GEMMs); closer to the fp64 oracle than "
+                          "exact partial products, fp32 accumulation (k_mars_conv16 + k_mars_dense1, this package's kernels); closer to the fp64 oracle than "
                           "fp32 arithmetic") if split else "fp32 on the fp32 matrix cores throughout (k_mars_conv + fp32 GEMM)",
             "roofline_cnn": {"bound": "mfma", "dtype": "f16 x3 (fp32-exact split)" if split else "f32",
                              "achieved": round(rows * issued / el / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
@@ -102,7 +102,7 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
     best = dict(out[(first, "f16x3")])
     best["mode"] = first + " -- " + modes[first]
     best["other_schedule"] = {"mode": second + " -- " + modes[second],
-                              **{k: out[(second, "f16x3")][k] for k in ("value", "ms_per_step", "cnn_ms_per_step")}}
+                              **{k: out[(second, "f16x3")][k] for k in ("value", "ms_per_step", "cnn_ms_per_step", "streams")}}
     best["fp32_dense1"] = {"mode": "serial", **{k: out[("serial", "f32")][k] for k in ("value", "ms_per_step", "cnn_ms_per_step", "cnn_arith")}}
     best["config"] = (f"{S * world} scenes, track -> features -> MARS CNN (random Keras-layout weights) -> keypoints every frame; "
                       f"BASELINE.json configs[4] shape at {world} GPU(s)")

@@ -344,6 +344,11 @@ int mmw_stats_reset(mmw_ctx *ctx);
  * queue with the context's stream: checked by the first mmw_step after mmw_create / mmw_set_stream /
  * mmw_set_chain_side_stream), 1 = yes, 2 = configured, not checked yet (no step since). */
 int mmw_side_workers(mmw_ctx *ctx);
+/* Do kernels queued on stream_b run while a kernel on stream_a is still running?  1 = yes, 0 = no: the HIP runtime multiplexes
+ * streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default, dealt round-robin at stream creation), and two streams
+ * that share one execute in order.  Callers that overlap their own work with the context's (the CNN beside the tracker:
+ * posture.PosturePipeline) pick their second stream with this.  Synchronises both streams; ~20 us when they are independent. */
+int mmw_streams_concurrent(mmw_ctx *ctx, void *stream_a, void *stream_b);
 /* Which kernels the next mmw_step launches for TrackBuffer.track (Tracking.py:683-703): 1 = the one-workgroup step (k_scene: a
  * scene's whole track() in one workgroup, then the DBSCAN worker blocks of k_post; contexts whose scenes are all resident at
  * once, mmw_config.fused_step), 2 = two launches (k_track with _predict_all at its head, k_post), 4 = the bulk kernels

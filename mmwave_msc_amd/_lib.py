@@ -32,7 +32,7 @@ EXPORTS = [
     "mmw_get_batch_ring_frame", "mmw_track_table", "mmw_profile_enable", "mmw_profile_reset", "mmw_profile_get",
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
-    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_reset_scenes", "mmw_get_errors",
+    "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
 ]
 
 
@@ -173,6 +173,7 @@ def load():
         "mmw_diag_queue": (C.c_int, [vp, vp]),
         "mmw_side_workers": (C.c_int, [vp]),
         "mmw_step_kind": (C.c_int, [vp]),
+        "mmw_streams_concurrent": (C.c_int, [vp, vp, vp]),
         "mmw_reset_scenes": (C.c_int, [vp, vp]),
         "mmw_get_errors": (C.c_int, [vp, vp]),
         "mmw_set_chain_side_stream": (C.c_int, [vp, i32]),

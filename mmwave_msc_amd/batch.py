@@ -124,6 +124,13 @@ class SceneBatch:
         self._chk(self.L.mmw_diag_queue(self.h, out.ctypes.data))
         return out
 
+    def streams_concurrent(self, stream_a: int, stream_b: int) -> bool:
+        """mmw_streams_concurrent: do kernels on HIP stream b (raw handles) run beside a running kernel of stream a?"""
+        rc = int(self.L.mmw_streams_concurrent(self.h, stream_a, stream_b))
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
+
     def step_kind(self) -> int:
         """mmw_step_kind: 1 = the one-workgroup step (k_scene), 2 = two launches, 4 = the bulk kernels."""
         return int(self.L.mmw_step_kind(self.h))

@@ -1031,6 +1031,14 @@ int mmw_side_workers(mmw_ctx *c)
     if (!c) return MMW_E_ARG;
     return c->dc.side_worker ? (c->side_probed ? 1 : 2) : 0;
 }
+int mmw_streams_concurrent(mmw_ctx *c, void *stream_a, void *stream_b)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ok = probe_one(c, (hipStream_t)stream_b, (hipStream_t)stream_a);
+    if (ok < 0) return fail(c, MMW_E_HIP, "mmw_streams_concurrent: probe failed: %s", hipGetErrorString(hipGetLastError()));
+    return ok;
+}
 int mmw_step_kind(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;

@@ -7,13 +7,16 @@ thousands of scenes the CNN (matrix cores) takes ~15x the tracker (vector ALUs /
 the two do not compete for the same units, so frame f's CNN runs on a second stream while
 frame f+1 is tracked:
 
-    tracker stream A:  step(f) feat(f) | wait cnn(f-1) scatter(f-1) | step(f+1) feat(f+1) | ...
-    CNN stream     B:                  wait feat(f-1)  cnn(f-1)     | wait feat(f) cnn(f) | ...
+    tracker stream A:  step(f) feat(f) | wait cnn(f-2) scatter(f-2) | step(f+1) feat(f+1) | wait cnn(f-1) scatter(f-1) | ...
+    CNN stream     B:  ... cnn(f-2) | wait feat(f-1) cnn(f-1) | wait feat(f) cnn(f) | ...
 
-* `mmw_features_async` leaves the row count in pinned host memory; the host waits for THAT
-  copy only (it completed a frame ago), so the GEMMs get their exact batch size and the GPU
-  never drains.
-* The scatter of frame f-1 runs after frame f was tracked, when list positions may have moved
+* `mmw_features_async` leaves the row count in pinned host memory; the host waits for THAT copy only, so the matrix
+  kernels get their exact batch size.  The CNN of frame f-1 is queued as soon as the count of frame f-1 is there -- i.e.
+  behind the CNN of frame f-2, which is still running: stream B never runs dry.  For that the tracker stream must not sit
+  behind the CNN that is running NOW, so the scatter lags TWO frames (three buffers): with a lag of one, `feat(f-1)` was
+  queued behind `wait cnn(f-2)`, the host got its count only after that CNN had ended, and every step paid tracker +
+  features + CNN in sequence (1.72 ms at 4096 scenes where the CNN alone is 1.34).
+* The scatter of frame f-2 runs after frame f was tracked, when list positions may have moved
   (`_maintain_tracks`), so it matches tracks by creation ordinal (`mmw_set_keypoints_uid`);
   it runs on the TRACKER stream, so it cannot race a spawn re-using a record.
 * The tracker never reads keypoints, so after `drain()` every live track holds exactly what the
@@ -31,8 +34,24 @@ class PosturePipeline:
         self.sb, self.model, self.cap = sb, model, int(cap_rows)
         self.dev = torch.device("cuda", sb.device)
         self.A = tracker_stream if tracker_stream is not None else torch.cuda.Stream(device=self.dev)
-        self.B = (cnn_stream if cnn_stream is not None else torch.cuda.Stream(device=self.dev)) if overlap else self.A
         sb.follow_torch_stream(self.A)
+        self.B = self.A
+        self.overlap_note = "one stream"
+        if overlap:
+            # A second stream only overlaps if it sits on another hardware queue (the runtime deals streams onto ~4 of them):
+            # a few candidates are probed (mmw_streams_concurrent), and without an independent one the schedule is serial
+            cands = [cnn_stream] if cnn_stream is not None else []
+            self._spare = []
+            for _ in range(8):
+                st = cands.pop(0) if cands else torch.cuda.Stream(device=self.dev)
+                if sb.streams_concurrent(self.A.cuda_stream, st.cuda_stream):
+                    self.B = st
+                    self.overlap_note = "two streams on independent hardware queues"
+                    break
+                self._spare.append(st)   # (kept alive: a freed stream would hand its queue slot to the next candidate)
+            else:
+                self.overlap_note = "no stream on an independent hardware queue found: serial"
+            sb.follow_torch_stream(self.A)
         # with the CNN on its own stream beside the tracker, the tracker's own side-stream workers (k_chain) only take
         # compute units from the statically tiled matrix kernels: off in that schedule -- if the library had them on
         # (mmw_side_workers; its choice, not re-derived here) --, and back on when the pipeline is drained
@@ -41,18 +60,24 @@ class PosturePipeline:
             sb.set_chain_side_stream(False)
         self.range_overflowed = False   # the split-fp16 CNN met an input / activation outside fp16's range (see drain())
         shape = (self.cap, sb.ring, 8, 8, 5) if sb.ring > 1 else (self.cap, 8, 8, 5)
+        # frame f uses buffer f % NBUF; the scatter of a frame follows its CNN at once on one stream (lag 1), two frames
+        # later on two (see the module docstring)
+        self.NBUF = 3
+        self.lag = 2 if self.B is not self.A else 1
         with torch.cuda.stream(self.A):
-            self.feat = [torch.zeros(shape, dtype=torch.float32, device=self.dev) for _ in range(2)]
-            self.owner = [torch.zeros((self.cap, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
-            self.uid = [torch.zeros((self.cap,), dtype=torch.int32, device=self.dev) for _ in range(2)]
-            self.kp = [torch.zeros((self.cap, NKP), dtype=torch.float32, device=self.dev) for _ in range(2)]
+            self.feat = [torch.zeros(shape, dtype=torch.float32, device=self.dev) for _ in range(self.NBUF)]
+            self.owner = [torch.zeros((self.cap, 2), dtype=torch.int32, device=self.dev) for _ in range(self.NBUF)]
+            self.uid = [torch.zeros((self.cap,), dtype=torch.int32, device=self.dev) for _ in range(self.NBUF)]
+            self.kp = [torch.zeros((self.cap, NKP), dtype=torch.float32, device=self.dev) for _ in range(self.NBUF)]
         self.A.synchronize()
-        self.ev_feat = [torch.cuda.Event() for _ in range(2)]
-        self.ev_cnn = [torch.cuda.Event() for _ in range(2)]
+        self.ev_feat = [torch.cuda.Event() for _ in range(self.NBUF)]
+        self.ev_cnn = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.time_cnn = bool(time_cnn)
         self._cnn_pairs = []       # (start, stop) timing events around model() on the CNN stream
         self.f = 0                 # frames submitted
-        self.rows = [0, 0]
+        self.cnn_done = 0          # frames whose CNN has been queued
+        self.scattered = 0         # frames whose keypoints have been scattered
+        self.rows = [0] * self.NBUF
         self.rows_total = 0        # feature tensors pushed through the CNN since construction / reset_counters()
 
     def reset_counters(self):
@@ -66,8 +91,9 @@ class PosturePipeline:
         self.B.synchronize()
         return sum(a.elapsed_time(b) for a, b in self._cnn_pairs) / len(self._cnn_pairs)
 
-    def _finish(self, d: int):
-        """CNN + scatter of the frame whose features sit in buffer d."""
+    def _cnn(self, g: int):
+        """queue the CNN of frame g (its features sit in buffer g % NBUF) on the CNN stream"""
+        d = g % self.NBUF
         n = self.sb.features_wait(ticket=d)
         self.rows[d] = n
         self.rows_total += n
@@ -83,23 +109,38 @@ class PosturePipeline:
                 pair[1].record(self.B)
                 self._cnn_pairs.append(pair)
             self.ev_cnn[d].record(self.B)
+
+    def _scatter(self, g: int):
+        """keypoints of frame g into the tracks that still exist, on the tracker stream behind that frame's CNN"""
+        d = g % self.NBUF
+        n = self.rows[d]
+        if n == 0:
+            return
         self.A.wait_event(self.ev_cnn[d])
         self.sb.set_keypoints_uid_dev(self.kp[d].data_ptr(), self.owner[d].data_ptr(), self.uid[d].data_ptr(), n)
 
     def after_step(self):
         """Call once after every `sb.step_dev(...)` (issued on the tracker stream)."""
-        d = self.f & 1
+        d = self.f % self.NBUF
         self.sb.features_async(self.feat[d].data_ptr(), self.owner[d].data_ptr(), self.uid[d].data_ptr(), self.cap, ticket=d)
         self.ev_feat[d].record(self.A)
-        if self.f > 0:
-            self._finish(d ^ 1)
         self.f += 1
+        while self.cnn_done < self.f - 1:           # the CNN of the frame before this one
+            self._cnn(self.cnn_done)
+            self.cnn_done += 1
+        while self.scattered < self.f - self.lag:   # ... and the scatter of the frame `lag` back
+            self._scatter(self.scattered)
+            self.scattered += 1
 
     def drain(self):
-        """CNN + scatter of the last submitted frame; afterwards the keypoints are those of the reference loop."""
-        if self.f > 0:
-            self._finish((self.f - 1) & 1)
-        self.f = 0
+        """CNN + scatter of every submitted frame that has not had them; afterwards the keypoints are those of the reference loop."""
+        while self.cnn_done < self.f:
+            self._cnn(self.cnn_done)
+            self.cnn_done += 1
+        while self.scattered < self.f:
+            self._scatter(self.scattered)
+            self.scattered += 1
+        self.f = self.cnn_done = self.scattered = 0
         self.A.synchronize()
         self.B.synchronize()
         if self._side_was_on and self.B is not self.A:
