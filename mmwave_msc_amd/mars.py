@@ -80,7 +80,7 @@ class MarsCNN(nn.Module):
         "f16x3" every fp32 operand split as a = hi + 2^-11 lo' (hi, lo' fp16) and a.w = hi.w_hi + 2^-11 (hi.w_lo' + lo'.w_hi)
                 on the fp16 matrix cores with fp32 accumulation (k_mars_conv16 + k_mars_dense1, both this package's kernels):
                 every partial product is exact, the dropped lo'.lo' term is 2^-22 relative, and the result is CLOSER to the
-                fp64 oracle than fp32 arithmetic (Dense-1 outputs: 1.2e-6 vs 2.5e-6 max error, scripts/exp_split_gemm.py).
+                fp64 oracle than fp32 arithmetic (Dense-1 outputs: 1.2e-6 vs 2.5e-6 max error, measured in round 2).
                 Not a reduced-precision mode: fp16 storage never holds a value that is not re-completed by its lo' half --
                 WITHIN fp16's range: |a| < 65 504.  Weights outside it make from_keras_weights fall back to "f32"; an input
                 or activation outside it raises the conv kernel's range word (range_overflow(): that sample's outputs are
