@@ -80,9 +80,10 @@ __device__ __forceinline__ void update_math(TrackRec *rec, bool live, const doub
             if (den == 0.0) err |= ERR_DIVZERO;
             const double coef = (nest - N) / den;
             const double hh = R[rSpr + c] / 2;
+            const double dg = (hh * hh) / N;   // Rm[c][c] / N; the off-diagonal 0 / N is +0 (N >= 1): one division, same bits
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                const double rc = ((i == c) ? hh * hh : 0.0) / N + coef * R[rGd + i * 6 + c];
+                const double rc = ((i == c) ? dg : 0.0) + coef * R[rGd + i * 6 + c];
                 W[wRc + i * 6 + c] = rc;
                 v[i] = Pw[i * 9 + c] + rc;  // S = H P H^T + R
             }

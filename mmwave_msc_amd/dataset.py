@@ -11,6 +11,8 @@ tracker inside `preprocess_experiment` is the GPU `TrackBuffer`.
   preprocess_experiment    one pass of preprocess_dataset()'s loop body                    preprocessing.py:148-275
   format_mmwave_to_npy,
   format_kinect_to_npy     pre-processed CSVs -> `<mode>_mmWave.npy` / `<mode>_labels.npy`  preprocessing.py:298-384
+  split_sets               experiments into training / validate / testing by name prefix    preprocessing.py:406-468
+  add_noise                jittered copies `N_<experiment>` of the training experiments     preprocessing.py:471-509
 
 Text output is written the way the reference writes it (pandas `to_csv`, `csv.writer`, `str(float)`), so that files
 compare byte for byte (tests/test_dataset.py: outputs recorded from the reference's own functions on a synthetic
@@ -224,3 +226,60 @@ def format_kinect_to_npy(kinect_directory: str, out_file: str) -> np.ndarray:
     out = np.array(rows)
     np.save(out_file, out)
     return out
+
+
+def split_sets(directories, prefixes) -> None:
+    """preprocessing.py:406-468: under each of `directories` (the pre-processed Kinect and mmWave trees) copy every
+    experiment -- a directory of CSV shards or a single CSV file -- into `validate/`, `testing/` or `training/`: the first
+    list of `prefixes` names the validation experiments, the second the test experiments (substring match on the name, as the
+    reference's `str.find`), everything else trains.  Existing mode directories are replaced (the reference removes them
+    first and fails when one is missing; here a missing one is simply created)."""
+    validate_prefix, testing_prefix = prefixes[0], prefixes[1]
+    modes = ("training", "validate", "testing")
+    for directory in directories:
+        for mode in modes:
+            shutil.rmtree(os.path.join(directory, mode), ignore_errors=True)
+    for directory in directories:
+        experiments = os.listdir(directory)
+        for mode in modes:
+            os.makedirs(os.path.join(directory, mode))
+        for experiment in experiments:
+            if any(experiment.find(mode) != -1 for mode in modes):
+                continue
+            source = os.path.join(directory, experiment)
+            if any(experiment.find(prefix) != -1 for prefix in validate_prefix):
+                mode = "validate"
+            elif any(experiment.find(prefix) != -1 for prefix in testing_prefix):
+                mode = "testing"
+            else:
+                mode = "training"
+            target = os.path.join(directory, mode, experiment)
+            if os.path.isdir(source):
+                shutil.copytree(source, target)
+            else:
+                shutil.copy(source, target)
+
+
+def add_noise(mmwave_training_dir: str, kinect_training_dir: str, mean: float = 0.0, std: float = 0.022, rng=None) -> None:
+    """preprocessing.py:471-509: for every training experiment a copy `N_<experiment>` whose mmWave rows have Gaussian noise
+    (sigma 2.2 cm) added to the non-zero x, y, z fields -- columns 1..3 of the pre-processed CSVs --, one draw per value in file
+    and row order; the Kinect labels of the copy are the original's.  `rng` = anything with `normal(loc=, scale=)`; the default
+    is numpy's global generator, which the reference uses (so `np.random.seed(s)` reproduces its files byte for byte)."""
+    rng = np.random if rng is None else rng
+    for experiment in os.listdir(mmwave_training_dir):
+        input_path = os.path.join(mmwave_training_dir, experiment)
+        distorted_path = os.path.join(mmwave_training_dir, f"N_{experiment}")
+        if os.path.exists(distorted_path):
+            shutil.rmtree(distorted_path)
+        os.mkdir(distorted_path)
+        for filename in os.listdir(input_path):
+            with open(os.path.join(input_path, filename), "r") as fh:
+                rows = list(csv.reader(fh))
+            for row in rows:
+                for i in range(1, 4):
+                    if float(row[i]) != 0:
+                        row[i] = str(float(row[i]) + rng.normal(loc=mean, scale=std))
+            with open(os.path.join(distorted_path, filename), "w", newline="") as fh:
+                csv.writer(fh).writerows(rows)
+    for experiment in os.listdir(kinect_training_dir):
+        shutil.copyfile(os.path.join(kinect_training_dir, experiment), os.path.join(kinect_training_dir, f"N_{experiment}"))

@@ -549,6 +549,66 @@ def gen_preprocess():
     print(f"  preprocess: {len(pairs)} pairs, {len(cen)} valid frames, files {pre_files}, mmWave {fm.shape}, labels {fk.shape}")
 
 
+def _splitsets_tree(root):
+    """A small pre-processed tree: experiments A1, A4, B2, B7 (mmWave: directories of two CSV shards; Kinect: one CSV each).
+    Deterministic content, a few exact zeros in the coordinate columns (add_noise leaves them alone)."""
+    rng = np.random.default_rng(99)
+    for name in ("A1", "A4", "B2", "B7"):
+        os.makedirs(os.path.join(root, "mmWave", name))
+        for k in (1, 2):
+            rows = []
+            for r in range(6):
+                v = rng.normal(0, 1, 3).round(4)
+                if (r + k) % 4 == 0:
+                    v[r % 3] = 0.0
+                rows.append(f"{r},{v[0]},{v[1]},{v[2]},{float(rng.normal(20, 5)):.3f}")
+            with open(os.path.join(root, "mmWave", name, f"{k}.csv"), "w") as fh:
+                fh.write("\n".join(rows) + "\n")
+        os.makedirs(os.path.join(root, "kinect"), exist_ok=True)
+        with open(os.path.join(root, "kinect", f"{name}.csv"), "w") as fh:
+            fh.write("".join(f"{i},{float(rng.normal()):.5f}\n" for i in range(4)))
+
+
+def _tree_dump(root):
+    out = {}
+    for base, _, files in os.walk(root):
+        for f in files:
+            p = os.path.join(base, f)
+            out[os.path.relpath(p, root)] = open(p, newline="").read()
+    return out
+
+
+def gen_splitsets():
+    """split_sets / add_noise (src/preprocessing.py:406-509) on a synthetic pre-processed tree, numpy's global generator
+    seeded: the resulting tree, file by file."""
+    import csv as _csv
+    import json as _json
+    import shutil as _shutil
+    const, utils, tracking = load_reference()
+    saved = {k: getattr(const, k) for k in ("P_PREPROCESS_PATH", "P_KINECT_DIR", "P_MMWAVE_DIR")}
+    prefixes = [["A4"], ["B7"]]
+    with tempfile.TemporaryDirectory() as d:
+        try:
+            _splitsets_tree(d)
+            for sub in ("kinect", "mmWave"):   # the reference removes the mode directories first and needs them to exist
+                for mode in ("training", "validate", "testing"):
+                    os.makedirs(os.path.join(d, sub, mode))
+            const.P_PREPROCESS_PATH, const.P_KINECT_DIR, const.P_MMWAVE_DIR = d + "/", "kinect/", "mmWave/"
+            ns = {"np": np, "os": os, "csv": _csv, "shutil": _shutil, "const": const}
+            ref = _reference_functions(os.path.join(os.path.dirname(const.__file__), "preprocessing.py"), {"split_sets", "add_noise"}, ns)
+            ref["split_sets"](prefixes)
+            after_split = _tree_dump(d)
+            np.random.seed(20241003)
+            ref["add_noise"]()
+            after_noise = _tree_dump(d)
+        finally:
+            for k, v in saved.items():
+                setattr(const, k, v)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "splitsets.npz"), prefixes=_json.dumps(prefixes), after_split=_json.dumps(after_split, sort_keys=True),
+                        after_noise=_json.dumps(after_noise, sort_keys=True), seed=20241003, meta=_meta())
+    print(f"  splitsets: {len(after_split)} files after split_sets, {len(after_noise)} after add_noise")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -573,6 +633,8 @@ def main():
         gen_uart()
     if not args.only or args.only == "preprocess":
         gen_preprocess()
+    if not args.only or args.only == "splitsets":
+        gen_splitsets()
     if not args.only or args.only == "popframe":
         gen_popframe()
     return 0

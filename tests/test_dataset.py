@@ -98,3 +98,37 @@ def test_preprocess_experiment_writes_the_reference_files(logs, gold):
     assert (out_kin / "A1.csv").read_bytes().decode() == str(gold["kinect_out"])
     assert np.array_equal(cen, gold["centroids"])
     assert np.array_equal(np.load(tmp / "A1_centroid.npy"), gold["centroids"])
+
+
+def test_split_sets_and_add_noise_give_the_reference_tree(tmp_path):
+    """split_sets / add_noise (preprocessing.py:406-509) on the synthetic pre-processed tree of tests/golden/splitsets.npz:
+    the tree the reference's own functions left (recorded by oracle/gen_golden.py with numpy's global generator seeded),
+    file by file and byte for byte."""
+    import json
+    from mmwave_msc_amd import dataset
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "splitsets.npz"))
+    after_split, after_noise = json.loads(str(z["after_split"])), json.loads(str(z["after_noise"]))
+    modes = ("training", "validate", "testing")
+    for rel, txt in after_split.items():          # the input tree = what is not under a mode directory
+        if rel.split(os.sep)[1] in modes:
+            continue
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        with open(p, "w", newline="") as fh:
+            fh.write(txt)
+
+    def dump():
+        out = {}
+        for base, _, files in os.walk(tmp_path):
+            for f in files:
+                q = os.path.join(base, f)
+                out[os.path.relpath(q, tmp_path)] = open(q, newline="").read()
+        return out
+
+    dataset.split_sets([str(tmp_path / "kinect"), str(tmp_path / "mmWave")], json.loads(str(z["prefixes"])))
+    assert dump() == after_split
+    np.random.seed(int(z["seed"]))
+    dataset.add_noise(str(tmp_path / "mmWave" / "training"), str(tmp_path / "kinect" / "training"))
+    got = dump()
+    assert sorted(got) == sorted(after_noise)
+    assert got == after_noise
