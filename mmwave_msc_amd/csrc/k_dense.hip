@@ -26,7 +26,9 @@
 // issued, with the MFMAs switched off the staging alone takes 0.88 of the 1.12 ms: the 8.1 GB a 256 x 128 tile moves from L2
 // to LDS (two accumulator sets cap the tile: 256 x 256 needs 256 accumulator registers per lane at 2 waves per SIMD).  The two
 // library GEMMs move the same bytes and take the same time.  Whole 128-byte lines per row (this layout) and an activation row
-// stride that is not a multiple of 4 KB (mars.py) are worth 6 % and 4 %.
+// stride that is not a multiple of 4 KB (mars.py) are worth 6 % and 4 %.  (One accumulator set -- main scaled by 2^11 through a
+// third weight array -- allows 256 x 256 tiles: 0.97 instead of 1.05 ms, but three roundings of the accumulator per K-step
+// instead of one made the keypoints less accurate than the fp32 path's on the stress inputs: measured, not kept.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
