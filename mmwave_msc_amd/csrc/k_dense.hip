@@ -40,11 +40,13 @@ typedef float df16 __attribute__((ext_vector_type(16)));
 namespace dense {
 constexpr int BM = 256, BN = 128, BK = 32, kThreads = 512;
 constexpr int kRowBytes = BK * 2 * 2;              // 128 B of a tile row: hi (64 B) | lo' (64 B)
-constexpr int kATile = BM * kRowBytes;             // 32 KB
 constexpr int kWTile = BN * kRowBytes;             // 16 KB
-constexpr int kBuf = kATile + kWTile;              // 48 KB per K-step
-constexpr int kStages = 3;                          // LDS ring: the tile in use + two in flight (144 KB)
-constexpr int kLds = kStages * kBuf;
+constexpr int kStages = 3;                          // LDS ring: the tile in use + two in flight
+// TBM = batch rows of a tile: 256 (8 waves as 4 x 2, a wave owns 64 x 64), or 128 for the tail of the tile list (8 waves as
+// 2 x 4, a wave owns 64 x 32): a last wave of workgroups that fills less than half the chip runs as twice as many half tiles
+constexpr int a_tile(int tbm) { return tbm * kRowBytes; }                         // 32 / 16 KB
+constexpr int buf_bytes(int tbm) { return a_tile(tbm) + kWTile; }                 // 48 / 32 KB per K-step
+constexpr int lds_bytes(int tbm) { return kStages * buf_bytes(tbm); }             // 144 / 96 KB
 constexpr float kInvSplit = 1.0f / 2048.0f;
 
 // 16-byte unit (row, c) of a tile image -> byte offset (c = 0..7: the row's eight units, 0..3 = hi, 4..7 = lo')
@@ -59,26 +61,31 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base)
 
 using namespace dense;
 
+template <int TBM>
 __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
                                                              long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
-                                                             int tiles_m, int tiles_n)
+                                                             long long row0, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int WN = TBM == 256 ? 2 : 4;          // waves along the features; 8 / WN along the batch rows, 64 rows each
+    constexpr int NT = BN / WN / 32;                 // MFMA tiles of a wave along the features (2 or 1); two along the rows
+    constexpr int CA = TBM / 64;                     // DMA chunks of the A tile per wave (4 or 2); the W tile: 2
+    constexpr int kATile = a_tile(TBM), kBuf = buf_bytes(TBM);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: workgroups are dealt to the eight XCDs round-robin; a group of consecutive LOGICAL tiles (one band of
     // batch rows against all feature tiles) goes to one XCD, whose L2 then serves the band's activations to every tile of it
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long long m0 = (long long)tm * BM;
+    const long long m0 = row0 + (long long)tm * TBM;
     const int n0 = tn * BN;
     // ---- this lane's share of a tile's DMA: unit u = chunk * 64 + lane of an operand tile; chunk = one wave instruction ----
-    // A: 32 chunks (8 waves x 4); W: 16 chunks (8 waves x 2).  A K-step advances every source by 64 halves (hi 32 | lo' 32).
-    const _Float16 *srcA[4], *srcW[2];
+    // A: TBM / 8 chunks (8 waves x CA); W: 16 chunks (8 waves x 2).  A K-step advances every source by 64 halves (hi 32 | lo' 32).
+    const _Float16 *srcA[CA], *srcW[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int u = (wave * 4 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < CA; i++) {
+        const int u = (wave * CA + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
         srcA[i] = a2 + (m0 + row) * lda + c * 8;
     }
 #pragma unroll
@@ -90,24 +97,24 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
         char *b = lds + buf * kBuf;
         const int k0 = kt * (2 * BK);
 #pragma unroll
-        for (int i = 0; i < 4; i++) glds16(srcA[i] + k0, b + (wave * 4 + i) * 1024);
+        for (int i = 0; i < CA; i++) glds16(srcA[i] + k0, b + (wave * CA + i) * 1024);
 #pragma unroll
         for (int i = 0; i < 2; i++) glds16(srcW[i] + k0, b + kATile + (wave * 2 + i) * 1024);
     };
     // ---- fragment addresses: lane (row = l & 31, k-group g = l >> 5) reads unit c = 2 kk + g (hi) and 4 + 2 kk + g (lo') ----
-    int offA[2][2], offW[2][2];   // [tile][kk]
+    int offA[2][2], offW[NT][2];   // [tile][kk]
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+        for (int x = 0; x < 2; x++) offA[x][kk] = unit_off(wm * 64 + x * 32 + (lane & 31), kk * 2 + (lane >> 5));
+#pragma unroll
+        for (int y = 0; y < NT; y++) offW[y][kk] = unit_off(wn * (32 * NT) + y * 32 + (lane & 31), kk * 2 + (lane >> 5));
+    }
+    df16 am[2][NT], ac[2][NT];
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            offA[x][kk] = unit_off(wm * 64 + x * 32 + (lane & 31), kk * 2 + (lane >> 5));
-            offW[x][kk] = unit_off(wn * 64 + x * 32 + (lane & 31), kk * 2 + (lane >> 5));
-        }
-    df16 am[2][2], ac[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; x++)
-#pragma unroll
-        for (int y = 0; y < 2; y++)
+        for (int y = 0; y < NT; y++)
 #pragma unroll
             for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
 
@@ -120,30 +127,36 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
     if (KT > 1) issue(1, 1);
     int cur = 0;
     for (int kt = 0; kt < KT; kt++) {
-        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt has landed (this wave's share)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < KT) {                                                   // tile kt has landed (this wave's share: CA + 2 requests per tile)
+            if constexpr (CA == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                        // ... everyone's share; buffer of tile kt - 1 is free
         asm volatile("" ::: "memory");
         const int nxt2 = cur >= 1 ? cur - 1 : kStages - 1;                   // (cur + 2) % 3
         if (kt + 2 < KT) issue(kt + 2, nxt2);
         const char *b = lds + cur * kBuf;
-        dh8 ah[2][2], al[2][2], wh[2][2], wl[2][2];   // [kk][tile]
+        dh8 ah[2][2], al[2][2], wh[2][NT], wl[2][NT];   // [kk][tile]
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++)
+        for (int kk = 0; kk < 2; kk++) {
 #pragma unroll
             for (int x = 0; x < 2; x++) {
                 ah[kk][x] = *reinterpret_cast<const dh8 *>(b + offA[x][kk]);
-                wh[kk][x] = *reinterpret_cast<const dh8 *>(b + kATile + offW[x][kk]);
-                wl[kk][x] = *reinterpret_cast<const dh8 *>(b + kATile + (offW[x][kk] ^ 64));
                 al[kk][x] = *reinterpret_cast<const dh8 *>(b + (offA[x][kk] ^ 64));
             }
+#pragma unroll
+            for (int y = 0; y < NT; y++) {
+                wh[kk][y] = *reinterpret_cast<const dh8 *>(b + kATile + offW[y][kk]);
+                wl[kk][y] = *reinterpret_cast<const dh8 *>(b + kATile + (offW[y][kk] ^ 64));
+            }
+        }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++)
 #pragma unroll
             for (int x = 0; x < 2; x++)
 #pragma unroll
-                for (int y = 0; y < 2; y++) {
+                for (int y = 0; y < NT; y++) {
                     am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][x], wh[kk][y], am[x][y], 0, 0, 0);
                     ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][x], wl[kk][y], ac[x][y], 0, 0, 0);
                     ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk][x], wh[kk][y], ac[x][y], 0, 0, 0);
@@ -153,8 +166,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
     }
     // ---- epilogue: D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]; a register of the 64 lanes = two rows x 128 B ----
 #pragma unroll
-    for (int y = 0; y < 2; y++) {
-        const int col = n0 + wn * 64 + y * 32 + (lane & 31);
+    for (int y = 0; y < NT; y++) {
+        const int col = n0 + wn * (32 * NT) + y * 32 + (lane & 31);
         const float bv = bias[col];
 #pragma unroll
         for (int x = 0; x < 2; x++) {
@@ -168,18 +181,39 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
     }
 }
 
-// rows_padded: a multiple of 256; K a multiple of 32; N a multiple of 128
+// rows_padded: a multiple of 256; K a multiple of 32; N a multiple of 128.
+// The tile list is cut where its last wave of workgroups would fill less than half the chip: bands of 256 rows that make whole
+// waves go to the 256-row instantiation, the rest -- as twice as many 128-row tiles -- to the other (18 304 rows x 1536: 864
+// tiles = 3 waves + 96 tiles on 256 CUs; the 96 become 192 half tiles: 3.5 tile-times instead of 4).
 int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
                        hipStream_t stream)
 {
     static bool prepared = false;
+    static int n_cu = 256;
     if (!prepared) {
-        if (hipFuncSetAttribute((const void *)k_mars_dense1, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256)) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(128)) != hipSuccess) return -1;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
         prepared = true;
     }
-    const int tiles_m = rows_padded / BM, tiles_n = N / BN;
-    hipLaunchKernelGGL(k_mars_dense1, dim3(tiles_m * tiles_n), dim3(kThreads), kLds, stream, reinterpret_cast<const _Float16 *>(a2), lda,
-                       reinterpret_cast<const _Float16 *>(w2), ldw, bias, out, K, N, tiles_m, tiles_n);
+    const int bands = rows_padded / BM, tiles_n = N / BN;
+    const long long total = (long long)bands * tiles_n;
+    int bands_main = bands;
+    const long long rem = total % n_cu;
+    if (rem != 0 && 2 * rem <= n_cu) {
+        // whole waves of workgroups as 256-row tiles (cut at a band boundary), the remainder as 128-row tiles
+        bands_main = (int)(((total / n_cu) * n_cu) / tiles_n);
+        if (2LL * (bands - bands_main) * tiles_n > n_cu) bands_main = bands;   // (the remainder would be more than one wave of half tiles)
+    }
+    const _Float16 *A = reinterpret_cast<const _Float16 *>(a2), *W = reinterpret_cast<const _Float16 *>(w2);
+    if (bands_main > 0)
+        hipLaunchKernelGGL(k_mars_dense1<256>, dim3(bands_main * tiles_n), dim3(kThreads), lds_bytes(256), stream, A, lda, W, ldw, bias, out, K, N, 0LL,
+                           tiles_n);
+    if (bands_main < bands)
+        hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * (bands - bands_main) * tiles_n), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias,
+                           out, K, N, (long long)bands_main * BM, tiles_n);
     return 0;
 }
 
