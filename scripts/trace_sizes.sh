@@ -1,4 +1,4 @@
-# usage: bash scripts/r03_trace.sh S  -- rocprofv3 kernel trace of the tracker-only bench at S scenes: per-kernel averages
+# usage: bash scripts/trace_sizes.sh S  -- rocprofv3 kernel trace of the tracker-only bench at S scenes: per-kernel averages
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 for S in ${@:-512}; do
   rm -rf gpurun_out/prof_s$S
