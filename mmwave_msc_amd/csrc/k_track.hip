@@ -512,125 +512,206 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     //      (track, column) sums while lanes 16..63 form min/max over four contiguous quarters of each run
     //      (combined in order with the sequential rule "a later value wins only if strictly smaller/larger",
     //      which is what a single left-to-right pass yields) ----
-    for (int jb = 0; jb < T; jb += 2 * kWaves) {
-        const bool grpA = lane < 12, grpB = lane >= 16;
-        const int pi = grpA ? lane : (grpB ? (lane - 16) >> 2 : 0), slice = (lane - 16) & 3;
-        const int jj = pi / 6, m = pi - jj * 6, j = jb + wave * 2 + jj;
-        const bool valid = j < T && (grpA || grpB);
-        const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
-        TrackRec *rec = trk + L.slot[valid ? j : 0];
-        const double *col = L.p6 + m * NPs + off;
-        double old = 0.0, ne_old = 0.0, sum = 0.0;
-        PROBE(20);
-        if (grpA && nj > 0) {
-            old = rec->spread[m];  // issued now, consumed after the chain
-            if (m == 0) ne_old = rec->n_est;
-            // LDS latency is what this chain waits for, not the adds: sixteen loads in flight, the next
-            // batch requested before the current one is summed
-            int r = 0;
-            double v[16], w[16];
-            if (nj >= 16) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) v[u] = col[u];
-                for (r = 16; r + 16 <= nj; r += 16) {
-#pragma unroll
-                    for (int u = 0; u < 16; u++) w[u] = col[r + u];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) sum += v[u];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = w[u];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; u++) sum += v[u];
-            }
-            if (r + 8 <= nj) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = col[r + u];
-#pragma unroll
-                for (int u = 0; u < 8; u++) sum += v[u];
-                r += 8;
-            }
-            {   // up to seven left
-                const int left = nj - r;
-#pragma unroll
-                for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 7; u++) if (u < left) sum += v[u];
-            }
+    // The (track, column) epilogue: centroid, spread estimate, N_est, lifetime, the leaves of a large cloud's pairwise sums
+    auto finish = [&](int j, int m, int nj, double sum, double mn, double mx, double old, double ne_old, TrackRec *rec) {
+        if (nj == 0) {
+            if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
+            return;
         }
-        PROBE(21);
-        double mn = __longlong_as_double(0x7ff0000000000000LL), mx = -mn;  // empty quarter: never wins
-        if (grpB && nj > 0) {
-            const int r0 = (nj * slice) >> 2, r1 = (nj * (slice + 1)) >> 2;
-            if (r0 < r1) { mn = col[r0]; mx = mn; }
-            int r = r0 + 1;
-            for (; r + 8 <= r1; r += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = col[r + u];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+        const double cen = sum / (double)nj;
+        L.cen[j * 6 + m] = cen;
+        rec->centroid[m] = cen;
+        rec->minv[m] = mn;
+        rec->maxv[m] = mx;
+        // _estimate_measurement_spread Tracking.py:246-268
+        double spread = mx - mn;
+        const double lim = cfg.kf_spread_lim[m], lim2 = 2 * lim;
+        if (nj != 1) spread = spread * (double)(nj + 1) / (double)(nj - 1);
+        spread = spread < lim2 ? spread : lim2;
+        spread = spread > lim ? spread : lim;
+        rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
+        if (m == 0) {
+            if (nj > 128) {  // leaves of this cloud's pairwise sums, for the dispersion phase below
+                int cnt = 0;
+                pw_for_each_leaf<kPwDepth>(0, nj, [&](int, int) { cnt++; });
+                const int first = atomicAdd(&L.ml[0], cnt), c = atomicAdd(&L.ml[1], 1);
+                int *lf = L.ml + 2 + first * 3, *cl = L.ml + 2 + 3 * pw_max_leaves(NP);
+                cl[c * 2] = j; cl[c * 2 + 1] = first;
+                int k = 0;
+                pw_for_each_leaf<kPwDepth>(0, nj, [&](int o, int len) { lf[k * 3] = j; lf[k * 3 + 1] = o; lf[k * 3 + 2] = len; k++; });
             }
-            {
-                const int left = r1 - r;
-                double v[7];
-#pragma unroll
-                for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : mn;  // mn itself never wins a strict compare
-#pragma unroll
-                for (int u = 0; u < 7; u++) if (u < left) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
-            }
+            rec->lifetime = 0.0;
+            rec->point_num = nj;
+            // _estimate_point_num Tracking.py:232-244
+            double ne = ne_old;
+            if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
+            else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
+            rec->n_est = ne;
+            L.nest[j] = ne;
         }
-        PROBE(22);
+    };
+    if (T <= 10) {  // uniform
+        // Up to ten tracks: ALL column sums on ONE wave (six lanes per track: the loop body is issued once for the scene, not
+        // once per pair of tracks), the min / max passes on the other three (192 lanes: S slices per (track, column), S the
+        // largest power of two that fits); the lane that ends up with a column's min / max finishes that column behind a
+        // barrier, with the sum the other wave left in LDS.
+        double mn = __longlong_as_double(0x7ff0000000000000LL), mx = -mn, old = 0.0, ne_old = 0.0;
+        int fg = -1;   // the (track, column) = fg / 6, fg % 6 this lane finishes behind the barrier
+        if (role == 0) {
+            const int grp = lane / 6, m = lane - grp * 6, j = grp;
+            const bool valid = lane < 60 && j < T;
+            const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
+            if (nj > 0) {
+                const double *col = L.p6 + m * NPs + off;
+                double sum = 0.0;
+                int r = 0;
+                double v[8], w[8];
+                if (nj >= 8) {  // eight rows in flight, the next eight requested before these are added
 #pragma unroll
-        for (int d = 1; d <= 2; d <<= 1) {  // quarters (0,1),(2,3) then halves: the partner holds the LATER rows
-            const double tn = __shfl_down(mn, d), tx = __shfl_down(mx, d);
-            mn = tn < mn ? tn : mn;
-            mx = tx > mx ? tx : mx;
-        }
-        double *wmm = L.wmm + wave * 24;
-        if (grpB && slice == 0) { wmm[pi * 2] = mn; wmm[pi * 2 + 1] = mx; }
-        wave_sync();
-        PROBE(23);
-        if (grpA && valid) {
-            if (nj == 0) {
-                if (m == 0) rec->lifetime += dt;  // update_lifetime(dt) Tracking.py:400-407
-            } else {
-                mn = wmm[pi * 2];
-                mx = wmm[pi * 2 + 1];
-                const double cen = sum / (double)nj;
-                L.cen[j * 6 + m] = cen;
-                rec->centroid[m] = cen;
-                rec->minv[m] = mn;
-                rec->maxv[m] = mx;
-                // _estimate_measurement_spread Tracking.py:246-268
-                double spread = mx - mn;
-                const double lim = cfg.kf_spread_lim[m], lim2 = 2 * lim;
-                if (nj != 1) spread = spread * (double)(nj + 1) / (double)(nj - 1);
-                spread = spread < lim2 ? spread : lim2;
-                spread = spread > lim ? spread : lim;
-                rec->spread[m] = spread > old ? spread : (1.0 - cfg.kf_a_spr) * old + cfg.kf_a_spr * spread;
-                if (m == 0) {
-                    if (nj > 128) {  // leaves of this cloud's pairwise sums, for the dispersion phase below
-                        int cnt = 0;
-                        pw_for_each_leaf<kPwDepth>(0, nj, [&](int, int) { cnt++; });
-                        const int first = atomicAdd(&L.ml[0], cnt), c = atomicAdd(&L.ml[1], 1);
-                        int *lf = L.ml + 2 + first * 3, *cl = L.ml + 2 + 3 * pw_max_leaves(NP);
-                        cl[c * 2] = j; cl[c * 2 + 1] = first;
-                        int k = 0;
-                        pw_for_each_leaf<kPwDepth>(0, nj, [&](int o, int len) { lf[k * 3] = j; lf[k * 3 + 1] = o; lf[k * 3 + 2] = len; k++; });
+                    for (int u = 0; u < 8; u++) v[u] = col[u];
+                    for (r = 8; r + 8 <= nj; r += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) w[u] = col[r + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) sum += v[u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = w[u];
                     }
-                    rec->lifetime = 0.0;
-                    rec->point_num = nj;
-                    // _estimate_point_num Tracking.py:232-244
-                    double ne = ne_old;
-                    if (cfg.kf_enable_est) ne = ((double)nj > ne) ? (double)nj : (1 - cfg.kf_a_n) * ne + cfg.kf_a_n * (double)nj;
-                    else ne = cfg.kf_est_pointnum > (double)nj ? cfg.kf_est_pointnum : (double)nj;
-                    rec->n_est = ne;
-                    L.nest[j] = ne;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sum += v[u];
+                }
+                {   // up to seven left
+                    const int left = nj - r;
+#pragma unroll
+                    for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 7; u++) if (u < left) sum += v[u];
+                }
+                L.cen[j * 6 + m] = sum;   // (the column's owner replaces it by the centroid below)
+            }
+        } else {
+            int lg = 5;   // S = 2^lg slices: 6 T S <= 192
+            while (lg > 0 && 6 * T * (1 << lg) > 192) lg--;
+            const int task = (role - 1) * 64 + lane, g = task >> lg, slice = task & ((1 << lg) - 1);
+            const int j = g / 6, m = g - j * 6;
+            const bool valid = g < 6 * T;
+            const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
+            TrackRec *rec = trk + L.slot[valid ? j : 0];
+            if (valid && slice == 0) {
+                fg = g;
+                if (nj > 0) {  // issued now, consumed behind the barrier
+                    old = rec->spread[m];
+                    if (m == 0) ne_old = rec->n_est;
                 }
             }
+            if (nj > 0) {
+                const double *col = L.p6 + m * NPs + off;
+                const int r0 = (nj * slice) >> lg, r1 = (nj * (slice + 1)) >> lg;
+                if (r0 < r1) { mn = col[r0]; mx = mn; }
+                int r = r0 + 1;
+                for (; r + 8 <= r1; r += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = col[r + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+                }
+                {
+                    const int left = r1 - r;
+                    double v[7];
+#pragma unroll
+                    for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : mn;  // mn itself never wins a strict compare
+#pragma unroll
+                    for (int u = 0; u < 7; u++) if (u < left) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+                }
+            }
+            for (int d = 1; d < (1 << lg); d <<= 1) {  // neighbouring slices, then pairs of them, ...: the partner holds the LATER rows
+                const double tn = __shfl_down(mn, d), tx = __shfl_down(mx, d);
+                mn = tn < mn ? tn : mn;
+                mx = tx > mx ? tx : mx;
+            }
         }
-        wave_sync();
+        lds_barrier();
+        if (fg >= 0) {
+            const int fj = fg / 6, fn = L.cls_n[fj + 1];
+            finish(fj, fg - fj * 6, fn, fn > 0 ? L.cen[fg] : 0.0, mn, mx, old, ne_old, trk + L.slot[fj]);
+        }
+    } else {
+        for (int jb = 0; jb < T; jb += 2 * kWaves) {
+            const bool grpA = lane < 12, grpB = lane >= 16;
+            const int pi = grpA ? lane : (grpB ? (lane - 16) >> 2 : 0), slice = (lane - 16) & 3;
+            const int jj = pi / 6, m = pi - jj * 6, j = jb + wave * 2 + jj;
+            const bool valid = j < T && (grpA || grpB);
+            const int nj = valid ? L.cls_n[j + 1] : 0, off = valid ? L.cls_off[j + 1] : 0;
+            TrackRec *rec = trk + L.slot[valid ? j : 0];
+            const double *col = L.p6 + m * NPs + off;
+            double old = 0.0, ne_old = 0.0, sum = 0.0;
+            PROBE(20);
+            if (grpA && nj > 0) {
+                old = rec->spread[m];  // issued now, consumed after the chain
+                if (m == 0) ne_old = rec->n_est;
+                // LDS latency is what this chain waits for, not the adds: eight loads in flight, the next
+                // batch requested before the current one is summed
+                int r = 0;
+                double v[8], w[8];
+                if (nj >= 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = col[u];
+                    for (r = 8; r + 8 <= nj; r += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) w[u] = col[r + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) sum += v[u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = w[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) sum += v[u];
+                }
+                {   // up to seven left
+                    const int left = nj - r;
+    #pragma unroll
+                    for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : 0.0;
+    #pragma unroll
+                    for (int u = 0; u < 7; u++) if (u < left) sum += v[u];
+                }
+            }
+            PROBE(21);
+            double mn = __longlong_as_double(0x7ff0000000000000LL), mx = -mn;  // empty quarter: never wins
+            if (grpB && nj > 0) {
+                const int r0 = (nj * slice) >> 2, r1 = (nj * (slice + 1)) >> 2;
+                if (r0 < r1) { mn = col[r0]; mx = mn; }
+                int r = r0 + 1;
+                for (; r + 8 <= r1; r += 8) {
+                    double v[8];
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = col[r + u];
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+                }
+                {
+                    const int left = r1 - r;
+                    double v[7];
+    #pragma unroll
+                    for (int u = 0; u < 7; u++) v[u] = (u < left) ? col[r + u] : mn;  // mn itself never wins a strict compare
+    #pragma unroll
+                    for (int u = 0; u < 7; u++) if (u < left) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
+                }
+            }
+            PROBE(22);
+    #pragma unroll
+            for (int d = 1; d <= 2; d <<= 1) {  // quarters (0,1),(2,3) then halves: the partner holds the LATER rows
+                const double tn = __shfl_down(mn, d), tx = __shfl_down(mx, d);
+                mn = tn < mn ? tn : mn;
+                mx = tx > mx ? tx : mx;
+            }
+            double *wmm = L.wmm + wave * 24;
+            if (grpB && slice == 0) { wmm[pi * 2] = mn; wmm[pi * 2 + 1] = mx; }
+            wave_sync();
+            PROBE(23);
+            if (grpA && valid) finish(j, m, nj, sum, nj > 0 ? wmm[pi * 2] : 0.0, nj > 0 ? wmm[pi * 2 + 1] : 0.0, old, ne_old, rec);
+            wave_sync();
+        }
     }
     PROBE(24);
     lds_barrier();
