@@ -613,18 +613,23 @@ def test_two_side_worker_contexts_in_one_process():
                     l=torch.empty((S, sb.UM), dtype=torch.int32, device=dev), b=torch.empty((S,), dtype=torch.int32, device=dev))
         ctxs.append((sb, st, bufs, (pts, cnt, dts)))
     torch.cuda.synchronize()
-    worst = 0.0
+    times = []
     for f in range(F):
         t0 = time.perf_counter()
         for sb, st, b, _ in ctxs:
             sb.step_dev(b["p"][f].data_ptr(), b["n"][f].data_ptr(), b["d"][f].data_ptr(), b["a"].data_ptr(), b["l"].data_ptr(), b["b"].data_ptr())
         torch.cuda.synchronize()
         if f >= 3:   # (the first frames hold the start-up DBSCAN and the stream probe)
-            worst = max(worst, time.perf_counter() - t0)
-    assert worst < 0.02, f"a step of two contexts took {worst * 1e3:.1f} ms: a polling worker held a stream back"
+            times.append(time.perf_counter() - t0)
+    # a worker that holds a stream back costs its bounded wait: 0.2 s and more (k_dbscan.hip: kMustWaitTicks) -- or, for idle
+    # workers on a crosswise-shared queue, a few ms per step.  Wall-clock on a shared box: the typical step is judged at 20 ms,
+    # a single one at 150 ms (one hiccup of the host must not fail the suite); give-ups are checked below (mmw_check)
+    times.sort()
+    assert times[len(times) // 2] < 0.02 and times[-1] < 0.15, f"steps of two contexts took {[round(t * 1e3, 1) for t in times]} ms: a polling worker held a stream back"
     for sb, st, b, (pts, cnt, dts) in ctxs:
         assert sb.side_workers() in (0, 1)
         sb.check()
+        assert int(sb.diag_queue()[4]) == 0   # no bounded wait was given up
         ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
         co.batch_run_f32(ob, pts, cnt, dts, 0)
         ntr = sb.num_tracks()
