@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
         __builtin_amdgcn_wave_barrier();
         CSTAMP(1);  // input staging
         // ---- conv1: the four 16-position tiles of a plane at a time (they share the weight fragments); D[oc][pos] ----
-#pragma unroll 1
+#pragma unroll
         for (int d = 0; d < NZ; d++) {
             int pc[4];
 #pragma unroll
@@ -332,25 +332,58 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
             f32x4 am[4], ac[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) { am[u] = f32x4{0.f, 0.f, 0.f, 0.f}; ac[u] = am[u]; }
+            // A K-step whose four taps all read a plane outside the volume is skipped (d and s are compile-time: 17 of the
+            // 21 steps remain); the operands of the next step are requested before the twelve MFMAs of this one are issued --
+            // the loop is bound by the LDS (10 KiB per wave and step), which must not also wait for the matrix pipe.
+            auto step_valid = [&](int s2) {
+                bool v = false;
 #pragma unroll
-            for (int s = 0; s < C::kS1; s++) {
-                const int g = lane >> 4, tap = 4 * s + g;
+                for (int g2 = 0; g2 < 4; g2++) {
+                    const int t2 = 4 * s2 + g2;
+                    v = v || (t2 < C::kTaps && (unsigned)(d + C::tap_kd(t2) - 1) < (unsigned)NZ);
+                }
+                return v;
+            };
+            h8 wh, wl, xh[4], xl[4];
+            auto load_step = [&](int s2, h8 &wh2, h8 &wl2, h8 (&xh2)[4], h8 (&xl2)[4]) {
+                const int g = lane >> 4, tap = 4 * s2 + g;
                 const int kd = NZ == 3 ? tap / 9 : 1;
                 const bool ok = tap < C::kTaps && (unsigned)(d + kd - 1) < (unsigned)NZ;
                 // tap offset of this lane's tap (the four candidates of the step are compile-time constants)
-                const int o0 = C::tap_off(4 * s + 0 < C::kTaps ? 4 * s + 0 : 0), o1 = C::tap_off(4 * s + 1 < C::kTaps ? 4 * s + 1 : 0),
-                          o2 = C::tap_off(4 * s + 2 < C::kTaps ? 4 * s + 2 : 0), o3 = C::tap_off(4 * s + 3 < C::kTaps ? 4 * s + 3 : 0);
+                const int o0 = C::tap_off(4 * s2 + 0 < C::kTaps ? 4 * s2 + 0 : 0), o1 = C::tap_off(4 * s2 + 1 < C::kTaps ? 4 * s2 + 1 : 0),
+                          o2 = C::tap_off(4 * s2 + 2 < C::kTaps ? 4 * s2 + 2 : 0), o3 = C::tap_off(4 * s2 + 3 < C::kTaps ? 4 * s2 + 3 : 0);
                 const int off = g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3;
-                const h8 wh = W1hi[s * 64 + lane], wl = W1lo[s * 64 + lane];
-                h8 xh[4], xl[4];
+                wh2 = W1hi[s2 * 64 + lane]; wl2 = W1lo[s2 * 64 + lane];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const int i = ok ? pc[u] + off : C::kPad; xh[u] = Xhi[i]; xl[u] = Xlo[i]; }
+                for (int u = 0; u < 4; u++) { const int i = ok ? pc[u] + off : C::kPad; xh2[u] = Xhi[i]; xl2[u] = Xlo[i]; }
+            };
+            {
+                int s0 = 0;
+#pragma unroll
+                for (int ss = C::kS1 - 1; ss >= 0; ss--) if (step_valid(ss)) s0 = ss;
+                load_step(s0, wh, wl, xh, xl);
+            }
+#pragma unroll
+            for (int s = 0; s < C::kS1; s++) {
+                if (!step_valid(s)) continue;   // compile-time
+                int nxt = -1;
+#pragma unroll
+                for (int ss = C::kS1 - 1; ss > s; ss--) if (step_valid(ss)) nxt = ss;
+                h8 nwh = wh, nwl = wl, nxh[4], nxl[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { nxh[u] = xh[u]; nxl[u] = xl[u]; }
+                if (nxt >= 0) load_step(nxt, nwh, nwl, nxh, nxl);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 4; u++) am[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[u], am[u], 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < 4; u++) ac[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[u], ac[u], 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < 4; u++) ac[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[u], ac[u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wh = nwh; wl = nwl;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { xh[u] = nxh[u]; xl[u] = nxl[u]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -402,15 +435,23 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 h8 nh0 = xh0, nl0 = xl0, nh1 = xh1, nl1 = xl1, nw = wlo;
                 if (nxt >= 0) {
                     const int i0 = pc0 + C::tap_off(nxt), i1 = pc1 + C::tap_off(nxt);
+#ifdef MMW_EXP
+                    if (nxt % 3 == 0) { nh0 = Hh[i0]; nl0 = Hl[i0]; nh1 = Hh[i1]; nl1 = Hl[i1]; }
+                    if (MMW_EXP == 1 || nxt % 3 == 0) nw = W2lo[nxt * 64 + lane];
+#else
                     nh0 = Hh[i0]; nl0 = Hl[i0]; nh1 = Hh[i1]; nl1 = Hl[i1];
                     nw = W2lo[nxt * 64 + lane];
+#endif
                 }
+                // (the scheduler must not pull tap k + 1's MFMAs up to their operands' loads: it would wait for the LDS there)
+                __builtin_amdgcn_sched_barrier(0);
                 am0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh0, am0, 0, 0, 0);
                 am1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh1, am1, 0, 0, 0);
                 ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl0, ac0, 0, 0, 0);
                 ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl1, ac1, 0, 0, 0);
                 ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh0, ac0, 0, 0, 0);
                 ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh1, ac1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 xh0 = nh0; xl0 = nl0; xh1 = nh1; xl1 = nl1; wlo = nw;
             }
             CSTAMP(3);  // conv2 MFMA loop
