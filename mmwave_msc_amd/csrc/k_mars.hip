@@ -280,7 +280,12 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
     //      2u, 2u + 4, 2u + 1, 2u + 5.  Column r of the MFMA's B operand = position (row(r >> 3), x = r & 7). ----
     const int x8 = lane & 7;
     const int cell1 = ((lane >> 3) & 1) * 40 + 10 + x8 + 1;                       // conv1: + (d * 100 + c * 10)
-    const int cell2 = (((lane >> 3) & 1) * 4 + ((lane >> 4) & 1)) * 10 + 10 + x8 + 1;  // conv2: + (d * 100 + 2u * 10)
+    // conv2: the sixteen lanes the LDS serves together are NOT consecutive ones -- of each 32 they are {0-3, 12-15, 20-27} and
+    // {4-11, 16-19, 28-31} (measured: with consecutive sixteens every operand read was a 2-way bank conflict, 52 % of the
+    // kernel's LDS cycles).  col2 = the tile column this lane's MFMA column stands for: those two lane sets in order.
+    const int l32 = lane & 31;
+    const int col2 = l32 < 4 ? l32 : l32 < 12 ? l32 + 12 : l32 < 16 ? l32 - 8 : l32 < 20 ? l32 + 8 : l32 < 28 ? l32 - 12 : l32;
+    const int cell2 = (((col2 >> 3) & 1) * 4 + ((col2 >> 4) & 1)) * 10 + 10 + (col2 & 7) + 1;  // + (d * 100 + 2u * 10)
     const int h2 = lane >> 5;
 
     const int stride = gridDim.x * 4;
@@ -435,13 +440,8 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 h8 nh0 = xh0, nl0 = xl0, nh1 = xh1, nl1 = xl1, nw = wlo;
                 if (nxt >= 0) {
                     const int i0 = pc0 + C::tap_off(nxt), i1 = pc1 + C::tap_off(nxt);
-#ifdef MMW_EXP
-                    if (nxt % 3 == 0) { nh0 = Hh[i0]; nl0 = Hl[i0]; nh1 = Hh[i1]; nl1 = Hl[i1]; }
-                    if (MMW_EXP == 1 || nxt % 3 == 0) nw = W2lo[nxt * 64 + lane];
-#else
                     nh0 = Hh[i0]; nl0 = Hl[i0]; nh1 = Hh[i1]; nl1 = Hl[i1];
                     nw = W2lo[nxt * 64 + lane];
-#endif
                 }
                 // (the scheduler must not pull tap k + 1's MFMAs up to their operands' loads: it would wait for the LDS there)
                 __builtin_amdgcn_sched_barrier(0);
@@ -471,8 +471,8 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                         hi[r] = a; lo[r] = l2;
                     }
                     const int oc0 = 8 * qg + 4 * (lane >> 5);
-                    *reinterpret_cast<h4 *>(stage + (lane & 31) * 32 + oc0) = hi;
-                    *reinterpret_cast<h4 *>(stage + 1024 + (lane & 31) * 32 + oc0) = lo;
+                    *reinterpret_cast<h4 *>(stage + col2 * 32 + oc0) = hi;
+                    *reinterpret_cast<h4 *>(stage + 1024 + col2 * 32 + oc0) = lo;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
