@@ -78,8 +78,14 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
     int err = 0;
     if (tracks_dense(cfg, nq)) {
         const int prev = parity ^ 1, n_dense = cfg.n_scenes * nq;
-        if ((int)blockIdx.x < n_dense) {
-            if ((int)blockIdx.x * 4 >= st.upd_count[(size_t)prev * (cfg.t_cap + 1)]) return;  // (bin 0 = the total)
+        // (bin 0 of the counts = the total: the dense work takes the first ceil(total / 4) units, every other unit of the launch
+        //  -- the kSpecialUnits behind the dense range always, and the idle rest of the dense range: after a frame in which
+        //  EVERY scene spawned tracks, the first frames after a reset, that is all of them; 64 waves alone took 555 us for the
+        //  4096 scenes of the start-up -- serves the two lists below)
+        const int total = st.upd_count[(size_t)prev * (cfg.t_cap + 1)];
+        int nd = (total + 3) >> 2;
+        nd = nd < n_dense ? nd : n_dense;
+        if ((int)blockIdx.x < nd) {
             const DenseBins B = dense_bins(cfg, st, prev, lane);
             for (int unit = blockIdx.x; unit * 4 < B.total; unit += n_dense) {
                 int s, j;
@@ -94,8 +100,9 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
             }
             return;
         }
+        const int pool = (int)gridDim.x - nd, me = (int)blockIdx.x - nd;
         const int count = st.spc_count[prev];
-        for (int i = (int)blockIdx.x - n_dense; i < count; i += kSpecialUnits) {
+        for (int i = me; i < count; i += pool) {
             const int s = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2], first = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2 + 1];
             const int n = n_pts[s];
             if (!frame_reaches_track(n, cfg.max_pts)) continue;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
         }
         // scenes whose last frame was empty (no update list holds them): all their tracks.  64 scenes per look (one
         // per lane), the rare hits one after the other
-        for (int s0 = ((int)blockIdx.x - n_dense) * 64; s0 < cfg.n_scenes; s0 += kSpecialUnits * 64) {
+        for (int s0 = me * 64; s0 < cfg.n_scenes; s0 += pool * 64) {
             const int sl = s0 + lane;
             bool mine = false;
             if (sl < cfg.n_scenes) {

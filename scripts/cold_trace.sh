@@ -1,0 +1,17 @@
+# usage: bash scripts/cold_trace.sh  -- kernel trace of the start-up frames (frames 0..3 of 4096 fresh scenes), launches in order
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+rm -rf gpurun_out/prof_cold
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_cold -- python3 $GRAFT_REPO_ROOT/scripts/cold_frames.py > $GRAFT_REPO_ROOT/gpurun_out/prof_cold.log 2>&1)
+grep -E "points per|dbscan calls|share" gpurun_out/prof_cold.log
+python3 - <<PY
+import csv,glob
+f=glob.glob('gpurun_out/prof_cold/*/*kernel_trace.csv')[0]
+rows=[r for r in csv.DictReader(open(f)) if 'mmw::' in r['Kernel_Name']]
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+# the second pass: from the last k_reset on
+last=max(i for i,r in enumerate(rows) if 'k_reset' in r['Kernel_Name'] or 'k_init' in r['Kernel_Name'])
+t0=int(rows[last]['Start_Timestamp'])
+for r in rows[last:]:
+    n=r['Kernel_Name'].split('(')[0].replace('void mmw::','').replace('mmw::','')
+    print(f"{(int(r['Start_Timestamp'])-t0)/1e3:9.1f} us  +{(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:8.1f}  {n[:60]}  grid {r.get('Grid_Size','?')} wg {r.get('Workgroup_Size','?')} lds {r.get('LDS_Block_Size','?')}")
+PY
