@@ -240,9 +240,9 @@ def main():
                          "weak: every GPU owns --scenes scenes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
-    ap.add_argument("--py-scenes-per-core", type=int, default=2)
+    ap.add_argument("--py-scenes-per-core", type=int, default=4)
     ap.add_argument("--py-frames", type=int, default=20)
-    ap.add_argument("--c-scenes", type=int, default=1024)
+    ap.add_argument("--c-scenes", type=int, default=4096)
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (tracker + features + CNN every frame) leg")
     ap.add_argument("--no-e2e-parity", action="store_true", help="skip the configs[3] end-to-end parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")

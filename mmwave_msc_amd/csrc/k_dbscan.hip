@@ -231,6 +231,52 @@ struct BitonicK {
     }
 };
 
+// The fp32 screen of one leaf for this lane's query (see dbscan_core, query_radius): n <= 60 candidates whose fp32
+// coordinates lie at xf / yf / zf (uniform addresses: LDS broadcasts), two per packed instruction.  Returns the bits of the
+// candidates whose fp32 metric is <= lo ("inside" for certain); `amb` = those in (lo, hi] -- for the fp64 formula.  Each
+// comparison lands in its word through the carry: v_cmp -> vcc, then word = 2 word + vcc in one v_addc.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long leaf_screen(const float *xf, const float *yf, const float *zf, int n, float px, float py, float pz,
+                                                          float c, float zw, float lo, float hi, unsigned long long &amb)
+{
+    const f32x2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz}, NC = {-c, -c}, ONE = {1.0f, 1.0f}, ZW = {zw, zw};
+    unsigned in0 = 0u, no0 = 0u, in1 = 0u, no1 = 0u;
+    auto pair = [&](int k, unsigned &inw, unsigned &now) {
+        const f32x2 bx = {xf[k], xf[k + 1]}, by = {yf[k], yf[k + 1]}, bz = {zf[k], zf[k + 1]};  // (k + 1 == n: a stray value, masked below)
+        const f32x2 w = __builtin_elementwise_fma(PY + by, NC, ONE);
+        const f32x2 dx = PX - bx, dy = PY - by, dz = PZ - bz;
+        f32x2 D = dx * dx;
+        D = __builtin_elementwise_fma(dy, dy, D);
+        D = __builtin_elementwise_fma(dz * ZW, dz, D);
+        const f32x2 d = w * D;
+        asm volatile("v_cmp_ge_f32 vcc, %4, %2\n\t"
+                     "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %5, %2\n\t"
+                     "v_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %4, %3\n\t"
+                     "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %5, %3\n\t"
+                     "v_addc_co_u32 %1, vcc, %1, %1, vcc"
+                     : "+v"(inw), "+v"(now)
+                     : "v"(d.x), "v"(d.y), "s"(lo), "s"(hi)
+                     : "vcc");
+    };
+    const int n2 = (n + 1) & ~1, nA = n2 < 32 ? n2 : 32, nB = n2 - nA;
+    for (int k = 0; k < nA; k += 2) pair(k, in0, no0);
+    for (int k = 32; k < n2; k += 2) pair(k, in1, no1);
+    // candidate k of a word that took m of them sits at bit m - 1 - k
+    unsigned long long inb = nA > 0 ? (unsigned long long)(__brev(in0) >> (32 - nA)) : 0ULL;
+    unsigned long long nob = nA > 0 ? (unsigned long long)(__brev(no0) >> (32 - nA)) : 0ULL;
+    if (nB > 0) {
+        inb |= (unsigned long long)(__brev(in1) >> (32 - nB)) << 32;
+        nob |= (unsigned long long)(__brev(no1) >> (32 - nB)) << 32;
+    }
+    const unsigned long long valid = n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL);
+    inb &= valid;
+    amb = nob & ~inb & valid;
+    return inb;
+}
+
 // The whole of DBSCAN.fit_predict for one cloud.  On return L.idx2[i] = label of
 // point i (-1 noise) and the number of clusters is returned (uniform).
 template <int NT, bool ALL8>
@@ -659,12 +705,27 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             for (int p = tid; p < U; p += NT) col[p] = L.key[p];
         }
     }
+    // fp32 copies of the coordinates by tree position, for the screen in front of the leaf tests of query_radius (below): in
+    // the three arrays that are dead between the build and the labelling -- the spare one of idx / idx2, next, lab (the
+    // labelling's -1 are written again behind the queries) -- and the extents the screen's error bound needs
+    float *XF = reinterpret_cast<float *>(idx2), *YF = reinterpret_cast<float *>(L.next), *ZF = reinterpret_cast<float *>(L.lab);
+    if (tid == 0) { L.mm[0] = ~0ULL; L.mm[1] = 0ULL; L.mm[2] = 0ULL; }
     __syncthreads();
+    double ext_lo = 1.7976931348623157e308, ext_hi = -1.7976931348623157e308, ext_m = 0.0;
     for (int p0 = 0; p0 < U; p0 += NT) {
         const int p = p0 + tid;
         const bool act = p < U;
         const int i = act ? p : 0;
         const double px = L.X[i], py = L.Y[i], pz = L.Z[i];
+        if (act) {
+            XF[p] = (float)px; YF[p] = (float)py; ZF[p] = (float)pz;
+            ext_lo = py < ext_lo ? py : ext_lo;
+            ext_hi = py > ext_hi ? py : ext_hi;
+            const double ax = fabs(px), ay = fabs(py), az = fabs(pz);
+            double am = ax > ay ? ax : ay;
+            am = am > az ? am : az;
+            ext_m = am > ext_m ? am : ext_m;   // (a NaN coordinate never enters: its comparisons are false in fp32 as in fp64)
+        }
         int node = 0;
         for (int level = 0; level < n_levels; level++) {
             double d = act ? alt_dist(L.ncen[node * 3], L.ncen[node * 3 + 1], L.ncen[node * 3 + 2], px, py, pz, rw, zw) : 0.0;
@@ -683,11 +744,45 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             }
         }
     }
+    ext_lo = wave_min_d(ext_lo);
+    ext_hi = wave_max_d(ext_hi);
+    ext_m = wave_max_d(ext_m);
+    if (lane == 0 && ext_lo <= ext_hi) {
+        atomicMin(&L.mm[0], sortable(ext_lo));
+        atomicMax(&L.mm[1], sortable(ext_hi));
+        atomicMax(&L.mm[2], (unsigned long long)__double_as_longlong(ext_m));
+    }
     __syncthreads();
 
     DSTAMP(2);
     // ---- BallTree.query_radius(X, eps) for every point (_binary_tree.pxi.tp:1903-1980) ----
     const int lbits = n_levels - 1;
+    // The leaf tests -- "is metric(p, q) <= eps" for every point q of a leaf some query of the wave reached: nine tenths of
+    // this phase, 14 fp64 operations each -- go through an fp32 SCREEN first: the same formula on the fp32 copies, two
+    // candidates per packed instruction, decides every pair whose fp32 value is further than E from eps; the few in between
+    // are computed in fp64 as before.  E bounds |metric_fp32 - metric_fp64| for all pairs whose coordinate differences are
+    // within R, R^2 = 4 max(eps, 1) / (wmin min(1, z_w)) (beyond R the metric is >= 4 max(eps, 1) and its fp32 value within
+    // 15 % of it: "out" either way), from |coordinates| <= M and y in [ymin, ymax] (u = 2^-23, twice the unit roundoff; a
+    // difference is off by <= 2Mu + 2u|d|, its square by <= 4RMu + 6uR^2, the weight by <= 12cMu + 4u, c = |range_w| / 2),
+    // doubled.  Clouds whose extents make E useless (or the far-pair argument void) skip the screen: the decisions -- and with
+    // them counts, rows, labels -- are those of the fp64 formula in every case.
+    float scr_lo = 0.f, scr_hi = 0.f;
+    bool use_scr = false;
+    {
+        const double ymin = unsortable(L.mm[0]), ymax = unsortable(L.mm[1]), M = __longlong_as_double((long long)L.mm[2]);
+        const double wa = 1 - ymax * rw, wb = 1 - ymin * rw, wmin = wa < wb ? wa : wb;
+        const double u = 1.0 / 8388608.0, c = 0.5 * fabs(rw), mz = zw < 1.0 ? zw : 1.0, e1 = eps > 1.0 ? eps : 1.0;
+        if (wmin > 0.0 && zw >= 1.0 / 1024.0 && eps > 0.0 && L.mm[0] != ~0ULL) {
+            const double R2 = 4.0 * e1 / (wmin * mz), R = sqrt(R2), Wm = 1.0 + 2.0 * c * M, Dm = (2.0 + zw) * R2;
+            const double dD = (2.0 + zw) * (4.0 * R * M * u + 6.0 * u * R2) + 4.0 * u * Dm, dw = 12.0 * c * M * u + 4.0 * u;
+            const double E = 2.0 * (Wm * dD + Dm * dw + 2.0 * u * Wm * Dm) + eps * (1.0 / 4194304.0);
+            if (M <= 65536.0 * R && dw <= 0.1 * wmin && E < 0.25 * (eps < 1.0 ? eps : 1.0)) {
+                use_scr = true;
+                scr_lo = (float)(eps - E);
+                scr_hi = (float)(eps + E);
+            }
+        }
+    }
     // A WAVE walks the tree as one: its 64 queries are neighbours in the tree (one or two leaves), so the nodes any of them
     // needs are nearly the nodes each of them needs -- and with node and level uniform every branch below is taken by
     // the whole wave, the candidates of a leaf are read once (one LDS broadcast per coordinate) and the distance block runs
@@ -719,6 +814,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             const int p = pb + lane;
             const bool act = p < U;
             const double px = L.X[act ? p : 0], py = L.Y[act ? p : 0], pz = L.Z[act ? p : 0];
+            const float pxf = (float)px, pyf = (float)py, pzf = (float)pz, cf = (float)(0.5 * rw), zwf = (float)zw;
             unsigned long long m = 0;
             int count = 0, node = 0, level = 0;  // node, level: uniform
             unsigned alive = 1u;
@@ -753,12 +849,19 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                 }
                 if (level == lbits && __any(state == 2)) {
                     // (a leaf holds at most 2 * leaf_size = 60 points: one word of bits relative to its start, two row words)
-                    unsigned long long bits = 0ULL;
-#pragma unroll 4
-                    for (int q = s + qpart; q < e; q += qparts) {
-                        const unsigned long long in = alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps ? 1ULL : 0ULL;
-                        bits |= in << (q - s);
+                    // (spare waves: slice `qpart` of the leaf; everything here is uniform but the lane's own state and bits)
+                    const int n = e - s, per = (n + qparts - 1) / qparts;
+                    const int a = qpart * per < n ? qpart * per : n, b = a + per < n ? a + per : n;
+                    unsigned long long bits = 0ULL, amb_all = b - a >= 64 ? ~0ULL : ((1ULL << (b - a)) - 1ULL);
+                    if (use_scr && b > a) bits = leaf_screen(XF + s + a, YF + s + a, ZF + s + a, b - a, pxf, pyf, pzf, cf, zwf, scr_lo, scr_hi, amb_all);
+                    unsigned long long amb = state == 2 ? amb_all : 0ULL;  // (the lanes that do not test this leaf drop their bits below)
+                    while (amb) {  // what the screen left open (without it: every candidate): the fp64 formula
+                        const int k = __ffsll((long long)amb) - 1;
+                        amb &= amb - 1ULL;
+                        const int q = s + a + k;
+                        if (alt_dist(px, py, pz, L.X[q], L.Y[q], L.Z[q], rw, zw) <= eps) bits |= 1ULL << k;
                     }
+                    bits <<= a;
                     if (state == 2) {
                         count += __popcll(bits);
                         if (use_adj) {
@@ -788,10 +891,10 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         }
     }
     __syncthreads();
-    if (qparts > 1) {
+    for (int p = tid; p < U; p += NT) L.lab[p] = -1;  // (held the fp32 z column during the queries)
+    if (qparts > 1)
         for (int p = tid; p < U; p += NT) L.core[p] = qcount[p] >= min_samples ? 1 : 0;
-        __syncthreads();
-    }
+    __syncthreads();
 
     DSTAMP(3);
     // ---- dbscan_inner (sklearn/cluster/_dbscan_inner.pyx): clusters seeded in ascending
