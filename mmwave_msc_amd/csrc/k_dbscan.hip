@@ -241,29 +241,43 @@ __device__ __forceinline__ unsigned long long leaf_screen(const float *xf, const
 {
     const f32x2 PX = {px, px}, PY = {py, py}, PZ = {pz, pz}, NC = {-c, -c}, ONE = {1.0f, 1.0f}, ZW = {zw, zw};
     unsigned in0 = 0u, no0 = 0u, in1 = 0u, no1 = 0u;
-    auto pair = [&](int k, unsigned &inw, unsigned &now) {
-        const f32x2 bx = {xf[k], xf[k + 1]}, by = {yf[k], yf[k + 1]}, bz = {zf[k], zf[k + 1]};  // (k + 1 == n: a stray value, masked below)
+    auto metric2 = [&](const f32x2 bx, const f32x2 by, const f32x2 bz) {
         const f32x2 w = __builtin_elementwise_fma(PY + by, NC, ONE);
         const f32x2 dx = PX - bx, dy = PY - by, dz = PZ - bz;
         f32x2 D = dx * dx;
         D = __builtin_elementwise_fma(dy, dy, D);
         D = __builtin_elementwise_fma(dz * ZW, dz, D);
-        const f32x2 d = w * D;
-        asm volatile("v_cmp_ge_f32 vcc, %4, %2\n\t"
+        return w * D;
+    };
+    // four candidates a round: their twelve coordinates are requested together (past the leaf's end: stray values, masked below)
+    auto quad = [&](int k, unsigned &inw, unsigned &now) {
+        const f32x2 bx0 = {xf[k], xf[k + 1]}, by0 = {yf[k], yf[k + 1]}, bz0 = {zf[k], zf[k + 1]};
+        const f32x2 bx1 = {xf[k + 2], xf[k + 3]}, by1 = {yf[k + 2], yf[k + 3]}, bz1 = {zf[k + 2], zf[k + 3]};
+        const f32x2 d0 = metric2(bx0, by0, bz0), d1 = metric2(bx1, by1, bz1);
+        asm volatile("v_cmp_ge_f32 vcc, %6, %2\n\t"
                      "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                     "v_cmp_ge_f32 vcc, %5, %2\n\t"
+                     "v_cmp_ge_f32 vcc, %7, %2\n\t"
                      "v_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
-                     "v_cmp_ge_f32 vcc, %4, %3\n\t"
+                     "v_cmp_ge_f32 vcc, %6, %3\n\t"
                      "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                     "v_cmp_ge_f32 vcc, %5, %3\n\t"
+                     "v_cmp_ge_f32 vcc, %7, %3\n\t"
+                     "v_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %6, %4\n\t"
+                     "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %7, %4\n\t"
+                     "v_addc_co_u32 %1, vcc, %1, %1, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %6, %5\n\t"
+                     "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                     "v_cmp_ge_f32 vcc, %7, %5\n\t"
                      "v_addc_co_u32 %1, vcc, %1, %1, vcc"
                      : "+v"(inw), "+v"(now)
-                     : "v"(d.x), "v"(d.y), "s"(lo), "s"(hi)
+                     : "v"(d0.x), "v"(d0.y), "v"(d1.x), "v"(d1.y), "v"(lo), "v"(hi)
                      : "vcc");
     };
-    const int n2 = (n + 1) & ~1, nA = n2 < 32 ? n2 : 32, nB = n2 - nA;
-    for (int k = 0; k < nA; k += 2) pair(k, in0, no0);
-    for (int k = 32; k < n2; k += 2) pair(k, in1, no1);
+    n = __builtin_amdgcn_readfirstlane(n);  // (uniform by construction: scalar loop counters)
+    const int n4 = (n + 3) & ~3, nA = n4 < 32 ? n4 : 32, nB = n4 - nA;
+    for (int k = 0; k < nA; k += 4) quad(k, in0, no0);
+    for (int k = 32; k < n4; k += 4) quad(k, in1, no1);
     // candidate k of a word that took m of them sits at bit m - 1 - k
     unsigned long long inb = nA > 0 ? (unsigned long long)(__brev(in0) >> (32 - nA)) : 0ULL;
     unsigned long long nob = nA > 0 ? (unsigned long long)(__brev(no0) >> (32 - nA)) : 0ULL;
@@ -807,7 +821,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     if (use_adj || (ALL8 && qparts > 1)) __syncthreads();
     {
         const int wv = tid >> 6;
-        const int qpart = ALL8 ? wv / Wq : 0;                     // (uniform per wave)
+        const int qpart = __builtin_amdgcn_readfirstlane(ALL8 ? wv / Wq : 0);  // (uniform per wave)
         const int pbase = ALL8 ? (wv - qpart * Wq) * 64 : wv * 64;
         const int pstep = ALL8 ? U : NT;                           // (thread-per-point build: one batch)
         for (int pb = pbase; pb < U && qpart < qparts; pb += pstep) {
@@ -830,7 +844,8 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                     else if (level == lbits) state = 2;
                     else state = 3;
                 }
-                const int s = L.nstart[node], e = L.nend[node];
+                // (the same LDS words for every lane: scalar from here on, the loops below are uniform)
+                const int s = __builtin_amdgcn_readfirstlane(L.nstart[node]), e = __builtin_amdgcn_readfirstlane(L.nend[node]);
                 if (state == 1 || state == 2) {
                     const int span = 1 << (lbits - level);
                     const int fl = (node + 1 - (1 << level)) * span;
@@ -851,7 +866,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                     // (a leaf holds at most 2 * leaf_size = 60 points: one word of bits relative to its start, two row words)
                     // (spare waves: slice `qpart` of the leaf; everything here is uniform but the lane's own state and bits)
                     const int n = e - s, per = (n + qparts - 1) / qparts;
-                    const int a = qpart * per < n ? qpart * per : n, b = a + per < n ? a + per : n;
+                    const int a = __builtin_amdgcn_readfirstlane(qpart * per < n ? qpart * per : n), b = a + per < n ? a + per : n;
                     unsigned long long bits = 0ULL, amb_all = b - a >= 64 ? ~0ULL : ((1ULL << (b - a)) - 1ULL);
                     if (use_scr && b > a) bits = leaf_screen(XF + s + a, YF + s + a, ZF + s + a, b - a, pxf, pyf, pzf, cf, zwf, scr_lo, scr_hi, amb_all);
                     unsigned long long amb = state == 2 ? amb_all : 0ULL;  // (the lanes that do not test this leaf drop their bits below)
