@@ -792,8 +792,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             const double E = 2.0 * (Wm * dD + Dm * dw + 2.0 * u * Wm * Dm) + eps * (1.0 / 4194304.0);
             if (M <= 65536.0 * R && dw <= 0.1 * wmin && E < 0.25 * (eps < 1.0 ? eps : 1.0)) {
                 use_scr = true;
+#ifdef MMW_MUTANT_NO_MARGIN   // (mutation check of tests/test_gpu_parity.py::test_dbscan_pairs_at_the_threshold_vs_oracle: never the product)
+                scr_lo = scr_hi = (float)eps;
+#else
                 scr_lo = (float)(eps - E);
                 scr_hi = (float)(eps + E);
+#endif
             }
         }
     }

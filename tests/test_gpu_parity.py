@@ -300,6 +300,52 @@ def test_dbscan_golden():
     sb.close()
 
 
+def test_dbscan_pairs_at_the_threshold_vs_oracle():
+    """query_radius decides most leaf tests from an fp32 value of the metric and only the pairs within its error bound of eps in
+    fp64 (k_dbscan.hip, leaf_screen).  Clouds built so that MANY pairs sit within 1e-7 .. 1e-3 of eps (lattices at the
+    threshold spacing, jittered), the same far from the origin (a wider bound), and at coordinates where fp32 resolves nothing
+    (1e9: the screen must switch itself off): labels equal the fp64 oracle's (Utils.py:250-291 through sklearn's BallTree)."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(5)
+    cfg = co.default_config()
+    eps, rw = cfg.db_eps, cfg.db_range_weight
+    clouds = []
+    for off, jit in ((0.0, 1e-7), (0.0, 1e-5), (40.0, 1e-6), (3000.0, 1e-4), (1e9, 1e-3), (0.0, 0.0)):
+        y0 = 2.0
+        h = float(np.sqrt(eps / (1.0 - y0 * rw)))          # metric(p, p + (h, 0, 0)) == eps up to rounding
+        rows = []
+        for r in range(6):   # chains along x, 10 m apart in z: with min_samples = 2 a chain breaks wherever a step is "out"
+            k = 60
+            pts = np.zeros((k, 8))
+            pts[:, 0] = off + np.cumsum(h * (1.0 + jit * rng.standard_normal(k)))
+            pts[:, 1] = y0
+            pts[:, 2] = 10.0 * r
+            rows.append(pts)
+        c = np.concatenate(rows)
+        clouds.append(c[rng.permutation(len(c))])
+    # clusters a hundred times the usual size: every difference is large, the far-pair argument of the bound is what holds
+    big = np.zeros((300, 8))
+    big[:, 0] = 100.0 * rng.normal(0, 0.4, 300) + np.repeat([0.0, 500.0, -800.0], 100)
+    big[:, 1] = np.abs(rng.normal(3.0, 1.0, 300))
+    big[:, 2] = rng.uniform(0, 2, 300)
+    clouds.append(big)
+    mx = max(len(c) for c in clouds)
+    sb = _mk(len(clouds), 512)
+    pts = np.zeros((len(clouds), mx, 8))
+    n = np.array([len(c) for c in clouds], np.int32)
+    for i, c in enumerate(clouds):
+        pts[i, : len(c)] = c
+    seen = set()
+    for ms in (2, 3, 5):
+        labels, ncl = sb.dbscan_host(pts, n, min_samples=ms)
+        for i, c in enumerate(clouds):
+            want = co.dbscan(cfg, c, min_samples=ms)
+            assert np.array_equal(labels[i, : len(c)], want), (i, ms)
+            seen.add(int(want.max()))
+    sb.close()
+    assert len(seen) > 2   # the chains fall apart differently with min_samples: the threshold pairs matter
+
+
 def test_full_size_config_against_oracle():
     """BASELINE.json configs[2] shape (512 pts, TR_MAX_TRACKS 8, mixed target counts) on 384 scenes:
     final track state after 10 frames bit-equal to the oracle for EVERY scene, plus the
