@@ -1591,6 +1591,13 @@ __global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const 
             }
             __syncthreads();
         }
+        // No side-stream workers this step (small contexts, the start-up frames, a profiler): what the work list and the two
+        // queues hold now is all there is, and nobody else can have claimed any of it -- three counters in one round trip, and
+        // a worker of a step without apply_DBscan (most steps) is gone; the atomics below are 4 dependent round trips more.
+        if (!cfg.side_worker) {
+            const int c3 = st.db_count[parity * 4 + 3], c0 = st.q[parity * 8 + kQCount], cb = st.q[kQBig + parity * 8 + kQCount];
+            if ((c3 | c0 | cb) == 0) return;  // (uniform: the same words in every thread)
+        }
         // k_track has finished: no more pushes this step.  (Every worker block says so: the first to arrive releases k_chain.)
         if (threadIdx.x == 0) atomicMax(&st.q[kQStop], epoch);
         {   // list 3 (the clouds k_track did not queue early): a static share per block, as short as a pair count each
