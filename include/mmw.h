@@ -152,7 +152,10 @@ typedef struct mmw_ctx mmw_ctx;
 int mmw_config_default(mmw_config *cfg);
 
 /* TrackBuffer() + BatchedData() for `n_scenes` scenes (Tracking.py:504-511, 38-41;
- * offline_main.py:32-34).  max_pts = largest point count of one frame. */
+ * offline_main.py:32-34).  max_pts = largest point count of one frame (<= MMW_MAX_PTS_LIMIT).  apply_DBscan clusters
+ * the unassigned part of the ring, up to (FB_FRAMES_BATCH + 1) * max_pts <= 4096 points: up to 1920 points its BallTree
+ * lives in on-chip memory; a context whose ring can hold more additionally gets a slower global-memory path for those
+ * clouds (one more launch per step, only in such contexts). */
 int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t device, mmw_ctx **out);
 int mmw_destroy(mmw_ctx *ctx);
 const char *mmw_last_error(const mmw_ctx *ctx);
@@ -218,7 +221,7 @@ int mmw_step_host(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const d
                   int32_t *assoc, int32_t *db_labels, int32_t *db_n);
 
 /* Utils.apply_DBscan (Utils.py:250-291) on arbitrary clouds: pts[S][max_n][8], n[S]
- * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts). */
+ * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts; max_n > 1920: the global-memory path). */
 int mmw_dbscan(mmw_ctx *ctx, const double *pts, const int32_t *n, int32_t max_n, double eps,
                int32_t min_samples, int32_t *labels, int32_t *n_clusters);
 

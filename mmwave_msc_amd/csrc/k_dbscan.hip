@@ -124,8 +124,16 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
+// MW = 64-bit words of a position's leaf-state mask (two bits per leaf): 1 for the LDS-resident classes (<= 32 leaves, the mask
+// lies over key[]), more for the clouds of more than 1920 points, whose carve-up lives in global memory (k_dbscan_huge).
+__host__ __device__ inline int db_mask_words(int UM)
+{
+    const int leaves = 1 << (db_levels(UM) - 1);
+    return (2 * leaves + 63) / 64 > 1 ? (2 * leaves + 63) / 64 : 1;
+}
+__host__ __device__ inline int db_front_stride(int MW) { return MW == 1 ? 4 : 4 + MW; }  // doubles per staged frontier entry: mask word 0, x, y, z, (mask words 1..)
 template <bool WRITE>
-__host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool all8, char *base, DbLds *L)
+__host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool all8, char *base, DbLds *L, int MW = 1)
 {
     const int NB = (UM + 63) / 64;
     const int levels = db_levels(UM), nodes = (1 << levels) - 1, half = (1 << (levels - 1)) / 2 > 0 ? (1 << (levels - 1)) / 2 : 1;
@@ -162,8 +170,9 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(cl_n, int, CL + 2)
     CARVE(cl_off, int, CL + 2)
     CARVE(ccen, double, (CL + 1) * 6)
-    CARVE(fst, double, kFrontChunk * 4)
+    CARVE(fst, double, kFrontChunk * db_front_stride(MW))
     CARVE(adj, unsigned long long, db_adj_words(UM))
+    if (MW > 1) { CARVE(mask, unsigned long long, (size_t)UM * MW) }
 #undef CARVE
     return off;
 }
@@ -293,7 +302,7 @@ __device__ __forceinline__ unsigned long long leaf_screen(const float *xf, const
 
 // The whole of DBSCAN.fit_predict for one cloud.  On return L.idx2[i] = label of
 // point i (-1 noise) and the number of clusters is returned (uniform).
-template <int NT, bool ALL8>
+template <int NT, bool ALL8, int MW = 1>
 __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, const RowSrc src, int U, int UMc, double eps, int min_samples,
                                            unsigned long long *dbg, bool screened = false)
 {
@@ -833,7 +842,9 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             const bool act = p < U;
             const double px = L.X[act ? p : 0], py = L.Y[act ? p : 0], pz = L.Z[act ? p : 0];
             const float pxf = (float)px, pyf = (float)py, pzf = (float)pz, cf = (float)(0.5 * rw), zwf = (float)zw;
-            unsigned long long m = 0;
+            unsigned long long m[MW];
+#pragma unroll
+            for (int w = 0; w < MW; w++) m[w] = 0ULL;
             int count = 0, node = 0, level = 0;  // node, level: uniform
             unsigned alive = 1u;
             for (;;) {
@@ -854,8 +865,20 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                     const int span = 1 << (lbits - level);
                     const int fl = (node + 1 - (1 << level)) * span;
                     const unsigned long long pat = state == 1 ? 0x5555555555555555ULL : 0xAAAAAAAAAAAAAAAAULL;
-                    const unsigned long long sel = span == 32 ? ~0ULL : ((1ULL << (2 * span)) - 1ULL);
-                    m |= (pat & sel) << (2 * fl);
+                    if constexpr (MW == 1) {
+                        const unsigned long long sel = span == 32 ? ~0ULL : ((1ULL << (2 * span)) - 1ULL);
+                        m[0] |= (pat & sel) << (2 * fl);
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < MW; w++) {  // bits [2 fl, 2 fl + 2 span) of the mask, word by word
+                            const int lo = 2 * fl - 64 * w, hi = lo + 2 * span;
+                            if (hi > 0 && lo < 64) {
+                                const int a = lo < 0 ? 0 : lo, b = hi > 64 ? 64 : hi;
+                                const unsigned long long sel = b - a == 64 ? ~0ULL : (((1ULL << (b - a)) - 1ULL) << a);
+                                m[w] |= pat & sel;
+                            }
+                        }
+                    }
                 }
                 if (state == 1 && qpart == 0) {
                     count += e - s;
@@ -903,7 +926,10 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             }
             if (act) {
                 // the key[] buffer is dead after the build: it now holds the masks
-                if (qpart == 0) L.mask[p] = m;
+                if (qpart == 0) {
+#pragma unroll
+                    for (int w = 0; w < MW; w++) L.mask[(size_t)p * MW + w] = m[w];
+                }
                 if (qparts > 1) atomicAdd(&qcount[p], count);
                 else L.core[p] = count >= min_samples ? 1 : 0;
             }
@@ -1011,12 +1037,15 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             for (int f0 = 0; f0 < fcount; f0 += kFrontChunk) {
                 const int fc = fcount - f0 < kFrontChunk ? fcount - f0 : kFrontChunk;
                 if (f0 > 0) __syncthreads();  // the previous chunk has been consumed
+                constexpr int FS = MW == 1 ? 4 : 4 + MW;  // (db_front_stride)
                 if (tid < fc) {
                     const int pp = front[f0 + tid];
-                    L.fst[tid * 4 + 0] = __longlong_as_double((long long)L.mask[pp]);
-                    L.fst[tid * 4 + 1] = L.X[pp];
-                    L.fst[tid * 4 + 2] = L.Y[pp];
-                    L.fst[tid * 4 + 3] = L.Z[pp];
+                    L.fst[tid * FS + 0] = __longlong_as_double((long long)L.mask[(size_t)pp * MW]);
+                    L.fst[tid * FS + 1] = L.X[pp];
+                    L.fst[tid * FS + 2] = L.Y[pp];
+                    L.fst[tid * FS + 3] = L.Z[pp];
+#pragma unroll
+                    for (int w = 1; w < MW; w++) L.fst[tid * FS + 3 + w] = __longlong_as_double((long long)L.mask[(size_t)pp * MW + w]);
                 }
                 __syncthreads();
                 for (int q = tid; q < U; q += NT) {
@@ -1028,9 +1057,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                         double4 en[4];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            const double2 *e2 = reinterpret_cast<const double2 *>(L.fst + (f + u < fc ? f + u : f) * 4);
+                            const double2 *e2 = reinterpret_cast<const double2 *>(L.fst + (f + u < fc ? f + u : f) * FS);
                             const double2 a = e2[0], b = e2[1];
                             en[u] = make_double4(a.x, a.y, b.x, b.y);
+                            if constexpr (MW > 1) {  // the mask word this point's leaf lies in
+                                if ((lq >> 5) != 0) en[u].x = L.fst[(f + u < fc ? f + u : f) * FS + 3 + (lq >> 5)];
+                            }
                         }
                         // leaf states first: most (point, frontier point) pairs are PRUNE, and a wave's 64 points
                         // sit in one or two leaves, so the distance block below is skipped by whole waves
@@ -1038,7 +1070,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                         bool test = false;
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            stt[u] = (int)(((unsigned long long)__double_as_longlong(en[u].x) >> (2 * lq)) & 3ULL);
+                            stt[u] = (int)(((unsigned long long)__double_as_longlong(en[u].x) >> (2 * (lq & 31))) & 3ULL);
                             hit = hit || stt[u] == 1;
                             test = test || stt[u] == 2;
                         }
@@ -1199,7 +1231,7 @@ __device__ __forceinline__ void add_clusters(const DevCfg &cfg, const DevState &
     }
 }
 
-template <int NT, bool ALL8>
+template <int NT, bool ALL8, int MW = 1>
 __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &st, const DbLds &L, int s, int UMc, int CL, int UM_out,
                                             bool screened, int parity, int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
@@ -1208,7 +1240,7 @@ __device__ __forceinline__ void spawn_scene(const DevCfg &cfg, const DevState &s
     const int U = hdr->db_u;
     const RowSrc src = ring_rows_of(cfg, st, hdr, s);
     __syncthreads();  // every thread has read the header before anyone rewrites it below
-    const int ncl = dbscan_core<NT, ALL8>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, stats_slot(st, s), screened);
+    const int ncl = dbscan_core<NT, ALL8, MW>(cfg, L, src, U, UMc, cfg.db_eps, cfg.db_min_samples, stats_slot(st, s), screened);
     const int *labi = L.idx2;
     if (labels_out)
         for (int i = tid; i < U; i += NT) labels_out[(size_t)s * UM_out + i] = labi[i];
@@ -1763,6 +1795,56 @@ __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const d
     if (tid == 0 && ncl_out) ncl_out[s] = ncl;
 }
 
+// ---- Clouds of more than 1920 points (a context with ring * max_pts up to 4096: apply_DBscan itself has no limit,
+//      Utils.py:250-291) ----------------------------------------------------------------------------------------------------
+// 64 .. 128 leaves: the carve-up (up to ~0.5 MB) does not fit the LDS and lives in GLOBAL memory instead, one slab per worker
+// (DevState::huge_scratch) -- the same dbscan_core / add_clusters, instantiated over pointers into that slab: the address
+// space is the only difference (workgroup barriers order global memory inside a workgroup as they order the LDS: its waves
+// share the CU's L1, stores write through), and the leaf-state mask of a position is MW = 4 words instead of one.  A chain
+// of L2 round trips instead of LDS ones, several times slower per cloud: this is the path that makes such a context POSSIBLE
+// (a scene that lost its tracks clusters its whole ring), not one the step is tuned around.  k_track puts these scenes on
+// work list 2; one launch behind k_dbscan_big, only in contexts whose rings can hold such a cloud.
+constexpr int kHugeThreads = 512;
+constexpr int kHugeMW = 4;       // <= 128 leaves
+static_assert(MMW_RING_MAX * MMW_MAX_PTS_LIMIT <= 4096 && 2 * (MMW_RING_MAX * MMW_MAX_PTS_LIMIT / 30 + 1) <= 64 * 2 * kHugeMW, "the largest cloud: 12 position bits in the labelling's seed key, <= 128 leaves");
+constexpr int kHugeWorkers = 64;
+__global__ __launch_bounds__(kHugeThreads) void k_dbscan_huge(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity,
+                                                              int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
+{
+    DbLds L;
+    db_lds_layout<true>(UMc, CL, false, st.huge_scratch + (size_t)blockIdx.x * st.huge_stride, &L, kHugeMW);
+    const int count = st.db_count[parity * 4 + 2];
+    for (int w = blockIdx.x; w < count; w += gridDim.x) {
+        const int s = st.db_list[(size_t)2 * cfg.n_scenes + w];
+        if (cfg.seek_inner && !st.hdr[s].need_db) continue;  // cancelled by k_inner (uniform)
+        spawn_scene<kHugeThreads, false, kHugeMW>(cfg, st, L, s, UMc, CL, UM_out, false, parity, labels_out, db_n_out);
+        __syncthreads();  // the slab is reused by the next scene
+    }
+}
+
+// Utils.apply_DBscan on caller-provided clouds of more than 1920 points (mmw_dbscan): as k_dbscan_only, slab per workgroup
+__global__ __launch_bounds__(kHugeThreads) void k_dbscan_only_huge(DevCfg cfg, DevState st, int UM, int n_clouds, const double *__restrict__ pts,
+                                                                   const int32_t *__restrict__ n_all, int max_n, double eps, int min_samples,
+                                                                   int32_t *__restrict__ labels_out, int32_t *__restrict__ ncl_out)
+{
+    DbLds L;
+    db_lds_layout<true>(UM, 0, false, st.huge_scratch + (size_t)blockIdx.x * st.huge_stride, &L, kHugeMW);
+    const int tid = threadIdx.x;
+    for (int s = blockIdx.x; s < n_clouds; s += gridDim.x) {
+        const int U = n_all[s];
+        if (U <= 0 || U > UM) { if (tid == 0 && ncl_out) ncl_out[s] = 0; continue; }
+        RowSrc src;
+        src.gb = pts + (size_t)s * max_n * 8;
+        src.stride = 0;
+        src.slots = 0;
+        src.c1 = src.c2 = src.c3 = 0x7fffffff;
+        const int ncl = dbscan_core<kHugeThreads, false, kHugeMW>(cfg, L, src, U, UM, eps, min_samples, nullptr);
+        for (int i = tid; i < U; i += kHugeThreads) labels_out[(size_t)s * max_n + i] = L.idx2[i];
+        if (tid == 0 && ncl_out) ncl_out[s] = ncl;
+        __syncthreads();
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------
 static const int kClassUM[3] = {256, 768, 1920};
 
@@ -1780,7 +1862,7 @@ size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples)
     if (cls == 0) return tpp;
     return strided > tpp ? strided : tpp;  // k_dbscan_big carves either way per cloud
 }
-size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM, 0, false, nullptr, nullptr); }
+size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM < kClassUM[2] ? UM : kClassUM[2], 0, false, nullptr, nullptr); }
 
 static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
 {
@@ -1917,11 +1999,33 @@ void launch_dbscan_big(const DevCfg &cfg, const DevState &st, int UM, int u_boun
     mmw_launch(k_dbscan_big, dim3(g), dim3(kBigThreads), big_lds_bytes(um, cl, false), stream, cfg, st, um, cl, UM, parity, labels, db_n);
 }
 
-void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
+void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_dbscan_only, dim3(cfg.n_scenes), dim3(256), dbscan_only_lds_bytes(UM), stream, cfg, UM, pts, n, max_n, eps,
-                       min_samples, labels, ncl);
+    if (max_n > kClassUM[2]) {  // clouds the LDS cannot hold: slabs in global memory
+        const int g = cfg.n_scenes < kHugeWorkers ? cfg.n_scenes : kHugeWorkers;
+        hipLaunchKernelGGL(k_dbscan_only_huge, dim3(g), dim3(kHugeThreads), 0, stream, cfg, st, UM, cfg.n_scenes, pts, n, max_n, eps, min_samples,
+                           labels, ncl);
+        return;
+    }
+    const int umk = UM < kClassUM[2] ? UM : kClassUM[2];  // (a context whose rings hold more: the LDS classes stop at 1920)
+    hipLaunchKernelGGL(k_dbscan_only, dim3(cfg.n_scenes), dim3(256), dbscan_only_lds_bytes(umk), stream, cfg, umk, pts, n, max_n, eps, min_samples,
+                       labels, ncl);
+}
+
+// the clouds of more than 1920 points (work list 2): contexts whose rings can hold one
+int dbscan_huge_workers(int n_scenes) { return n_scenes < kHugeWorkers ? n_scenes : kHugeWorkers; }
+size_t dbscan_huge_slab_bytes(int UM, int t_cap, int min_samples)
+{
+    if (UM <= kClassUM[2]) return 0;
+    const size_t a = db_lds_layout<false>(UM, big_cl(UM, t_cap, min_samples), false, nullptr, nullptr, kHugeMW);
+    return (a + 255) & ~(size_t)255;
+}
+void launch_dbscan_huge(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
+{
+    if (UM <= kClassUM[2] || u_bound <= kClassUM[2]) return;  // no ring of this context can hold such a cloud (yet)
+    mmw_launch(k_dbscan_huge, dim3(dbscan_huge_workers(cfg.n_scenes)), dim3(kHugeThreads), 0, stream, cfg, st, UM, big_cl(UM, cfg.t_cap, cfg.db_min_samples), UM,
+               parity, labels, db_n);
 }
 
 }  // namespace mmw

@@ -877,12 +877,12 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
         if (listed) {
             // work list 3 = clouds <= 256 points (BallTree + _add_tracks), queue 1 = the larger ones: k_post's worker blocks
             // take both after this launch (no side-stream workers beside a context this small)
-            const int cl3 = U <= 256 ? 3 : 1;
+            const int cl3 = U <= 256 ? 3 : (U <= kBigCloudMax ? 1 : 2);  // (list 2: k_dbscan_huge, contexts whose rings hold more than the LDS classes)
             if (tid == 0) {
-                int32_t *cnt = cl3 == 3 ? st.db_count + parity * 4 + 3 : st.q + kQBig + parity * 8 + kQCount;
+                int32_t *cnt = cl3 >= 2 ? st.db_count + parity * 4 + cl3 : st.q + kQBig + parity * 8 + kQCount;
                 const int pos = atomicAdd(cnt, 1);
                 int32_t *e = st.db_list + (size_t)cl3 * cfg.n_scenes + pos;
-                if (cl3 == 3) *e = s;
+                if (cl3 >= 2) *e = s;
                 else __hip_atomic_store(e, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {

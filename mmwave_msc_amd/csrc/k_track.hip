@@ -914,7 +914,8 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             // i.e. the ones whose DBSCAN may be a ~60 us BallTree chain; queue 1 = the clouds of more than 256 points
             // (100-250 us each).  Everything this workgroup has stored for the scene must be visible device-wide before the
             // queue entry is -- one workgroup barrier + a release store, paid by those scenes only.
-            const int cls = Udb <= 256 ? (Udb >= kEarlyU && cfg.side_worker ? 0 : 3) : 1;  // uniform
+            // (work list 2 = the clouds the LDS cannot hold, k_dbscan_huge: only in contexts with ring * max_pts > kBigCloudMax)
+            const int cls = Udb <= 256 ? (Udb >= kEarlyU && cfg.side_worker ? 0 : 3) : (Udb <= kBigCloudMax ? 1 : 2);  // uniform
             // (a device-scope release writes this XCD's L2 back: in the start-up frames, when EVERY scene pushes a large cloud
             //  and the side workers could take a handful, the entries are stored plainly for the kernels behind this one --
             //  cfg.big_live; frame 0 of 4096 scenes: k_track 386 -> 120 us)
@@ -923,10 +924,10 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             if (tid == 0) {
                 // (queues: the RELEASE of the entry's store is the only fence: it follows the workgroup barrier, so it covers
                 //  what the other waves stored; a full __threadfence() here would also invalidate this CU's caches)
-                int32_t *cnt = cls == 3 ? st.db_count + parity * 4 + 3 : st.q + cls * kQBig + parity * 8 + kQCount;
+                int32_t *cnt = cls >= 2 ? st.db_count + parity * 4 + cls : st.q + cls * kQBig + parity * 8 + kQCount;
                 const int pos = atomicAdd(cnt, 1);  // (< n_scenes: one push per scene and step)
                 int32_t *e = st.db_list + (size_t)cls * cfg.n_scenes + pos;
-                if (cls == 3) *e = s;
+                if (cls >= 2) *e = s;
                 else if (live) __hip_atomic_store(e, s + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 else __hip_atomic_store(e, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

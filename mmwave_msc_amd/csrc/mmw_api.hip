@@ -36,7 +36,10 @@ hipError_t prepare_inner(const DevCfg &cfg);
 size_t inner_lds_demand(const DevCfg &cfg);
 int inner_um(const DevCfg &cfg);
 void launch_inner(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int32_t *db_n, hipStream_t stream);
-void launch_dbscan_only(const DevCfg &cfg, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
+int dbscan_huge_workers(int n_scenes);
+size_t dbscan_huge_slab_bytes(int UM, int t_cap, int min_samples);
+void launch_dbscan_huge(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
+void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
 void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
@@ -261,7 +264,10 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (cfg->fb_frames_batch < 0 || cfg->fb_frames_batch + 1 > MMW_RING_MAX) return fail(nullptr, MMW_E_ARG, "FB_FRAMES_BATCH must be in [0,%d]", MMW_RING_MAX - 1);
     if (cfg->dim_x != 9 && cfg->dim_x != 6) return fail(nullptr, MMW_E_ARG, "dim_x must be 9 (CONST_ACC_MODEL) or 6 (CONST_VEL_MODEL)");
     const int ring = cfg->fb_frames_batch + 1;
-    if (ring * max_pts > 30 * 64) return fail(nullptr, MMW_E_ARG, "ring*max_pts = %d exceeds 1920 (BallTree emulation holds <= 32 leaves)", ring * max_pts);
+    // (apply_DBscan has no size limit, Utils.py:250-291; here a cloud is at most the ring: MMW_RING_MAX frames of MMW_MAX_PTS_LIMIT
+    //  points.  Up to 1920 points its BallTree lives in the LDS; larger ones -- only contexts with ring * max_pts > 1920 can
+    //  see them -- run on slabs in global memory, k_dbscan_huge)
+    if (ring * max_pts > MMW_RING_MAX * MMW_MAX_PTS_LIMIT) return fail(nullptr, MMW_E_ARG, "ring*max_pts = %d exceeds %d", ring * max_pts, MMW_RING_MAX * MMW_MAX_PTS_LIMIT);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, MMW_E_NODEVICE, "no HIP device visible: libmmw_hip has no CPU path");
     if (device < 0 || device >= ndev) return fail(nullptr, MMW_E_NODEVICE, "device %d not available (%d visible)", device, ndev);
@@ -404,6 +410,14 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap, cfg->db_min_samples);
     if (e1 == hipSuccess && scene_lds_bytes(d) <= 160 * 1024) e1 = prepare_scene(d);
     if (e1 != hipSuccess || e2 != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(max dynamic LDS) failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
+    c->st.huge_scratch = nullptr;
+    c->st.huge_stride = dbscan_huge_slab_bytes(c->UM, cap, cfg->db_min_samples);
+    if (c->st.huge_stride) {   // a ring of this context can hold a cloud the LDS cannot: one BallTree slab per worker of k_dbscan_huge
+        if (hipMalloc((void **)&c->st.huge_scratch, c->st.huge_stride * (size_t)dbscan_huge_workers(n_scenes)) != hipSuccess) {
+            mmw_destroy(c);
+            return fail(nullptr, MMW_E_HIP, "hipMalloc(%zu B of BallTree slabs) failed", c->st.huge_stride * (size_t)dbscan_huge_workers(n_scenes));
+        }
+    }
     launch_reset(d, c->st, nullptr, c->stream);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "reset kernel failed: %s", hipGetErrorString(hipGetLastError())); }
     *out = c;
@@ -422,7 +436,7 @@ int mmw_destroy(mmw_ctx *c)
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
-                    c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export};
+                    c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export, c->st.huge_scratch};
     for (void *p : ptrs) if (p) hipFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
     if (c->h_rows) hipHostFree(c->h_rows);
@@ -649,6 +663,7 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_DBSCAN, ep);
     launch_dbscan_big(c->dc, c->st, c->UM, u_bound, c->step_parity, db_labels, db_n, c->stream);
+    launch_dbscan_huge(c->dc, c->st, c->UM, u_bound, c->step_parity, db_labels, db_n, c->stream);  // (contexts with ring * max_pts > 1920 only)
     prof_armed_done(c, ep);
     if (c->pending.size() >= 2048) prof_fold(c);
     c->step_parity ^= 1;
@@ -693,7 +708,7 @@ int mmw_dbscan(mmw_ctx *c, const double *pts, const int32_t *n, int32_t max_n, d
     if (!c || !pts || !n || !labels) return fail(c, MMW_E_ARG, "mmw_dbscan: null pointer");
     if (max_n < 1 || max_n > c->UM) return fail(c, MMW_E_ARG, "mmw_dbscan: max_n=%d must be in [1, ring*max_pts=%d]", max_n, c->UM);
     HIPCHK(c, hipSetDevice(c->device));
-    launch_dbscan_only(c->dc, c->UM, pts, n, max_n, eps, min_samples, labels, n_clusters, c->stream);
+    launch_dbscan_only(c->dc, c->st, c->UM, pts, n, max_n, eps, min_samples, labels, n_clusters, c->stream);
     HIPCHK(c, hipGetLastError());
     return MMW_OK;
 }

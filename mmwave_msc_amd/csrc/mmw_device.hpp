@@ -15,6 +15,7 @@ constexpr int kGateChunk = 16;      // tracks whose gate matrices sit in LDS at 
 constexpr int kGateRec = 44;        // doubles per gate record: Ci[36] | log|det| | predicted position hx[6] | pad
 constexpr int kLeafSize = 30;       // sklearn BallTree default leaf_size (DBSCAN passes it through)
 constexpr int kMaxLeaves = 32;      // n <= 1920 -> <= 63 nodes -> <= 32 leaves
+constexpr int kBigCloudMax = 30 * 64;  // = 1920: the largest cloud whose BallTree carve-up fits the LDS; larger ones (work list 2) run on slabs in global memory
 constexpr int kMaxNodes = 63;
 
 // per-scene error bits (sticky until mmw_reset)
@@ -96,7 +97,7 @@ struct DevState {
     double *g_ring;       // [S][ring][max_pts][8]
     const float *default_posture;  // [57]
     unsigned long long *stats;     // [kStatSlots][32] algorithmic-byte / work counters (see mmw_stats_get), summed on read-out
-    int32_t *db_list;              // [4][S] scenes whose apply_DBscan the cell count could not finish this step, filled by k_track: list 3 = clouds <= 256 points (k_post); rows 0 and 1 are the rings of the two queues below
+    int32_t *db_list;              // [4][S] scenes whose apply_DBscan the cell count could not finish this step, filled by k_track: list 3 = clouds <= 256 points (k_post), list 2 = clouds of more than kBigCloudMax points (k_dbscan_huge); rows 0 and 1 are the rings of the two queues below
     int32_t *db_count;             // [2][4] list lengths, double-buffered by step parity (list 3)
     int32_t *q;                    // [kQWords] the early queue = list 0 (n_scenes entries, 0 = empty, else scene + 1), per step parity p at
                                    // q[8p + ...]: kQCount pushes, kQHead claims, kQDone finished items of the step (reset a step ahead by
@@ -110,6 +111,8 @@ struct DevState {
     int32_t *spc_list;             // [2][S][2] ... (scene, first new track): scenes that spawned tracks this frame
     int32_t *inner_buf;            // [S][kInnerHdr + inner_cap] seek_inner_clusters calls of the last frame (cfg.seek_inner; mmw_get_inner)
     int32_t inner_cap;             // label words per scene
+    char *huge_scratch;            // [workers][huge_stride] BallTree carve-ups of the clouds of more than kBigCloudMax points (k_dbscan_huge); null when no ring of the context can hold one
+    size_t huge_stride;
 };
 // Contexts of at most this many scenes run a two-launch step (mmw_kalman.hpp: pred_in_track, k_dbscan.hip: k_post takes the large
 // clouds): their step is launch latency.  768 = what is resident at once with the PRED build of k_track (three workgroups

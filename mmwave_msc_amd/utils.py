@@ -20,7 +20,7 @@ import numpy as np
 from . import constants as const
 from .batch import SceneBatch
 
-_UTIL_MAX_PTS = 960   # with ring 2: DBSCAN clouds up to 1920 points (the BallTree emulation's limit)
+_UTIL_MAX_PTS = 1024  # MMW_MAX_PTS_LIMIT; with ring 2: DBSCAN clouds up to 2048 points, ring 4 (dbscan_labels on larger ones): 4096
 _ctx_cache = {}
 
 
@@ -32,7 +32,7 @@ def _util_ctx(**cfg_over) -> SceneBatch:
         kw = dict(fb_frames_batch=1)
         kw.update(cfg_over)
         ring = kw["fb_frames_batch"] + 1
-        sb = SceneBatch(const.to_config(**kw), 1, min(_UTIL_MAX_PTS, 1920 // ring))
+        sb = SceneBatch(const.to_config(**kw), 1, min(_UTIL_MAX_PTS, 4096 // ring))
         _ctx_cache[key] = sb
     return sb
 
@@ -127,6 +127,8 @@ def dbscan_labels(pointcloud, eps=None, min_samples=None) -> np.ndarray:
     if n == 0:
         return np.zeros(0, dtype=np.int32)
     sb = _util_ctx()
+    if n > sb.UM:
+        sb = _util_ctx(fb_frames_batch=3)   # capacity only: the largest cloud a context can hold (4 frames of 1024 points)
     if n > sb.UM:
         raise ValueError(f"apply_DBscan on {n} points: the GPU BallTree emulation holds at most {sb.UM}")
     pts = np.zeros((1, n, 8))

@@ -223,6 +223,27 @@ def gen_dbscan():
     print(f"  dbscan: sizes {sizes}")
 
 
+def gen_dbscan_huge():
+    """apply_DBscan on clouds of more than 1920 points (64 .. 128 BallTree leaves): the reference has no size limit
+    (Utils.py:250-291); here they run on slabs in global memory (k_dbscan_huge).  A separate file so that dbscan.npz
+    stays byte-stable."""
+    const, utils, _ = load_reference()
+    from sklearn.cluster import DBSCAN
+    sizes = [1921, 2500, 3072, 3841, 4096]
+    data = {}
+    for n in sizes:
+        f = 4
+        per = -(-n // f)
+        pts, _, _ = make_scene(7000 + n, f, per, 8)
+        x = pts.reshape(-1, 8)[:n].astype(np.float64)
+        for ms in (35, 8):
+            lab = DBSCAN(eps=const.DB_EPS, min_samples=ms, metric=utils.altered_EuclideanDist).fit_predict(x)
+            data[f"labels_{n}_{ms}"] = lab.astype(np.int16)
+        data[f"pts_{n}"] = x.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "dbscan_huge.npz"), sizes=np.array(sizes), meta=_meta(), **data)
+    print(f"  dbscan_huge: sizes {sizes}, clusters {[int(data[f'labels_{n}_35'].max()) + 1 for n in sizes]} / {[int(data[f'labels_{n}_8'].max()) + 1 for n in sizes]}")
+
+
 def gen_offline():
     """OfflineManager + offline_main dt logic (Utils.py:53-177, offline_main.py:40-62).
     offline_main.py itself cannot be imported (PyQt5/keras); its loop is 12 lines and
@@ -625,6 +646,8 @@ def main():
         gen_normalize()
     if not args.only or args.only == "dbscan":
         gen_dbscan()
+    if not args.only or args.only == "dbscan_huge":
+        gen_dbscan_huge()
     if not args.only or args.only == "offline":
         gen_offline()
     if not args.only or args.only == "formatters":

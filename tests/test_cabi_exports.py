@@ -46,7 +46,9 @@ def test_create_fails_loudly_without_gpu_or_with_bad_args():
     cfg = _lib.default_config()
     h = C.c_void_p()
     assert L.mmw_create(C.byref(cfg), 1, 4096, 0, C.byref(h)) == _lib.E_ARG  # max_pts limit
-    assert L.mmw_create(C.byref(cfg), 1, 1000, 0, C.byref(h)) == _lib.E_ARG  # ring*max_pts > 1920
+    cfg5 = _lib.default_config(fb_frames_batch=4)
+    assert L.mmw_create(C.byref(cfg5), 1, 256, 0, C.byref(h)) == _lib.E_ARG  # ring = FB_FRAMES_BATCH + 1 > MMW_RING_MAX
+    # (ring * max_pts itself has no limit of its own any more: clouds of more than 1920 points run on k_dbscan_huge)
     if not torch.cuda.is_available():
         rc = L.mmw_create(C.byref(cfg), 1, 256, 0, C.byref(h))
         assert rc in (_lib.E_NODEVICE, _lib.E_HIP) and not h.value

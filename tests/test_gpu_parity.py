@@ -637,6 +637,93 @@ def test_largest_capacity_context_vs_oracle():
     sb.close()
 
 
+def test_dbscan_of_more_than_1920_points_golden():
+    """apply_DBscan has no size limit (Utils.py:250-291); a context's largest cloud is its ring, MMW_RING_MAX x
+    MMW_MAX_PTS_LIMIT = 4096 points.  Above 1920 points (64 .. 128 BallTree leaves) the carve-up lives in global memory
+    (k_dbscan_only_huge / k_dbscan_huge, four mask words per position): sklearn's labels on the reference's metric for
+    1921 .. 4096 points, and the smaller golden clouds through the same context (they take the LDS kernel)."""
+    z = np.load(os.path.join(GOLDEN, "dbscan_huge.npz"))
+    sizes = [int(v) for v in z["sizes"]]
+    mx = max(sizes)
+    sb = _mk(len(sizes), 1024, fb_frames_batch=3)
+    assert sb.UM == 4096
+    pts = np.zeros((len(sizes), mx, 8))
+    n = np.array(sizes, np.int32)
+    for i, sz in enumerate(sizes):
+        pts[i, :sz] = z[f"pts_{sz}"]
+    for ms in (35, 8):
+        labels, ncl = sb.dbscan_host(pts, n, min_samples=ms)
+        for i, sz in enumerate(sizes):
+            want = z[f"labels_{sz}_{ms}"]
+            assert np.array_equal(labels[i, :sz], want), f"n={sz} min_samples={ms}"
+            assert ncl[i] == want.max() + 1
+    zs = np.load(os.path.join(GOLDEN, "dbscan.npz"))
+    small = [int(v) for v in zs["sizes"]][-len(sizes):]
+    pts2 = np.zeros((len(sizes), max(small), 8))
+    for i, sz in enumerate(small):
+        pts2[i, :sz] = zs[f"pts_{sz}"]
+    labels, ncl = sb.dbscan_host(pts2, np.array(small, np.int32), min_samples=35)
+    for i, sz in enumerate(small):
+        assert np.array_equal(labels[i, :sz], zs[f"labels_{sz}_35"]), sz
+    sb.check()
+    sb.close()
+
+
+def test_rings_of_more_than_1920_points_vs_oracle():
+    """ring * max_pts = 4 x 960: scenes of clutter keep clustering their whole ring -- 960, 1920, 2880, 3840 points: the last
+    two on k_dbscan_huge (work list 2) --, and scenes whose targets return 10 points a frame get their clusters only once
+    the ring holds four frames of them (min_samples 35), i.e. from a cloud of > 1920 points: labels, spawned tracks and every
+    later frame equal the oracle."""
+    from oracle import c_oracle as co
+    from mmwave_msc_amd.synth import make_batch
+    S, N, T, F = 9, 960, 4, 8
+    rng = np.random.default_rng(77)
+    pts = np.zeros((F, S, N, 8), np.float32)
+    pts[..., 0] = rng.uniform(-6, 6, size=(F, S, N))
+    pts[..., 1] = rng.uniform(0.3, 7.5, size=(F, S, N))
+    pts[..., 2] = rng.uniform(0.05, 2.4, size=(F, S, N))
+    pts[..., 3:6] = rng.normal(0, 0.05, size=(F, S, N, 3))
+    pts[..., 6] = rng.normal(0, 0.3, size=(F, S, N))
+    pts[..., 7] = rng.gamma(1.0, 30.0, size=(F, S, N))
+    for s in range(S):
+        if s % 3 == 0:
+            continue   # clutter only
+        for k in range(1 + s % 2):   # one or two faint targets: 10 points a frame each
+            c = np.array([-2.0 + 3.0 * k + 0.3 * s, 2.0 + 0.5 * s])
+            for f in range(F):
+                idx = rng.choice(N, size=10, replace=False)
+                pts[f, s, idx, 0:2] = (c + rng.normal(0, 0.06, size=(10, 2))).astype(np.float32)
+                pts[f, s, idx, 2] = rng.uniform(0.6, 1.4, size=10).astype(np.float32)
+    cnt = np.full((F, S), N, np.int32)
+    dts = np.full((F, S), 0.1)
+    kw = dict(tr_max_tracks=T, fb_frames_batch=3)
+    sb = _mk(S, N, **kw)
+    assert sb.UM == 3840
+    ob = co.OracleBatch(co.default_config(**kw), S, N)
+    biggest = clustered_big = 0
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        oa, ol, od = ob.step(pts[f].astype(np.float64), cnt[f], dts[f])
+        assert np.array_equal(dbn, od), f
+        assert np.array_equal(assoc, oa), f
+        for s in range(S):
+            if od[s] > 0:
+                assert np.array_equal(labels[s, : od[s]], ol[s, : od[s]]), (f, s)
+                if od[s] > 1920 and ol[s, : od[s]].max() >= 0:
+                    clustered_big += 1
+        biggest = max(biggest, int(od.max()))
+    assert biggest > 3000 and clustered_big > 0, (biggest, clustered_big)
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    for s in range(S):
+        want = ob.scenes[s].tracks()
+        assert ntr[s] == len(want), s
+        for name in ("x", "P", "centroid", "spread_est", "n_est", "lifetime", "point_num", "ring_n"):
+            assert np.array_equal(trk[s, : ntr[s]][name], want[name]), (s, name)
+    sb.check()
+    sb.close()
+
+
 def test_two_side_worker_contexts_in_one_process():
     """Two contexts with DBSCAN chain workers (each its own side stream) stepped alternately on their own streams: streams are
     multiplexed onto a few hardware queues, a polling worker must never keep a context's own kernels waiting for its

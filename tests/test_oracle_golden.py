@@ -78,6 +78,17 @@ def test_dbscan_matches_sklearn_golden():
         assert np.array_equal(sizes, z[f"sizes_{n}"])
 
 
+def test_dbscan_of_more_than_1920_points_matches_sklearn_golden():
+    """64 .. 128 BallTree leaves (Utils.py:250-291 has no size limit): the oracle the GPU's global-memory path is checked
+    against, pinned on sklearn's labels for the reference's own metric."""
+    z = np.load(os.path.join(GOLDEN, "dbscan_huge.npz"))
+    cfg = co.default_config()
+    for n in z["sizes"]:
+        pts = z[f"pts_{n}"].astype(np.float64)
+        for ms in (35, 8):
+            assert np.array_equal(co.dbscan(cfg, pts, min_samples=ms), z[f"labels_{n}_{ms}"]), f"n={n} min_samples={ms}"
+
+
 def test_log_and_pairwise_sum_helpers():
     import math
 
