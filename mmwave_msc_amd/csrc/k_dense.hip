@@ -181,6 +181,115 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
     }
 }
 
+// ---- 256 x 192 tiles, for feature counts that are a multiple of 192 (define_CNN_3D: 1536): fewer bytes from L2 per
+//      multiply-add (56 KB per K-step for 1.5 x the work of the 48 KB of a 256 x 128 tile) and a third fewer workgroups.  Two
+//      accumulator sets of a 64 x 96 wave tile are 192 of the 256 registers a lane has at two waves per SIMD (fragment
+//      addresses derived from one register per operand: 255 VGPRs, no scratch -- a spilled build's scratch traffic counts in
+//      vmcnt and breaks the counted waits: 1.04 ms); the LDS holds a ring of three A tiles (two in flight) and of two W
+//      tiles (one in flight: the weights are L2-resident) = 144 KB.  Same K order per output element: bit-identical results.
+//      Measured 0.988 against 1.023 ms on one box (18 304 x 6144 x 1536): the staging bytes are not all that holds the 256 x 128
+//      tile back. ----
+namespace dense192 {
+constexpr int BN2 = 192;
+constexpr int kA = 256 * kRowBytes, kW = BN2 * kRowBytes;   // 32 KB, 24 KB
+constexpr int kLds = 3 * kA + 2 * kW;                        // 144 KB
+}
+__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
+                                                                  long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
+                                                                  int tiles_n)
+{
+    using namespace dense192;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long long m0 = (long long)tm * 256;
+    const int n0 = tn * BN2;
+    const _Float16 *srcA[4], *srcW[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = (wave * 4 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+        srcA[i] = a2 + (m0 + row) * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int u = (wave * 3 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+        srcW[i] = w2 + (long long)(n0 + row) * ldw + c * 8;
+    }
+    auto issueA = [&](int kt) {
+        char *b = lds + (kt % 3) * kA;
+#pragma unroll
+        for (int i = 0; i < 4; i++) glds16(srcA[i] + kt * (2 * BK), b + (wave * 4 + i) * 1024);
+    };
+    auto issueW = [&](int kt) {
+        char *b = lds + 3 * kA + (kt & 1) * kW;
+#pragma unroll
+        for (int i = 0; i < 3; i++) glds16(srcW[i] + kt * (2 * BK), b + (wave * 3 + i) * 1024);
+    };
+    // fragment addresses: one register per operand -- tile x / y is 32 rows = 4096 bytes further, the second half step (kk = 1)
+    // flips bit 5 of the offset (unit c ^ 2), lo' bit 6
+    const int offA0 = unit_off(wm * 64 + (lane & 31), lane >> 5), offW0 = unit_off(wn * 96 + (lane & 31), lane >> 5);
+    df16 am[2][3], ac[2][3];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
+    const int KT = K / BK;
+    // issue order per step: W(kt + 1), then A(kt + 2) -- so that "everything but the last A tile" is what step kt + 1 waits for
+    issueW(0);
+    issueA(0);
+    if (KT > 1) issueA(1);
+    for (int kt = 0; kt < KT; kt++) {
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < KT) issueW(kt + 1);
+        if (kt + 2 < KT) issueA(kt + 2);
+        const char *ba = lds + (kt % 3) * kA, *bw = lds + 3 * kA + (kt & 1) * kW;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            dh8 wh[3], wl[3];
+#pragma unroll
+            for (int y = 0; y < 3; y++) {
+                wh[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32)) + y * 4096));
+                wl[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32) ^ 64) + y * 4096));
+            }
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                const dh8 ah = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32)) + x * 4096));
+                const dh8 al = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32) ^ 64) + x * 4096));
+#pragma unroll
+                for (int y = 0; y < 3; y++) {
+                    am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[y], am[x][y], 0, 0, 0);
+                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[y], ac[x][y], 0, 0, 0);
+                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[y], ac[x][y], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+#pragma unroll
+    for (int y = 0; y < 3; y++) {
+        const int col = n0 + wn * 96 + y * 32 + (lane & 31);
+        const float bv = bias[col];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (am[x][y][r] + ac[x][y][r] * kInvSplit) + bv;
+                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);
+            }
+        }
+    }
+}
+
 // rows_padded: a multiple of 256; K a multiple of 32; N a multiple of 128.
 // The tile list is cut where its last wave of workgroups would fill less than half the chip: bands of 256 rows that make whole
 // waves go to the 256-row instantiation, the rest -- as twice as many 128-row tiles -- to the other (18 304 rows x 1536: 864
@@ -208,6 +317,27 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
         if (2LL * (bands - bands_main) * tiles_n > n_cu) bands_main = bands;   // (the remainder would be more than one wave of half tiles)
     }
     const _Float16 *A = reinterpret_cast<const _Float16 *>(a2), *W = reinterpret_cast<const _Float16 *>(w2);
+    if (N % dense192::BN2 == 0) {   // 256 x 192 tiles for the whole waves of workgroups, the rest as below
+        static bool prep2 = false;
+        if (!prep2) {
+            if (hipFuncSetAttribute((const void *)k_mars_dense1_w192, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return -1;
+            prep2 = true;
+        }
+        const int tn2 = N / dense192::BN2;
+        int bm2 = (int)((((long long)bands * tn2 / n_cu) * n_cu) / tn2);   // whole waves of 256 x 192 tiles, cut at a band boundary
+        if (bm2 > 0)
+            hipLaunchKernelGGL(k_mars_dense1_w192, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
+        if (bm2 < bands) {
+            const long long rest = (long long)(bands - bm2) * tiles_n;
+            if (2 * rest <= n_cu)
+                hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * rest), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias, out, K, N,
+                                   (long long)bm2 * BM, tiles_n);
+            else
+                hipLaunchKernelGGL(k_mars_dense1<256>, dim3(rest), dim3(kThreads), lds_bytes(256), stream, A, lda, W, ldw, bias, out, K, N,
+                                   (long long)bm2 * BM, tiles_n);
+        }
+        return 0;
+    }
     if (bands_main > 0)
         hipLaunchKernelGGL(k_mars_dense1<256>, dim3(bands_main * tiles_n), dim3(kThreads), lds_bytes(256), stream, A, lda, W, ldw, bias, out, K, N, 0LL,
                            tiles_n);
