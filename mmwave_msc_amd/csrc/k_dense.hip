@@ -324,18 +324,17 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
             prep2 = true;
         }
         const int tn2 = N / dense192::BN2;
-        int bm2 = (int)((((long long)bands * tn2 / n_cu) * n_cu) / tn2);   // whole waves of 256 x 192 tiles, cut at a band boundary
+        const long long total2 = (long long)bands * tn2, rem2 = total2 % n_cu;
+        int bm2 = bands;
+        if (rem2 != 0 && 2 * rem2 <= n_cu) {   // the last wave of workgroups would fill less than half the chip: cut it off at a band boundary
+            bm2 = (int)(((total2 / n_cu) * n_cu) / tn2);
+            if (2LL * (bands - bm2) * tiles_n > n_cu) bm2 = bands;   // (... unless the rest is more than one wave of 128 x 128 half tiles)
+        }
         if (bm2 > 0)
             hipLaunchKernelGGL(k_mars_dense1_w192, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
-        if (bm2 < bands) {
-            const long long rest = (long long)(bands - bm2) * tiles_n;
-            if (2 * rest <= n_cu)
-                hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * rest), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias, out, K, N,
-                                   (long long)bm2 * BM, tiles_n);
-            else
-                hipLaunchKernelGGL(k_mars_dense1<256>, dim3(rest), dim3(kThreads), lds_bytes(256), stream, A, lda, W, ldw, bias, out, K, N,
-                                   (long long)bm2 * BM, tiles_n);
-        }
+        if (bm2 < bands)
+            hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * (bands - bm2) * tiles_n), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias, out, K,
+                               N, (long long)bm2 * BM, tiles_n);
         return 0;
     }
     if (bands_main > 0)

@@ -95,7 +95,7 @@ def test_split_fp16_cnn_holds_the_fp32_tolerance(frames, n):
     assert not m16.range_overflow()
 
 
-@pytest.mark.parametrize("frames,n", [(3, 700), (3, 256), (1, 1000), (1, 3)])
+@pytest.mark.parametrize("frames,n", [(3, 700), (3, 256), (3, 8500), (1, 1000), (1, 3)])   # 8500 rows x 1536: a whole wave of 256 x 192 tiles + half tiles
 def test_fused_dense1_kernel_vs_two_gemms_and_fp64(frames, n):
     """Dense-1 of the split arithmetic as ONE kernel (mmw_mars_dense1_split, csrc/k_dense.hip: train.py:49,87 with BN folded in)
     against the two-GEMM formulation it replaces (hi.W_hi and [hi | lo'].[W_lo' ; W_hi] through torch / hipBLASLt) and against
