@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
     constexpr int NT = BN / WN / 32;                 // MFMA tiles of a wave along the features (2 or 1); two along the rows
     constexpr int CA = TBM / 64;                     // DMA chunks of the A tile per wave (4 or 2); the W tile: 2
     constexpr int kATile = a_tile(TBM), kBuf = buf_bytes(TBM);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: see k_mars_dense1_w192)
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: workgroups are dealt to the eight XCDs round-robin; a group of consecutive LOGICAL tiles (one band of
     // batch rows against all feature tiles) goes to one XCD, whose L2 then serves the band's activations to every tile of it
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
 //      addresses derived from one register per operand: 255 VGPRs, no scratch -- a spilled build's scratch traffic counts in
 //      vmcnt and breaks the counted waits: 1.04 ms); the LDS holds a ring of three A tiles (two in flight) and of two W
 //      tiles (one in flight: the weights are L2-resident) = 144 KB.  Same K order per output element: bit-identical results.
-//      Measured 0.988 against 1.023 ms on one box (18 304 x 6144 x 1536): the staging bytes are not all that holds the 256 x 128
-//      tile back. ----
+//      Measured 0.924-0.931 against 0.997-1.001 ms on one box (18 304 x 6144 x 1536), with the wave index scalar (ring slots,
+//      tile origins and DMA destinations in SGPRs). ----
 namespace dense192 {
 constexpr int BN2 = 192;
 constexpr int kA = 256 * kRowBytes, kW = BN2 * kRowBytes;   // 32 KB, 24 KB
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
 {
     using namespace dense192;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: ring slots and tile origins stay out of the VGPRs)
     const int wm = wave >> 1, wn = wave & 1;
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
@@ -244,12 +244,16 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
     issueA(0);
     if (KT > 1) issueA(1);
     for (int kt = 0; kt < KT; kt++) {
-        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const bool moreW = kt + 1 < KT, moreA = kt + 2 < KT;
+        if (moreW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the four pieces of A(kt + 1)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < KT) issueW(kt + 1);
-        if (kt + 2 < KT) issueA(kt + 2);
+        // The seven DMA pieces of this step (W(kt + 1), then A(kt + 2): the order the counted wait relies on) are issued BETWEEN
+        // the MFMA groups of the first half step, one per three MFMAs, not in a block behind the barrier (measured: 0.5 % over
+        // the block; peeling the last two steps off so that no branch sits between the MFMAs: nothing, at 256 VGPRs)
+        char *dw = lds + 3 * kA + ((kt + 1) & 1) * kW + wave * 3 * 1024, *da = lds + ((kt + 2) % 3) * kA + wave * 4 * 1024;
+        const int kw1 = __builtin_amdgcn_readfirstlane((kt + 1) * (2 * BK)), ka2 = __builtin_amdgcn_readfirstlane((kt + 2) * (2 * BK));
         const char *ba = lds + (kt % 3) * kA, *bw = lds + 3 * kA + (kt & 1) * kW;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -269,6 +273,11 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
                     am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[y], am[x][y], 0, 0, 0);
                     ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[y], ac[x][y], 0, 0, 0);
                     ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[y], ac[x][y], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kk == 0 && x == 0) { if (moreW) glds16(srcW[y] + kw1, dw + y * 1024); }
+                    else if (kk == 0 && x == 1) { if (moreA) glds16(srcA[y] + ka2, da + y * 1024); }
+                    else if (kk == 1 && x == 0 && y == 0) { if (moreA) glds16(srcA[3] + ka2, da + 3 * 1024); }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
