@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
     bool over = false;   // an input outside fp16's range was split (range_flag) ...
     float amax = 0.f;    // ... largest activation magnitude split so far
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the wave's LDS region and sample index stay out of the VGPRs)
     // ---- LDS carve-up ----
     h8 *W1hi = reinterpret_cast<h8 *>(lds_raw);                 // [kS1][64] conv1 A fragments (shared)
     h8 *W1lo = W1hi + C::kS1 * 64;
