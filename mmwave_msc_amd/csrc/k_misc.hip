@@ -132,55 +132,76 @@ __device__ inline void sort_rows_store(int lane, double v0, double v1, double v2
     dst[lane * 5 + 4] = (float)s4;
 }
 
-// One wave per (eligible track, ring frame): lane r owns row r of the 64-row frame.
+// One wave per (eligible track, ring frame): lane r owns row r of the 64-row frame.  A workgroup = a scene: lane j of every wave
+// first reads what track j's frames need (slot, ring sizes and slots, centroid: one round trip for the whole scene), a ballot
+// gives every eligible track its output row, and the (track, frame) items are then dealt over the four waves -- each item one
+// more round trip (its rows).  (Track after track with the waves over the frames, every step behind the previous one's loads,
+// this kernel took 120 us for 18 k tracks: 0.27 of the HBM rate for 290 MB.)
 __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const int32_t *__restrict__ row_off,
                                                   float *__restrict__ feat, int32_t *__restrict__ owner, int32_t *__restrict__ uid,
                                                   int cap_rows)
 {
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SceneHdr *hdr = st.hdr + s;
     const int32_t *order = st.order + (size_t)s * cfg.t_cap;
     const TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
-    const int T = hdr->n_tracks, ring = cfg.ring;
-    int row = row_off[s];
-    unsigned long long rd_bytes = 0, rows_done = 0;
-    for (int j = 0; j < T; j++) {
-        const int slot = order[j];
+    const int T = hdr->n_tracks, ring = cfg.ring;   // (T <= t_cap <= 64: one lane per track)
+    const int row0 = row_off[s];
+    int slot = 0, rlen = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0, rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, uidv = 0;
+    double cx = 0.0, cy = 0.0;
+    bool elig = false;
+    if (lane < T) {
+        slot = order[lane];
         const TrackRec *rec = trk + slot;
-        int total = 0;
-        for (int k = 0; k < rec->ring_len; k++) total += rec->ring_n[k];
-        if (!(total > cfg.model_min_input)) continue;
-        if (row >= cap_rows) break;
-        for (int k = 0; k < rec->ring_len; k++) rd_bytes += 64ULL * min(rec->ring_n[k], 64);
-        rows_done++;
-        if (tid == 0) {
-            owner[row * 2] = s;
-            owner[row * 2 + 1] = j;
-            if (uid) uid[row] = rec->uid;
-        }
-        const double cx = rec->centroid[0], cy = rec->centroid[1];
-        for (int k = wave; k < ring; k += 4) {
-            float *dst = feat + (((size_t)row * ring + k) * 64) * 5;
-            double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-            if (k < rec->ring_len) {
-                const int m = min(rec->ring_n[k], 64);
-                if (lane < m) {
-                    const double *p = st.trk_ring + ((((size_t)s * cfg.t_cap + slot) * ring + rec->ring_slot[k]) * cfg.ring_rows + lane) * 8;
-                    v0 = p[0] - cx;                                     // relative_coordinates Utils.py:455-463
-                    v1 = p[1] - cy;
-                    v2 = p[2] - 0;
-                    v3 = p[6] - 0;
-                    v4 = ((p[7] - 0) - cfg.intensity_mu) / cfg.intensity_std;  // Utils.py:502
-                }
-            }
-            sort_rows_store(lane, v0, v1, v2, v3, v4, dst);
-        }
-        row++;
+        rlen = rec->ring_len;
+        rn0 = rec->ring_n[0]; rn1 = rec->ring_n[1]; rn2 = rec->ring_n[2]; rn3 = rec->ring_n[3];
+        rs0 = rec->ring_slot[0]; rs1 = rec->ring_slot[1]; rs2 = rec->ring_slot[2]; rs3 = rec->ring_slot[3];
+        cx = rec->centroid[0]; cy = rec->centroid[1];
+        uidv = rec->uid;
+        const int total = (rlen > 0 ? rn0 : 0) + (rlen > 1 ? rn1 : 0) + (rlen > 2 ? rn2 : 0) + (rlen > 3 ? rn3 : 0);
+        elig = total > cfg.model_min_input;   // Tracking.py:721
     }
-    if (tid == 0 && st.stats && rows_done) {  // algorithmic bytes: ring rows read (<= 64 per frame, 64 B each), fp32 tensor written
-        unsigned long long *sl = stats_slot(st, s);
-        atomicAdd(&sl[kStatFeatBytes], rd_bytes + rows_done * (unsigned long long)(ring * 64 * 5 * 4));
-        atomicAdd(&sl[kStatFeatRows], rows_done);
+    // rows in track-list order; a track whose row does not fit the caller's buffer is dropped, and so is every later one
+    const int my_row = row0 + __popcll(__ballot(elig) & lanemask_lt());
+    const bool use = elig && my_row < cap_rows;
+    const unsigned long long um = __ballot(use);
+    if (wave == 0 && use) {
+        owner[my_row * 2] = s;
+        owner[my_row * 2 + 1] = lane;
+        if (uid) uid[my_row] = uidv;
+    }
+    const int ne = __popcll(um);
+    for (int item = wave; item < ne * ring; item += 4) {   // (uniform per wave)
+        const int i = item / ring, k = item - i * ring;
+        unsigned long long m = um;
+        for (int t = 0; t < i; t++) m &= m - 1ULL;
+        const int j = __ffsll((long long)m) - 1;   // the i-th eligible track's list position
+        const int sl = __shfl(slot, j), rl = __shfl(rlen, j), row = __shfl(my_row, j);
+        const int n_k = __shfl(k == 0 ? rn0 : k == 1 ? rn1 : k == 2 ? rn2 : rn3, j), slot_k = __shfl(k == 0 ? rs0 : k == 1 ? rs1 : k == 2 ? rs2 : rs3, j);
+        const double ccx = __shfl(cx, j), ccy = __shfl(cy, j);
+        float *dst = feat + (((size_t)row * ring + k) * 64) * 5;
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+        if (k < rl && lane < min(n_k, 64)) {
+            const double *p = st.trk_ring + ((((size_t)s * cfg.t_cap + sl) * ring + slot_k) * cfg.ring_rows + lane) * 8;
+            const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 6);
+            v0 = a.x - ccx;                                     // relative_coordinates Utils.py:455-463
+            v1 = a.y - ccy;
+            v2 = p[2] - 0;
+            v3 = b.x - 0;
+            v4 = ((b.y - 0) - cfg.intensity_mu) / cfg.intensity_std;  // Utils.py:502
+        }
+        sort_rows_store(lane, v0, v1, v2, v3, v4, dst);
+    }
+    if (st.stats && wave == 0) {  // algorithmic bytes: ring rows read (<= 64 per frame, 64 B each), fp32 tensor written
+        int rows_b = 0;
+        if (use) rows_b = (rlen > 0 ? min(rn0, 64) : 0) + (rlen > 1 ? min(rn1, 64) : 0) + (rlen > 2 ? min(rn2, 64) : 0) + (rlen > 3 ? min(rn3, 64) : 0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rows_b += __shfl_xor(rows_b, o);
+        if (lane == 0 && ne) {
+            unsigned long long *sl = stats_slot(st, s);
+            atomicAdd(&sl[kStatFeatBytes], 64ULL * (unsigned long long)rows_b + (unsigned long long)ne * (unsigned long long)(ring * 64 * 5 * 4));
+            atomicAdd(&sl[kStatFeatRows], (unsigned long long)ne);
+        }
     }
 }
 
