@@ -125,10 +125,9 @@ __device__ inline void sort_rows_store(int lane, double v0, double v1, double v2
         }
     }
     const double s0 = __shfl(v0, src), s1 = __shfl(v1, src), s2 = __shfl(v2, src), s3 = __shfl(v3, src), s4 = __shfl(v4, src);
-    dst[lane * 5 + 0] = (float)s0;
-    dst[lane * 5 + 1] = (float)s1;
-    dst[lane * 5 + 2] = (float)s2;
-    dst[lane * 5 + 3] = (float)s3;
+    // a lane's five values are 20 consecutive bytes: one 16-byte and one 4-byte store (4-byte aligned: global memory takes that)
+    struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
+    *reinterpret_cast<F4 *>(dst + lane * 5) = F4{(float)s0, (float)s1, (float)s2, (float)s3};
     dst[lane * 5 + 4] = (float)s4;
 }
 
