@@ -177,6 +177,55 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     return off;
 }
 
+// The carve-up of a cloud the LDS cannot hold (k_dbscan_huge): the arrays every phase hammers -- the three coordinate columns,
+// the exchange slots of the level sort, the per-node min / max words of the build -- in the LDS (152 KB at 4096 points), all the
+// others in a slab of global memory.  Returns the slab's bytes, *hot_bytes = the LDS bytes.  (generic build only: all8 = false)
+template <bool WRITE>
+__host__ __device__ __forceinline__ size_t db_hybrid_layout(int UM, int CL, char *hot, char *cold, DbLds *L, int MW, size_t *hot_bytes)
+{
+    const int NB = (UM + 63) / 64;
+    const int levels = db_levels(UM), nodes = (1 << levels) - 1, half = (1 << (levels - 1)) / 2 > 0 ? (1 << (levels - 1)) / 2 : 1;
+    size_t oh = 0, oc = 0;
+#define HOT(field, type, count)                            \
+    if constexpr (WRITE) L->field = (type *)(hot + oh);    \
+    oh = db_align16(oh + sizeof(type) * (size_t)(count));
+#define COLD(field, type, count)                           \
+    if constexpr (WRITE) L->field = (type *)(cold + oc);   \
+    oc = db_align16(oc + sizeof(type) * (size_t)(count));
+    HOT(X, double, UM)
+    HOT(Y, double, UM)
+    HOT(Z, double, UM)
+    HOT(key, double, db_pow2ceil(UM))
+    HOT(front, int, db_pow2ceil(UM))
+    HOT(mm, unsigned long long, half * 16)
+    HOT(sdim, int, half)
+    HOT(lbase, int, half)
+    HOT(misc, int, 16)
+    COLD(idx, int, UM)
+    COLD(idx2, int, UM)
+    COLD(lab, int, UM)
+    COLD(next, int, UM)
+    COLD(core, unsigned char, UM)
+    COLD(leafpos, unsigned char, UM)
+    COLD(nstart, int, nodes + 1)
+    COLD(nend, int, nodes + 1)
+    COLD(nsum, double, nodes * 3)
+    COLD(ncen, double, nodes * 3)
+    COLD(nrad, unsigned long long, nodes + 1)
+    COLD(blk, int, (NB + 1) > 64 ? (NB + 1) : 64)
+    COLD(cnt, int, NB *(CL + 1))
+    COLD(cl_n, int, CL + 2)
+    COLD(cl_off, int, CL + 2)
+    COLD(ccen, double, (CL + 1) * 6)
+    COLD(fst, double, kFrontChunk * db_front_stride(MW))
+    COLD(adj, unsigned long long, db_adj_words(UM))
+    COLD(mask, unsigned long long, (size_t)UM * (MW > 1 ? MW : 1))
+#undef HOT
+#undef COLD
+    if (hot_bytes) *hot_bytes = oh;
+    return oc;
+}
+
 __device__ __forceinline__ int node_of(const DbLds &L, int p, int level)
 {
     int node = 0;
@@ -732,6 +781,14 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     // the three arrays that are dead between the build and the labelling -- the spare one of idx / idx2, next, lab (the
     // labelling's -1 are written again behind the queries) -- and the extents the screen's error bound needs
     float *XF = reinterpret_cast<float *>(idx2), *YF = reinterpret_cast<float *>(L.next), *ZF = reinterpret_cast<float *>(L.lab);
+    if constexpr (MW > 1) {
+        // (the clouds of more than 1920 points, db_hybrid_layout: those three are in global memory there, while the exchange slots of
+        //  the level sort -- key[] and front[], in the LDS, dead after the build; the masks have their own array -- hold exactly
+        //  three fp32 columns)
+        XF = reinterpret_cast<float *>(L.key);
+        YF = XF + UMc;
+        ZF = reinterpret_cast<float *>(L.front);
+    }
     if (tid == 0) { L.mm[0] = ~0ULL; L.mm[1] = 0ULL; L.mm[2] = 0ULL; }
     __syncthreads();
     double ext_lo = 1.7976931348623157e308, ext_hi = -1.7976931348623157e308, ext_m = 0.0;
@@ -1811,8 +1868,9 @@ constexpr int kHugeWorkers = 64;
 __global__ __launch_bounds__(kHugeThreads) void k_dbscan_huge(DevCfg cfg, DevState st, int UMc, int CL, int UM_out, int parity,
                                                               int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     DbLds L;
-    db_lds_layout<true>(UMc, CL, false, st.huge_scratch + (size_t)blockIdx.x * st.huge_stride, &L, kHugeMW);
+    db_hybrid_layout<true>(UMc, CL, lds_raw, st.huge_scratch + (size_t)blockIdx.x * st.huge_stride, &L, kHugeMW, nullptr);
     const int count = st.db_count[parity * 4 + 2];
     for (int w = blockIdx.x; w < count; w += gridDim.x) {
         const int s = st.db_list[(size_t)2 * cfg.n_scenes + w];
@@ -1827,8 +1885,9 @@ __global__ __launch_bounds__(kHugeThreads) void k_dbscan_only_huge(DevCfg cfg, D
                                                                    const int32_t *__restrict__ n_all, int max_n, double eps, int min_samples,
                                                                    int32_t *__restrict__ labels_out, int32_t *__restrict__ ncl_out)
 {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     DbLds L;
-    db_lds_layout<true>(UM, 0, false, st.huge_scratch + (size_t)blockIdx.x * st.huge_stride, &L, kHugeMW);
+    db_hybrid_layout<true>(UM, 0, lds_raw, st.huge_scratch + (size_t)blockIdx.x * st.huge_stride, &L, kHugeMW, nullptr);
     const int tid = threadIdx.x;
     for (int s = blockIdx.x; s < n_clouds; s += gridDim.x) {
         const int U = n_all[s];
@@ -1847,6 +1906,7 @@ __global__ __launch_bounds__(kHugeThreads) void k_dbscan_only_huge(DevCfg cfg, D
 
 // ---- host side ---------------------------------------------------------------------------
 static const int kClassUM[3] = {256, 768, 1920};
+static size_t dbscan_huge_lds_bytes(int UM, int cl);
 
 int dbscan_class_um(int cls, int UM) { return kClassUM[cls] < UM ? kClassUM[cls] : UM; }
 int dbscan_class_cl(int cls, int UM, int t_cap, int min_samples)
@@ -1914,6 +1974,13 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_dbscan_startup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
+    if (UM > kClassUM[2]) {   // the clouds of more than 1920 points: hot arrays in the LDS, the rest on slabs in global memory
+        const size_t hot = dbscan_huge_lds_bytes(UM, big_cl(UM, t_cap, min_samples));
+        e = hipFuncSetAttribute((const void *)k_dbscan_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void *)k_dbscan_only_huge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot);
+        if (e != hipSuccess) return e;
+    }
     return hipFuncSetAttribute((const void *)k_dbscan_only, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbscan_only_lds_bytes(UM));
 }
 
@@ -2004,8 +2071,8 @@ void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const dou
 {
     if (max_n > kClassUM[2]) {  // clouds the LDS cannot hold: slabs in global memory
         const int g = cfg.n_scenes < kHugeWorkers ? cfg.n_scenes : kHugeWorkers;
-        hipLaunchKernelGGL(k_dbscan_only_huge, dim3(g), dim3(kHugeThreads), 0, stream, cfg, st, UM, cfg.n_scenes, pts, n, max_n, eps, min_samples,
-                           labels, ncl);
+        hipLaunchKernelGGL(k_dbscan_only_huge, dim3(g), dim3(kHugeThreads), dbscan_huge_lds_bytes(UM, 0), stream, cfg, st, UM, cfg.n_scenes, pts, n, max_n,
+                           eps, min_samples, labels, ncl);
         return;
     }
     const int umk = UM < kClassUM[2] ? UM : kClassUM[2];  // (a context whose rings hold more: the LDS classes stop at 1920)
@@ -2018,14 +2085,21 @@ int dbscan_huge_workers(int n_scenes) { return n_scenes < kHugeWorkers ? n_scene
 size_t dbscan_huge_slab_bytes(int UM, int t_cap, int min_samples)
 {
     if (UM <= kClassUM[2]) return 0;
-    const size_t a = db_lds_layout<false>(UM, big_cl(UM, t_cap, min_samples), false, nullptr, nullptr, kHugeMW);
+    const size_t a = db_hybrid_layout<false>(UM, big_cl(UM, t_cap, min_samples), nullptr, nullptr, nullptr, kHugeMW, nullptr);
     return (a + 255) & ~(size_t)255;
+}
+static size_t dbscan_huge_lds_bytes(int UM, int cl)
+{
+    size_t hot = 0;
+    db_hybrid_layout<false>(UM, cl, nullptr, nullptr, nullptr, kHugeMW, &hot);
+    return hot;
 }
 void launch_dbscan_huge(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream)
 {
     if (UM <= kClassUM[2] || u_bound <= kClassUM[2]) return;  // no ring of this context can hold such a cloud (yet)
-    mmw_launch(k_dbscan_huge, dim3(dbscan_huge_workers(cfg.n_scenes)), dim3(kHugeThreads), 0, stream, cfg, st, UM, big_cl(UM, cfg.t_cap, cfg.db_min_samples), UM,
-               parity, labels, db_n);
+    const int cl = big_cl(UM, cfg.t_cap, cfg.db_min_samples);
+    mmw_launch(k_dbscan_huge, dim3(dbscan_huge_workers(cfg.n_scenes)), dim3(kHugeThreads), dbscan_huge_lds_bytes(UM, cl), stream, cfg, st, UM, cl, UM, parity,
+               labels, db_n);
 }
 
 }  // namespace mmw
