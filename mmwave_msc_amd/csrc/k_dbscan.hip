@@ -626,6 +626,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             L.sdim[tid] = jmax;
         }
         __syncthreads();
+        DSTAMP(6);  // (diagnostic) min/max + split dim
         // partition_node_indices: the n_mid smallest under (value, index) go left
         // (_partition_nodes.pyx:35-39); both halves keep ascending point-index order.
         // Rank inside the node = slot after sorting the whole level by (node, value, point index), minus the
@@ -686,6 +687,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
             __syncthreads();
             }
         }
+        DSTAMP(8);  // (diagnostic) keys + rank
         const int NBLK = (U + 63) / 64;
         for (int p0 = 0; p0 < U; p0 += NT) {
             const int p = p0 + tid;
@@ -723,6 +725,7 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
         }
         { int *t = idx; idx = idx2; idx2 = t; }
         __syncthreads();
+        DSTAMP(9);  // (diagnostic) partition
     }
 
     DSTAMP(1);
