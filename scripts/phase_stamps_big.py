@@ -19,11 +19,12 @@ for s in range(S):   # a faint target: 14 points a frame -> a cluster only in th
         pts[f, s, idx, 2] = rng.uniform(0.6, 1.4, size=14)
 cnt = np.full((F, S), N, np.int32); dts = np.full((F, S), 0.1)
 sb = SceneBatch(_lib.default_config(tr_max_tracks=4, chain_side_stream=-1), S, N)
+WHICH = int(os.environ.get("FRAME", "2"))   # 1: 256 trees of 1024 points, a cluster each; 2: ~55 trees of 1536 points, none
 for f in range(F):
-    if f == 2:
+    if f == WHICH:
         sb.synchronize(); sb.stats_reset()
     sb.step_host(pts[f], cnt[f], dts[f])
-    if f == 2:
+    if f == WHICH:
         break
 sb.synchronize()
 out = np.zeros(32, dtype=np.uint64)
