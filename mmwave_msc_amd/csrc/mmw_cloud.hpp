@@ -18,14 +18,46 @@ __device__ inline double unsortable(unsigned long long k)
     return __longlong_as_double((long long)u);
 }
 
+// lane ^ J of a 64-bit value: DPP inside quads (J = 1, 2) and inside rows of 16 (J = 4, 8: the two row shifts, picked by the
+// lane's bit J), ds_bpermute for 16 and 32 -- four of the six butterfly steps of a wave reduction without the LDS crossbar
+// (a strided BallTree level reduces sixteen columns per 64 points: with six ds_bpermute steps each that pass was a third of
+// a large cloud's build)
+template <int J>
+__device__ __forceinline__ double xor_lane_d(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    int lo = (int)(unsigned)u, hi = (int)(unsigned)(u >> 32);
+    if constexpr (J == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); }
+    else if constexpr (J == 2) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); }
+    else if constexpr (J == 4 || J == 8) {
+        const bool up = (__lane_id() & J) != 0;
+        const int lu = __builtin_amdgcn_update_dpp(0, lo, 0x100 + J, 0xF, 0xF, true), ld = __builtin_amdgcn_update_dpp(0, lo, 0x110 + J, 0xF, 0xF, true);
+        const int hu = __builtin_amdgcn_update_dpp(0, hi, 0x100 + J, 0xF, 0xF, true), hd = __builtin_amdgcn_update_dpp(0, hi, 0x110 + J, 0xF, 0xF, true);
+        lo = up ? ld : lu;
+        hi = up ? hd : hu;
+    } else { lo = __shfl_xor(lo, J); hi = __shfl_xor(hi, J); }
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
 __device__ inline double wave_min_d(double v)
 {
-    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t < v ? t : v; }
+    double t;
+    t = xor_lane_d<1>(v); v = t < v ? t : v;
+    t = xor_lane_d<2>(v); v = t < v ? t : v;
+    t = xor_lane_d<4>(v); v = t < v ? t : v;
+    t = xor_lane_d<8>(v); v = t < v ? t : v;
+    t = xor_lane_d<16>(v); v = t < v ? t : v;
+    t = xor_lane_d<32>(v); v = t < v ? t : v;
     return v;
 }
 __device__ inline double wave_max_d(double v)
 {
-    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o); v = t > v ? t : v; }
+    double t;
+    t = xor_lane_d<1>(v); v = t > v ? t : v;
+    t = xor_lane_d<2>(v); v = t > v ? t : v;
+    t = xor_lane_d<4>(v); v = t > v ? t : v;
+    t = xor_lane_d<8>(v); v = t > v ? t : v;
+    t = xor_lane_d<16>(v); v = t > v ? t : v;
+    t = xor_lane_d<32>(v); v = t > v ? t : v;
     return v;
 }
 
