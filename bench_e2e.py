@@ -59,6 +59,7 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a):
         torch.cuda.synchronize()
         barrier()
         el = max_over_ranks(time.perf_counter() - t0)
+        pipe.close()   # (outside the clock: hands the tracker's side-stream workers back for the next mode's constructor to see)
         sb.profile(False)
         sb.check()
         K = F - W
@@ -207,6 +208,7 @@ def e2e_parity_leg(ref, device):
             err = np.abs(got["keypoints"].astype(np.float64) - wk) / np.maximum(1.0, np.abs(wk))
             max_err = max(max_err, float(err.max()))
             n_kp += len(want)
+    pipe.close()
     sb.close()
     return {"config": f"{S} scenes x {N} pts x TR_MAX_TRACKS={T}, {F} frames, track+features+CNN+keypoints every frame; BASELINE.json {p.get('label', 'configs[3]')}",
             "tracker_state_bit_equal_vs_oracle": bool(ints_ok), "tracks_checked": int(n_kp),

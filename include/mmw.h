@@ -357,6 +357,11 @@ int mmw_streams_concurrent(mmw_ctx *ctx, void *stream_a, void *stream_b);
  * once, mmw_config.fused_step), 2 = two launches (k_track with _predict_all at its head, k_post), 4 = the bulk kernels
  * (k_predict, k_track, k_post, k_dbscan_big).  The results do not depend on it. */
 int mmw_step_kind(mmw_ctx *ctx);
+/* How the batched Kalman kernels of the bulk step (k_predict, the update half of k_post) are laid out -- mmw_config.
+ * kalman_dense_min_units: 1 = over the TRACKS of the context (four per wave, from the update lists k_track builds), 0 = per
+ * scene (also: always with seek_inner, with track_cap > 63 and in the one-workgroup step).  The results do not depend on
+ * it; the parity tests assert that the layout they asked for is the one that ran. */
+int mmw_kalman_layout(mmw_ctx *ctx);
 /* Diagnostic: the queue of scenes whose small-cloud DBSCAN k_track could not rule out (k_dbscan.hip), per step parity p:
  * [8p] pushed, [8p+1] claimed, [8p+2] finished this step; [3] last step whose k_post has begun, [4] waits given up (also
  * reported by mmw_check); [16 + 8p ...] the same three words for the queue of the clouds of more than 256 points.
@@ -371,6 +376,8 @@ int mmw_profile_enable(mmw_ctx *ctx, int32_t on);
 int mmw_profile_reset(mmw_ctx *ctx);
 int mmw_profile_get(mmw_ctx *ctx, int32_t kernel_id, double *total_ms, int64_t *launches);   /* sync */
 const char *mmw_kernel_name(int32_t kernel_id);
+/* "mmw-hip <version> (gfx950) src:<hash>": <hash> = first 16 hex digits of the SHA-256 over csrc/ and
+ * this header at build time (csrc/Makefile); the Python loader refuses a library built from other sources. */
 const char *mmw_version(void);
 
 #ifdef __cplusplus

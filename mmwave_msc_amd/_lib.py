@@ -33,6 +33,7 @@ EXPORTS = [
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
+    "mmw_kalman_layout",
 ]
 
 
@@ -83,13 +84,37 @@ class MmwError(RuntimeError):
         self.code = code
 
 
+def source_hash() -> str:
+    """First 16 hex digits of the SHA-256 over csrc/*.hip, csrc/*.hpp (byte order of their names) and include/mmw.h:
+    what csrc/Makefile compiles into mmw_version().  The sources travel with the package, so a library built from other
+    sources -- a stale .so with a newer mtime, one copied in from another checkout -- is recognisable."""
+    import hashlib
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    h = hashlib.sha256()
+    for p in [os.path.join(CSRC, f) for f in names] + [os.path.join(os.path.dirname(_HERE), "include", "mmw.h")]:
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(path: str = None):
+    """The src:<hash> a built library carries, read from the file (no dlopen); None if absent or unhashed."""
+    import re
+    path = path or LIB_PATH
+    if not os.path.isfile(path):
+        return None
+    with open(path, "rb") as fh:
+        m = re.search(rb"\(gfx950\) src:([0-9a-f]{16})", fh.read())
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False) -> str:
-    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mmw.h"))
-    newest = max(os.path.getmtime(p) for p in srcs)
-    if force or not os.path.isfile(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950) unless the one present was built from exactly
+    these sources (mmw_version()'s hash, not file times)."""
+    if force or built_hash() != source_hash():
         subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+        if built_hash() != source_hash():
+            raise RuntimeError(f"{LIB_PATH}: built, but its source hash {built_hash()} is not {source_hash()}")
     return LIB_PATH
 
 
@@ -126,6 +151,12 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950).  mmwave_msc_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    L.mmw_version.restype = C.c_char_p
+    ver = (L.mmw_version() or b"").decode()
+    if os.path.isdir(CSRC) and not ver.endswith("src:" + source_hash()):
+        raise ImportError(
+            f"{LIB_PATH} reports {ver!r} but the sources beside it hash to {source_hash()}: it was built from other "
+            "sources.  Rebuild it: `python -c 'import __graft_entry__ as g; g.build()'`.")
     vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
     i32, i32p, i64p = C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     f64p = C.POINTER(C.c_double)
@@ -173,6 +204,7 @@ def load():
         "mmw_diag_queue": (C.c_int, [vp, vp]),
         "mmw_side_workers": (C.c_int, [vp]),
         "mmw_step_kind": (C.c_int, [vp]),
+        "mmw_kalman_layout": (C.c_int, [vp]),
         "mmw_streams_concurrent": (C.c_int, [vp, vp, vp]),
         "mmw_reset_scenes": (C.c_int, [vp, vp]),
         "mmw_get_errors": (C.c_int, [vp, vp]),

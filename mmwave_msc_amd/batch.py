@@ -135,6 +135,10 @@ class SceneBatch:
         """mmw_step_kind: 1 = the one-workgroup step (k_scene), 2 = two launches, 4 = the bulk kernels."""
         return int(self.L.mmw_step_kind(self.h))
 
+    def kalman_layout(self) -> int:
+        """mmw_kalman_layout: 1 = the batched Kalman kernels are laid out over the tracks of the context, 0 = per scene."""
+        return int(self.L.mmw_kalman_layout(self.h))
+
     def synchronize(self):
         self._chk(self.L.mmw_synchronize(self.h))
 

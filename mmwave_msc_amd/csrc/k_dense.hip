@@ -31,6 +31,7 @@
 // instead of one made the keypoints less accurate than the fp32 path's on the stress inputs: measured, not kept.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace mmw {
 
@@ -306,16 +307,23 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
 int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
                        hipStream_t stream)
 {
-    static bool prepared = false;
-    static int n_cu = 256;
-    if (!prepared) {
-        if (hipFuncSetAttribute((const void *)k_mars_dense1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256)) != hipSuccess) return -1;
-        if (hipFuncSetAttribute((const void *)k_mars_dense1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(128)) != hipSuccess) return -1;
-        int dev = 0;
+    // per DEVICE (a process may drive several GPUs, each from its own thread): the dynamic-LDS attribute of the three kernels
+    // and the CU count behind the tile split, taken once on whichever thread gets there first
+    struct DevPrep { std::once_flag once; int n_cu = 256; bool ok = false; };
+    static DevPrep g_prep[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    DevPrep &P = g_prep[dev];
+    std::call_once(P.once, [&]() {
+        if (hipFuncSetAttribute((const void *)k_mars_dense1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256)) != hipSuccess) return;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(128)) != hipSuccess) return;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1_w192, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-        prepared = true;
-    }
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) P.n_cu = prop.multiProcessorCount;
+        P.ok = true;
+    });
+    if (!P.ok) return -1;
+    const int n_cu = P.n_cu;
     const int bands = rows_padded / BM, tiles_n = N / BN;
     const long long total = (long long)bands * tiles_n;
     int bands_main = bands;
@@ -327,11 +335,6 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
     }
     const _Float16 *A = reinterpret_cast<const _Float16 *>(a2), *W = reinterpret_cast<const _Float16 *>(w2);
     if (N % dense192::BN2 == 0) {   // 256 x 192 tiles for the whole waves of workgroups, the rest as below
-        static bool prep2 = false;
-        if (!prep2) {
-            if (hipFuncSetAttribute((const void *)k_mars_dense1_w192, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return -1;
-            prep2 = true;
-        }
         const int tn2 = N / dense192::BN2;
         const long long total2 = (long long)bands * tn2, rem2 = total2 % n_cu;
         int bm2 = bands;

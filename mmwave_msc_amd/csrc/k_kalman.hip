@@ -91,7 +91,9 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
                 int s, j;
                 bool live = dense_pick(cfg, st, prev, B, unit, lane, g, s, j);
                 const int n = n_pts[s];
-                live = live && frame_reaches_track(n, cfg.max_pts);
+                // (j < n_tracks: a scene that mmw_reset_scenes has emptied since the lists were built holds no track -- its
+                //  stale records must not be predicted, nor their error bits come back on the fresh scene)
+                live = live && frame_reaches_track(n, cfg.max_pts) && j < st.hdr[s].n_tracks;
                 if (!__any(live)) continue;
                 TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? st.order[(size_t)s * cfg.t_cap + j] : 0);
                 int e1 = 0;

@@ -178,9 +178,21 @@ static void prof_end(mmw_ctx *c, EventPair &ep)
 
 static int read_headers(mmw_ctx *c, std::vector<SceneHdr> &h);
 
+// Which step a context runs is decided in ONE place: the one-workgroup step (k_scene) when it was chosen at creation and
+// neither the side-stream workers are asked for (they claim scenes while the association kernel runs) nor a global ring has
+// been resized (k_track's INNER instantiations read the sizes per ring).  What was ASKED for counts, not what the stream
+// probe left of it: a context whose probe turned the workers off keeps the bulk kernels, as mmw_create's `can` has it.
+static void refresh_step_kind(mmw_ctx *c) { c->dc.fused = (c->fused_wanted && !c->side_wanted && !c->dc.var_ring) ? 1 : 0; }
+
 extern "C" {
 
-const char *mmw_version(void) { return "mmw-hip 0.1 (gfx950)"; }
+// MMW_SRC_HASH: the first 16 hex digits of the SHA-256 of csrc/*.hip, csrc/*.hpp and include/mmw.h (csrc/Makefile passes it
+// when this file is compiled, and this object depends on all of them): mmwave_msc_amd/_lib.py refuses a library whose
+// hash is not that of the sources beside it.
+#ifndef MMW_SRC_HASH
+#define MMW_SRC_HASH "unhashed"
+#endif
+const char *mmw_version(void) { return "mmw-hip 0.4 (gfx950) src:" MMW_SRC_HASH; }
 
 const char *mmw_kernel_name(int32_t k)
 {
@@ -454,7 +466,7 @@ int mmw_reset(mmw_ctx *c)
     launch_reset(c->dc, c->st, nullptr, c->stream);
     HIPCHK(c, hipGetLastError());
     c->dc.var_ring = 0;   // fresh BatchedData objects: default sizes again
-    c->dc.fused = (c->fused_wanted && !c->dc.side_worker) ? 1 : 0;
+    refresh_step_kind(c);
     c->ring_frames_bound = 0;
     return MMW_OK;
 }
@@ -512,8 +524,8 @@ int mmw_set_batch_size(mmw_ctx *c, const int32_t *scene_flags, int32_t new_size)
     launch_set_batch_size(c->dc, c->st, d_flags, new_size, c->stream);
     HIPCHK(c, hipGetLastError());
     if (scene_flags) HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->dc.var_ring = 1;
-    c->dc.fused = 0;   // resized rings are k_track's (its INNER instantiations read the sizes per ring); the state layout is the same
+    c->dc.var_ring = 1;   // resized rings are k_track's (its INNER instantiations read the sizes per ring); the state layout is the same
+    refresh_step_kind(c);
     return MMW_OK;
 }
 
@@ -542,7 +554,7 @@ int mmw_set_chain_side_stream(mmw_ctx *c, int32_t on)
     if (on && c->dc.seek_inner) return fail(c, MMW_E_ARG, "mmw_set_chain_side_stream: not with seek_inner (k_inner may cancel queued scenes)");
     if (on && !c->side_stream) HIPCHK(c, create_side_streams(c));
     c->dc.side_worker = c->side_wanted = on ? 1 : 0;   // takes effect with the next mmw_step (the queues are empty between steps)
-    c->dc.fused = (c->fused_wanted && !on && !c->dc.var_ring) ? 1 : 0;   // the workers claim scenes while k_track runs: the bulk kernels' step
+    refresh_step_kind(c);   // the workers claim scenes while k_track runs: the bulk kernels' step
     c->side_probed = c->side_trusted;
     return MMW_OK;
 }
@@ -555,6 +567,7 @@ int mmw_set_stream(mmw_ctx *c, void *s)
     c->stream = s ? (hipStream_t)s : c->own_stream;
     c->dc.side_worker = c->side_wanted;   // (checked against the new stream by the next mmw_step)
     c->side_probed = c->side_trusted;
+    refresh_step_kind(c);
     return MMW_OK;
 }
 
@@ -1058,6 +1071,13 @@ int mmw_step_kind(mmw_ctx *c)
 {
     if (!c) return MMW_E_ARG;
     return c->dc.fused ? 1 : (pred_in_track(c->dc) ? 2 : 4);
+}
+int mmw_kalman_layout(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    int nq = (c->dc.tr_max_tracks + 3) / 4;
+    if (nq < 1) nq = 1;
+    return (!c->dc.fused && tracks_dense(c->dc, nq)) ? 1 : 0;
 }
 int mmw_diag_queue(mmw_ctx *c, int32_t *out /*[32]*/)
 {

@@ -86,8 +86,8 @@ class MarsCNN(nn.Module):
                 or activation outside it raises the conv kernel's range word (range_overflow(): that sample's outputs are
                 meaningless then), and predict() -- synchronous anyway -- computes such a batch again in fp32."""
         super().__init__()
-        if arith not in ("f32", "f16x3"):
-            raise ValueError(arith)
+        if arith not in ("f32", "f16x3", "torch"):
+            raise ValueError(arith)   # ("torch": torch's own convolutions and GEMMs on the GPU, only ever on request -- see forward())
         self.arith = arith
         self.arith_fallback = None   # why a model asked for as "f16x3" runs "f32" (from_keras_weights: weights beyond fp16's range)
         self.range_fallbacks = 0     # predict() calls recomputed in fp32 because an input / activation left fp16's range
@@ -150,8 +150,9 @@ class MarsCNN(nn.Module):
         # fp16's range is the split arithmetic's: a folded weight outside it would become inf in its hi half
         wmax = max(float(np.abs(f64[k]).max()) for k in ("conv1_w", "conv2_w", "conv1_b", "conv2_b"))
         if m.arith == "f16x3" and max(wmax, float(w32.abs().max())) >= FP16_SAFE_MAX:
-            m.arith = "f32"
-            m.arith_fallback = f"a weight of magnitude {max(wmax, float(w32.abs().max())):.3g} does not fit fp16: fp32 matrix cores instead"
+            m.arith = m.fp32_arith()
+            m.arith_fallback = (f"a weight of magnitude {max(wmax, float(w32.abs().max())):.3g} does not fit fp16: "
+                                + ("fp32 matrix cores instead" if m.arith == "f32" else "torch's fp32 kernels instead (the single-frame model has no fp32 HIP kernel)"))
         m.dense1.weight.copy_(torch.from_numpy(w1.T.copy()).float())
         m.dense1.bias.copy_(torch.from_numpy(b1).float())
         a2 = f64["bn2_gamma"] / np.sqrt(f64["bn2_var"] + BN_EPS)
@@ -241,11 +242,23 @@ class MarsCNN(nn.Module):
             self.range_flag.zero_()
         return hit
 
+    def fp32_arith(self) -> str:
+        """What replaces the split arithmetic where it cannot be used (weights / activations beyond fp16's range): the fp32
+        matrix-core kernel for the 3-frame model, torch's fp32 kernels for the single-frame one (no fp32 HIP kernel exists)."""
+        return "f32" if self.use_hip_conv_f32 else "torch"
+
     def forward(self, x: torch.Tensor, arith: str | None = None) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it.  `arith` overrides the model's for
-        this call."""
+        this call.  A CUDA tensor runs this package's HIP kernels or raises: torch's own convolutions take a GPU batch only
+        when arith = "torch" was asked for (CPU tensors always take the torch path -- training exports, CPU tests)."""
         arith = arith or self.arith
-        if self.use_hip_conv and x.is_cuda and x.dtype == torch.float32 and (arith == "f16x3" or self.use_hip_conv_f32):
+        if x.is_cuda and arith != "torch":
+            if x.dtype != torch.float32:
+                raise TypeError(f"MarsCNN: the HIP kernels take fp32 feature tensors (what mmw_features writes), got {x.dtype}; "
+                                "convert the batch, or ask for torch's kernels with arith='torch'")
+            if arith == "f32" and not self.use_hip_conv_f32:
+                raise ValueError("MarsCNN: the single-frame model has no fp32 HIP kernel; arith='f16x3' (default) runs k_mars_conv16, "
+                                 "arith='torch' torch's convolutions")
             with torch.cuda.device(x.device):
                 if arith == "f16x3":
                     h = self._dense1_split(self._hip_convs_split(x))
@@ -270,7 +283,7 @@ class MarsCNN(nn.Module):
         out = self(x).float().cpu().numpy()
         if self.arith == "f16x3" and x.is_cuda and self.range_overflow():
             self.range_fallbacks += 1
-            out = self(x, arith="f32").float().cpu().numpy()
+            out = self(x, arith=self.fp32_arith()).float().cpu().numpy()
         return out
 
     def predict(self, feat, verbose=0):  # Keras-style entry used by estimate_posture (Tracking.py:732)

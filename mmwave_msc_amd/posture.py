@@ -54,8 +54,10 @@ class PosturePipeline:
             sb.follow_torch_stream(self.A)
         # with the CNN on its own stream beside the tracker, the tracker's own side-stream workers (k_chain) only take
         # compute units from the statically tiled matrix kernels: off in that schedule -- if the library had them on
-        # (mmw_side_workers; its choice, not re-derived here) --, and back on when the pipeline is drained
+        # (mmw_side_workers; its choice, not re-derived here) -- for the LIFE of the pipeline (drain() is also called in
+        # the middle of a run), and back on in close()
         self._side_was_on = sb.side_workers() != 0
+        self._closed = False
         if self._side_was_on and self.B is not self.A:
             sb.set_chain_side_stream(False)
         self.range_overflowed = False   # the split-fp16 CNN met an input / activation outside fp16's range (see drain())
@@ -143,12 +145,26 @@ class PosturePipeline:
         self.f = self.cnn_done = self.scattered = 0
         self.A.synchronize()
         self.B.synchronize()
-        if self._side_was_on and self.B is not self.A:
-            self.sb.set_chain_side_stream(True)
-            self._side_was_on = False
         # the asynchronous path cannot recompute a frame that is long scattered: it reports (mars.MarsCNN.range_overflow)
         if getattr(self.model, "arith", None) == "f16x3" and hasattr(self.model, "range_overflow") and self.model.range_overflow():
             import warnings
             self.range_overflowed = True
             warnings.warn("MarsCNN (split-fp16 arithmetic): an input or activation left fp16's range during this run; the keypoints of "
                           "the samples concerned are meaningless -- use MarsCNN(arith='f32') for such data", RuntimeWarning, stacklevel=2)
+
+    def close(self):
+        """drain(), then hand the tracker back as it was found: its side-stream workers on again if this pipeline turned
+        them off.  The pipeline must not be used afterwards."""
+        if self._closed:
+            return
+        self.drain()
+        self._closed = True
+        if self._side_was_on and self.B is not self.A and self.sb.h:
+            self.sb.set_chain_side_stream(True)
+
+    def __del__(self):
+        try:
+            if not self._closed and self.sb.h and self._side_was_on and self.B is not self.A:
+                self.sb.set_chain_side_stream(True)
+        except Exception:
+            pass

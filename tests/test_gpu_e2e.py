@@ -56,7 +56,7 @@ def _run_loop(sb, pts, cnt, dts, model, pipelined):
         for f in range(F):
             sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
             pipe.after_step()
-        pipe.drain()
+        pipe.close()
     else:  # the reference's order: estimate_posture completes before the next track()
         for f in range(F):
             sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())

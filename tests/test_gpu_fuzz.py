@@ -1,0 +1,105 @@
+"""Seeded random differential test of the HIP path against the C oracle (oracle/c; Tracking.py:664-703, Utils.py:250-291,
+437-520): 64 random configurations x 12 frames x the four kernel layouts (tests/_layouts.py).
+
+What a configuration draws (tests/_fuzz.py: draw_case): 1..8 scenes; points per frame anywhere in [1, 1024] (multiples of
+64 are the exception); ring length 1..4; DB_EPS, DB_MIN_SAMPLES_MIN, DB_Z_WEIGHT, DB_RANGE_WEIGHT; TR_GATE,
+TR_MAX_TRACKS, TR_VEL_THRES, the two lifetimes; CONST_ACC / CONST_VEL model; KF_ENABLE_EST and the estimator constants;
+0..12 targets per scene (some appear or vanish half-way); ragged point counts; a different dt every frame; frames that
+are skipped (n = 0, offline_main.py:56) and frames on which track() is called with an empty cloud (MMW_EMPTY_FRAME); one
+configuration in eight runs ClusterTrack.seek_inner_clusters (Tracking.py:409-448).
+
+Everything is compared bit for bit, every frame: association vectors, DBSCAN labels and call pattern, track count and
+order, every fp64 field of every track, ring lengths, the global ring, inner-cluster labels, and the feature tensors."""
+import numpy as np
+import pytest
+
+from tests._fuzz import N_CASES, draw_case, scene_inputs
+from tests._golden import assert_tracks_match
+from tests._layouts import LAYOUTS, make_checked
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_random_configuration_vs_oracle(seed, layout):
+    from mmwave_msc_amd import _lib
+    from oracle import c_oracle as co
+    case = draw_case(seed)
+    kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
+    pts, cnt, dts = scene_inputs(case)                       # [F,S,N,8] float32, [F,S] (0 = skipped, -1 = empty cloud), [F,S]
+    sb = make_checked(S, N, layout, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    seen = dict(assigned=0, dbscan=0, clusters=0, empty=0, skipped=0)
+    for f in range(F):
+        # the oracle first: a frame on which the reference raises (numpy's LinAlgError for a singular 6 x 6 matrix,
+        # ZeroDivisionError in _get_Rc, Tracking.py:299-312) must be a loud error of the same kind here, and ends the case
+        want, failed = [None] * S, {}
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c != 0:
+                try:
+                    want[s] = scenes[s].track(pts[f, s, : max(c, 0)].astype(np.float64), float(dts[f, s]))
+                except RuntimeError as e:
+                    failed[s] = int(str(e).rsplit("rc=", 1)[1])
+        if failed:
+            codes = {-2: _lib.E_SINGULAR, -3: _lib.E_DIVZERO}
+            with pytest.raises(_lib.MmwError) as ei:
+                sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+            assert ei.value.code in {codes[v] for v in failed.values()}, (seed, f, failed, str(ei.value))
+            err = sb.errors()
+            for s in range(S):
+                assert bool(err[s] & 3) == (s in failed), (seed, f, s, err[s], failed)
+            seen["raised"] = seen.get("raised", 0) + 1
+            break
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=max(int(ntr.max()), 1))
+        ln, rn = sb.batch_ring()
+        inner = sb.inner_calls() if kw.get("seek_inner") else None
+        feat, owner = sb.features_host() if f in (F // 2, F - 1) else (None, None)
+        row = 0
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c == 0:                                     # the frame never reaches track()
+                seen["skipped"] += 1
+                assert dbn[s] == -1, (seed, f, s)
+            else:
+                n = max(c, 0)
+                seen["empty"] += int(c < 0)
+                oa, ol = want[s]
+                assert np.array_equal(assoc[s, :n], oa), (seed, f, s)
+                seen["assigned"] += int((oa >= 0).sum())
+                assert (ol is None) == (dbn[s] < 0), (seed, f, s, dbn[s])
+                if ol is not None:
+                    seen["dbscan"] += 1
+                    seen["clusters"] += int(ol.max() + 1) if len(ol) else 0
+                    assert dbn[s] == len(ol) and np.array_equal(labels[s, : dbn[s]], ol), (seed, f, s)
+                if inner is not None:
+                    oc = scenes[s].inner_calls()
+                    assert len(inner[s]) == len(oc), (seed, f, s)
+                    for a, (_, b) in zip(inner[s], oc):
+                        assert np.array_equal(a, b), (seed, f, s)
+            assert ntr[s] == scenes[s].n_tracks, (seed, f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"seed {seed} f{f} s{s}", exact=True)
+            assert np.array_equal(rn[s, : ln[s]], scenes[s].batch_ring()), (seed, f, s)
+            if feat is not None:
+                of, oo = scenes[s].features()
+                k = len(oo)
+                assert np.all(owner[row: row + k, 0] == s) and np.array_equal(owner[row: row + k, 1], oo), (seed, f, s)
+                if k:
+                    assert np.array_equal(feat[row: row + k], of), (seed, f, s)
+                row += k
+        if feat is not None:
+            assert row == len(owner), (seed, f)
+    else:
+        sb.check()
+        # the per-track rings of one scene, oldest frame first
+        s = seed % S
+        recs = scenes[s].tracks()
+        for t in range(scenes[s].n_tracks):
+            for k in range(int(recs[t]["ring_len"])):
+                assert np.array_equal(sb.track_ring_frame(s, t, k), scenes[s].track_ring_frame(t, k)[: sb.ring_rows]), (seed, s, t, k)
+    sb.close()
+    case["seen"] = seen

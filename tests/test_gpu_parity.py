@@ -15,32 +15,26 @@ from tests._golden import (GOLDEN, assert_feat_equal, assert_tracks_match, load_
 pytestmark = pytest.mark.gpu
 
 
-_LAYOUT = {"value": 0, "side": 0, "fused": 0}
+from tests._layouts import LAYOUTS, make_checked
+
+_LAYOUT = {"name": "per_scene"}
 
 
-@pytest.fixture(params=["per_scene", "track_wise", "track_wise+side_stream", "one_workgroup"], autouse=True)
+@pytest.fixture(params=LAYOUTS, autouse=True)
 def kalman_layout(request):
-    """Every test of this file runs with both layouts of the Kalman kernels (mmw_kalman.hpp: tracks_dense: by default the
-    track-wise one is only chosen for contexts with more than 1024 four-track waves, mmw_config.kalman_dense_min_units), and
-    a third time with the small-cloud DBSCAN workers on the side stream (k_chain beside k_track, mmw_config.chain_side_stream:
-    by default only for contexts of >= 1536 scenes), and a fourth time with the one-workgroup step (k_scene.hip,
-    mmw_config.fused_step: by default only for contexts of 257..512 scenes)."""
-    _LAYOUT["value"] = {"per_scene": -1, "one_workgroup": 0}.get(request.param, 1)
-    _LAYOUT["side"] = 1 if request.param.endswith("side_stream") else (0 if request.param == "one_workgroup" else -1)
-    _LAYOUT["fused"] = 1 if request.param == "one_workgroup" else -1
+    """Every test of this file runs under the four kernel layouts (tests/_layouts.py): the bulk kernels with the Kalman
+    kernels per scene, the same laid out over tracks (by default only for contexts with more than 1024 four-track waves,
+    mmw_config.kalman_dense_min_units), a third time with the small-cloud DBSCAN workers on the side stream (k_chain beside
+    k_track, mmw_config.chain_side_stream: by default only for contexts of >= 1536 scenes), and a fourth time with the
+    one-workgroup step (k_scene.hip, mmw_config.fused_step: by default only for contexts of 257..512 scenes).  A context
+    whose configuration forbids the layout is SKIPPED with the reason, never run as a duplicate of another layout."""
+    _LAYOUT["name"] = request.param
     yield
-    _LAYOUT["value"] = 0
-    _LAYOUT["side"] = 0
-    _LAYOUT["fused"] = 0
+    _LAYOUT["name"] = "per_scene"
 
 
 def _mk(n_scenes, max_pts, **kw):
-    from mmwave_msc_amd import _lib
-    from mmwave_msc_amd.batch import SceneBatch
-    kw.setdefault("kalman_dense_min_units", _LAYOUT["value"])
-    kw.setdefault("chain_side_stream", _LAYOUT["side"])
-    kw.setdefault("fused_step", _LAYOUT["fused"])
-    return SceneBatch(_lib.default_config(**kw), n_scenes, max_pts)
+    return make_checked(n_scenes, max_pts, _LAYOUT["name"], **kw)
 
 
 @pytest.mark.parametrize("name", scenario_names())
@@ -259,6 +253,53 @@ def test_many_tracks_vs_oracle():
             assert ntr[s] == scenes[s].n_tracks, (f, s)
             assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
             most = max(most, int(ntr[s]))
+    sb.check()
+    sb.close()
+    assert most > 16, most
+
+
+def test_more_than_16_tracks_below_the_one_workgroup_cap_vs_oracle():
+    """test_many_tracks_vs_oracle's scenes with track_cap = 40: below 64, so the one-workgroup step (k_scene.hip) and the
+    track-wise Kalman layout are available and every layout runs its OWN kernels -- k_scene's slow path for the tracks past
+    the kRes = 16 records it keeps in LDS (prediction, ring bookkeeping, statistics and update through global memory), the
+    dense update lists with more than 16 tracks per scene.  Every frame against the oracle (Tracking.py:664-703)."""
+    from oracle import c_oracle as co
+    S, N, F = 8, 640, 10
+    kw = dict(tr_max_tracks=28, db_min_samples=12, track_cap=40)
+    sb = _mk(S, N, **kw)
+    assert sb.track_cap == 40
+    if _LAYOUT["name"] == "one_workgroup":
+        assert sb.step_kind() == 1
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    pts = np.stack([_grid_scene(4400 + s, F, N, 17 + s) for s in range(S)], axis=1)  # [F][S][N][8]: 17 .. 24 targets
+    cnt = np.full((F, S), N, np.int32)
+    dts = np.full((F, S), 0.1)
+    most = 0
+    for f in range(F):
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=40)
+        feat, owner = sb.features_host()
+        row = 0
+        for s in range(S):
+            oa, ol = scenes[s].track(pts[f, s].astype(np.float64), dts[f, s])
+            assert np.array_equal(assoc[s], oa), (f, s)
+            assert (ol is None) == (dbn[s] < 0), (f, s)
+            if ol is not None:
+                assert np.array_equal(labels[s, : dbn[s]], ol), (f, s)
+            assert ntr[s] == scenes[s].n_tracks, (f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
+            of, oo = scenes[s].features()
+            k = len(oo)
+            assert np.all(owner[row: row + k, 0] == s) and np.array_equal(owner[row: row + k, 1], oo), (f, s)
+            if k:
+                assert np.array_equal(feat[row: row + k], of), (f, s)
+            row += k
+            most = max(most, int(ntr[s]))
+        assert row == len(owner)
+    if _LAYOUT["name"] == "one_workgroup":
+        assert sb.step_kind() == 1   # ... to the end
     sb.check()
     sb.close()
     assert most > 16, most

@@ -1,0 +1,85 @@
+"""Randomised differential test of the C oracle (oracle/c) against the LIVE reference (/root/reference/src imported in
+this container through oracle/ref_import.py; filterpy from oracle/filterpy_shim): what the golden fixtures pin on 21
+recorded scenarios, checked again on fresh seeds with random constant overrides -- the configurations of
+tests/_fuzz.py (the same generator drives the GPU fuzz test), smaller.
+
+`-m reference`: skipped where /root/reference is absent (the GPU box).  Integers -- association vectors, DBSCAN labels,
+track count and order, point counts, ring lengths, static flags, feature owners -- must be equal; fp64 state within
+tests/_golden.py's tolerance (BLAS / LAPACK summation order differs from the oracle's fixed order by a few ULP).
+
+DB_EPS and DB_MIN_SAMPLES_MIN are bound as default arguments of Utils.apply_DBscan when the reference is imported
+(Utils.py:250); a run with other values re-binds `apply_DBscan.__defaults__`, which is what editing constants.py does."""
+import numpy as np
+import pytest
+
+from tests._fuzz import draw_case, reference_overrides, scene_inputs
+from tests._golden import assert_feat_equal, assert_tracks_match
+
+pytestmark = pytest.mark.reference
+
+N_REF_CASES = 24
+
+
+@pytest.mark.parametrize("seed", range(N_REF_CASES))
+def test_live_reference_vs_c_oracle_on_fresh_seeds(seed):
+    from oracle import c_oracle as co
+    from oracle.ref_import import load_reference
+    from oracle.ref_runner import RefScene
+
+    # the reference is Python + a Python DBSCAN metric: small contexts (<= 2 scenes, <= 300 points, 10 frames)
+    case = draw_case(1000 + seed, max_pts=300, max_scenes=2, frames=10)
+    kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
+    pts, cnt, dts = scene_inputs(case)
+    const, utils, _ = load_reference()
+    over = reference_overrides(kw)
+    if "MOTION_MODEL" in over:
+        over["MOTION_MODEL"] = getattr(const, over["MOTION_MODEL"])
+    saved_defaults = utils.apply_DBscan.__defaults__
+    utils.apply_DBscan.__defaults__ = (kw["db_eps"], kw["db_min_samples"])
+    refs = []
+    try:
+        cfg = co.default_config(**kw)
+        n_int = n_db = 0
+        for s in range(S):
+            ref = RefScene(dict(over))
+            refs.append(ref)
+            orc = co.OracleScene(cfg, N)
+            for f in range(F):
+                c = int(cnt[f, s])
+                if c == 0:
+                    continue
+                rows = pts[f, s, : max(c, 0)].astype(np.float64)
+                try:
+                    ra, rl = ref.track(rows, float(dts[f, s]))
+                except (ZeroDivisionError, np.linalg.LinAlgError) as e:
+                    with pytest.raises(RuntimeError) as ei:     # the oracle's return code for the same exception
+                        orc.track(rows, float(dts[f, s]))
+                    assert ("rc=-3" if isinstance(e, ZeroDivisionError) else "rc=-2") in str(ei.value), (seed, s, f, e)
+                    break
+                oa, ol = orc.track(rows, float(dts[f, s]))
+                assert np.array_equal(oa, ra), (seed, s, f, "association")
+                assert (ol is None) == (rl is None), (seed, s, f, "apply_DBscan call pattern")
+                if ol is not None:
+                    n_db += 1
+                    assert np.array_equal(ol, rl), (seed, s, f, "DBSCAN labels")
+                if kw.get("seek_inner"):
+                    oc, rc = orc.inner_calls(), ref.inner
+                    assert len(oc) == len(rc), (seed, s, f, "seek_inner_clusters calls")
+                    for (tp, lab), (rtp, rlab) in zip(oc, rc):
+                        assert tp == rtp and np.array_equal(lab, rlab), (seed, s, f)
+                assert orc.n_tracks == ref.n_tracks, (seed, s, f)
+                assert_tracks_match(orc.tracks(), ref.tracks(), ctx=f"seed {seed} s{s} f{f}", tol=1e-7)
+                assert np.array_equal(orc.batch_ring(), ref.batch_ring()), (seed, s, f)
+                n_int += len(oa)
+                if f in (F // 2, F - 1):
+                    of, oo = orc.features()
+                    rf, ro = ref.features()
+                    assert np.array_equal(oo, ro), (seed, s, f, "feature owners")
+                    if len(oo):
+                        assert_feat_equal(of, rf.reshape(of.shape), ctx=f"seed {seed} s{s} f{f}")
+            ref.close()
+        assert n_int > 0
+    finally:
+        utils.apply_DBscan.__defaults__ = saved_defaults
+        for r in refs:
+            r.close()
