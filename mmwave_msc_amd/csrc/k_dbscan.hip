@@ -145,9 +145,11 @@ __host__ __device__ __forceinline__ size_t db_lds_layout(int UM, int CL, bool al
     CARVE(Y, double, UM)
     CARVE(Z, double, UM)
     if constexpr (WRITE) L->mask = (unsigned long long *)(base + off);
-    // (thread-per-point build: key[] / front[] are also the cross-wave exchange of the sort, one slot per THREAD -- 512
-    // threads wherever the capacity is above 256, see db_mm_copies)
-    const int xslots = UM > 256 && UM < 512 ? 512 : UM;
+    // (thread-per-point build: key[] / front[] are also the cross-wave exchange of the sort, one slot per THREAD -- 256
+    // threads up to a capacity of 256 points, 512 wherever it is above, see db_mm_copies -- whatever the capacity: a context
+    // whose ring holds fewer points than the kernel has threads still sorts over every thread slot.  With UM slots the
+    // idle threads' keys ran over idx[] .. nend[] for rings of fewer than ~150 points: found by tests/test_gpu_fuzz.py)
+    const int xslots = UM <= 256 ? 256 : (UM < 512 ? 512 : UM);
     CARVE(key, double, all8 ? xslots : db_pow2ceil(UM))   // (generic build: also the 64-bit half of the sort keys, one per slot)
     CARVE(idx, int, UM)
     CARVE(idx2, int, UM)

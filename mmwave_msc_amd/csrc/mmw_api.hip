@@ -808,8 +808,10 @@ int mmw_check(mmw_ctx *c)
         if (!e) continue;
         if (e & ERR_BADCOUNT) return fail(c, MMW_E_ARG, "scene %zu: n_pts outside [0, max_pts=%d]", s, c->dc.max_pts);
         if (e & ERR_CAPACITY) return fail(c, MMW_E_CAPACITY, "scene %zu: more tracks than track_cap=%d", s, c->dc.t_cap);
-        if (e & ERR_SINGULAR) return fail(c, MMW_E_SINGULAR, "scene %zu: singular 6x6 gate/innovation matrix", s);
+        // (a zero denominator leaves inf / NaN in the track's state, which the next frames' 6x6 inversions then report as
+        //  singular: when both bits are set the division came first -- as the reference's ZeroDivisionError would have)
         if (e & ERR_DIVZERO) return fail(c, MMW_E_DIVZERO, "scene %zu: (N_est-1)*N == 0 in _get_Rc / N_est == 0", s);
+        if (e & ERR_SINGULAR) return fail(c, MMW_E_SINGULAR, "scene %zu: singular 6x6 gate/innovation matrix", s);
     }
     int32_t q[16];
     HIPCHK(c, hipMemcpyAsync(q, c->d_q, sizeof(q), hipMemcpyDeviceToHost, c->stream));

@@ -74,9 +74,11 @@ __device__ __forceinline__ void update_math(TrackRec *rec, bool live, const doub
         double v[6], det;
 #pragma unroll
         for (int i = 0; i < 6; i++) v[i] = (c16 == i) ? 1.0 : 0.0;
+        // (every lane of the group: the lanes that report the LU's outcome below must know that a zero denominator came first --
+        //  Python raises ZeroDivisionError in _get_Rc, Tracking.py:299-312, before S is ever inverted)
+        const double N = (double)reinterpret_cast<const int32_t *>(R + rInts)[0], nest = R[rNest];
+        const double den = (nest - 1) * N;
         if (valid) {
-            const double N = (double)reinterpret_cast<const int32_t *>(R + rInts)[0], nest = R[rNest];
-            const double den = (nest - 1) * N;
             if (den == 0.0) err |= ERR_DIVZERO;
             const double coef = (nest - N) / den;
             const double hh = R[rSpr + c] / 2;
@@ -91,7 +93,7 @@ __device__ __forceinline__ void update_math(TrackRec *rec, bool live, const doub
         }
         const bool ok = lu6_inverse_cols(v, lane, det);
         if (live && c < 16) {
-            if (!ok) err |= ERR_SINGULAR;
+            if (!ok && den != 0.0) err |= ERR_SINGULAR;   // (den == 0: S is inf / NaN because of the division, not singular)
             if (c >= 6 && c < 12) {
 #pragma unroll
                 for (int r = 0; r < 6; r++) W[wSI + r * 6 + c - 6] = v[r];

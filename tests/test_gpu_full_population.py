@@ -61,7 +61,7 @@ def test_full_track_population_4096x512x8_vs_oracle():
                      "is_static", "ring_len", "ring_n"):
             assert np.array_equal(got[name], want[name]), (s, name)
         most = max(most, int(ntr[s]))
-    assert most == T and float(ntr.mean()) > 0.9 * T   # K = T: (nearly) every scene tracks all its targets
+    assert most >= T and float(ntr.mean()) > 0.9 * T   # K = T: (nearly) every scene tracks all its targets (a frame of several new clusters may exceed TR_MAX_TRACKS, Tracking.py:576-589)
     ln, rn = sb.batch_ring()
     for s in range(0, S, 3):
         assert np.array_equal(rn[s, : ln[s]], ob.scenes[s].batch_ring()), s

@@ -76,8 +76,15 @@ def test_split_fp16_cnn_holds_the_fp32_tolerance(frames, n):
     want = mars_forward_np(w, feat.astype(np.float64))
     x = torch.from_numpy(feat).to("cuda:0")
     m16 = MarsCNN.from_keras_weights(w).to("cuda:0")
-    m32 = MarsCNN.from_keras_weights(w, arith="f32").to("cuda:0")
-    assert m16.arith == "f16x3" and m32.arith == "f32" and m16.use_hip_conv
+    # (the fp32 comparison: the fp32 matrix-core kernel for the 3-frame model; the single-frame model has none, and torch's
+    #  convolutions are only ever run on request)
+    m32 = MarsCNN.from_keras_weights(w, arith="f32" if frames == 3 else "torch").to("cuda:0")
+    assert m16.arith == "f16x3" and m32.arith == m32.fp32_arith() and m16.use_hip_conv
+    if frames == 1:
+        with pytest.raises(ValueError):
+            m16(x[:n], arith="f32")           # no silent hand-over to torch
+        with pytest.raises(TypeError):
+            m16(x[:n].double())
     with torch.no_grad():
         k16, k32 = m16(x[:n]).double().cpu().numpy(), m32(x[:n]).double().cpu().numpy()
         a_hi, a_lo = (t.double().cpu().numpy() for t in deinterleave_split(m16._hip_convs_split(x)))
