@@ -251,6 +251,7 @@ def main():
                          "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
     ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the host-fed legs (frames from pinned host memory every step: bench_ingest.py)")
     ap.add_argument("--fused-step", type=int, default=0, choices=(-1, 0, 1),
                     help="mmw_config.fused_step: 0 = the library's choice (k_scene for contexts whose scenes are all resident), 1 = on, -1 = off")
     ap.add_argument("--dry-run", action="store_true",
@@ -546,6 +547,18 @@ def main():
         except Exception as exc:
             e2e_par = {"error": repr(exc)[:300]}
 
+    # ---- host-fed: the same frames from pinned host memory every step (H2D one frame ahead; fp32 rows, fp64 rows, raw rows
+    #      through mmw_normalize_f32; and the end-to-end form) ----
+    ingest = None
+    if single and not args.no_ingest:
+        try:
+            from bench_ingest import ingest_leg
+            e2e_ms = e2e.get("ms_per_step") if isinstance(e2e, dict) else None
+            ingest = ingest_leg(sb, pts, cnt, dts, d_cnt, d_dt, (d_assoc, d_lab, d_dbn), W, F, S, world, barrier, max_over_ranks, dev, side,
+                                resident_ms=el / K * 1e3, e2e_resident_ms=e2e_ms, with_e2e=not args.no_e2e)
+        except Exception as exc:  # never lose the headline line over a further leg
+            ingest = {"error": repr(exc)[:300]}
+
     if rank == 0:
         total_sf = S_total * K
         # per-kernel device time from the sampled HIP-event pairs (one step in PROF_EVERY); algorithmic bytes
@@ -648,6 +661,8 @@ def main():
             line["full_tracks"] = full
         if cold is not None:
             line["cold_start"] = cold
+        if ingest is not None:
+            line["ingest"] = ingest
         if e2e is not None:
             line["e2e"] = e2e
         if e2e_par is not None:

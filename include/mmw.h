@@ -203,6 +203,10 @@ int mmw_memcpy_d2h(mmw_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
  * raw[S][max_pts][5] = (x,y,z,doppler,peakVal) -> pts[S][max_pts][8], kept rows
  * compacted in input order; n_out[S].  All dev pointers. */
 int mmw_normalize(mmw_ctx *ctx, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out);
+/* The same from fp32 raw rows (20 bytes per detected object: what crosses PCIe in a host-fed loop, offline_main.py:40-57): each
+ * value is promoted to fp64 as it is loaded -- exact; the IWR1443's objects are int16 counts scaled by a power of two
+ * (ReadDataIWR1443.py:150-170) -- and the arithmetic is mmw_normalize's.  pts stays fp64 (normalize_data's own dtype). */
+int mmw_normalize_f32(mmw_ctx *ctx, const float *raw, const int32_t *n_raw, double *pts, int32_t *n_out);
 
 /* TrackBuffer.track(pointcloud, batch) for every scene (Tracking.py:664-703):
  *   pts[S][max_pts][8] fp64 (x,y,z,vx,vy,vz,doppler,peakVal), n_pts[S], dt[S] (= trackbuffer.dt).
@@ -216,7 +220,13 @@ int mmw_normalize(mmw_ctx *ctx, const double *raw, const int32_t *n_raw, double 
  *                          ring (Utils.py:272-278); db_n = -1 when it was not called. */
 int mmw_step(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double *dt,
              int32_t *assoc, int32_t *db_labels, int32_t *db_n);
-/* Same with host pointers (H2D, step, D2H; sync). */
+/* mmw_step on fp32 rows: pts[S][max_pts][8] float (32 bytes per point, 16-byte aligned), promoted to fp64 in registers as
+ * the association kernel loads them -- exact, so for rows that are fp32-representable (a CSV of the reference's logs, the
+ * synthetic scenes of bench.py) every output is bit-equal to mmw_step's on the promoted rows.  Half the bytes per frame
+ * over PCIe and out of HBM, and no conversion pass in front of the step. */
+int mmw_step_f32(mmw_ctx *ctx, const float *pts, const int32_t *n_pts, const double *dt,
+                 int32_t *assoc, int32_t *db_labels, int32_t *db_n);
+/* mmw_step with host pointers (H2D, step, D2H; sync). */
 int mmw_step_host(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_labels, int32_t *db_n);
 

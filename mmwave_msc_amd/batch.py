@@ -187,6 +187,15 @@ class SceneBatch:
         """TrackBuffer.track for all scenes; every argument is a device pointer (int)."""
         self._chk(self.L.mmw_step(self.h, pts_ptr, n_ptr, dt_ptr, assoc_ptr, labels_ptr, dbn_ptr))
 
+    def step_dev_f32(self, pts_ptr, n_ptr, dt_ptr, assoc_ptr=None, labels_ptr=None, dbn_ptr=None):
+        """mmw_step_f32: the same with the frame's rows as fp32 ([S][max_pts][8] float, device pointer), promoted exactly."""
+        self._chk(self.L.mmw_step_f32(self.h, pts_ptr, n_ptr, dt_ptr, assoc_ptr, labels_ptr, dbn_ptr))
+
+    def normalize_dev(self, raw_ptr, n_raw_ptr, pts_ptr, n_out_ptr, f32: bool = False):
+        """Utils.normalize_data on device buffers: raw[S][max_pts][5] (fp64, or fp32 with f32=True) -> pts[S][max_pts][8] fp64."""
+        fn = self.L.mmw_normalize_f32 if f32 else self.L.mmw_normalize
+        self._chk(fn(self.h, raw_ptr, n_raw_ptr, pts_ptr, n_out_ptr))
+
     def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray):
         """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S])."""
         pts = np.ascontiguousarray(pts, dtype=np.float64)

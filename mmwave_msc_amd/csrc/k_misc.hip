@@ -8,11 +8,15 @@
 //   k_table       fixed-size track summaries for the RCCL all-gather
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
+#include "mmw_launch.hpp"
 
 namespace mmw {
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const double *__restrict__ raw, const int32_t *__restrict__ n_raw,
+// RT = the raw rows' type: double (mmw_normalize) or float (mmw_normalize_f32: 20 bytes per detected object, promoted
+// exactly as it is loaded -- the IWR1443's objects are int16 counts scaled by a power of two, ReadDataIWR1443.py:150-170).
+template <typename RT>
+__global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const RT *__restrict__ raw, const int32_t *__restrict__ n_raw,
                                                    double *__restrict__ out, int32_t *__restrict__ n_out)
 {
     __shared__ int wcnt[4];
@@ -20,7 +24,7 @@ __global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const double *__r
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NP = cfg.max_pts;
     const int n = min(max(n_raw[s], 0), NP);
-    const double *in = raw + (size_t)s * NP * 5;
+    const RT *in = raw + (size_t)s * NP * 5;
     double *dst = out + (size_t)s * NP * 8;
     if (tid == 0) base_s = 0;
     __syncthreads();
@@ -29,7 +33,8 @@ __global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const double *__r
         bool keep = false;
         double o[8];
         if (i < n) {
-            const double x = in[i * 5], y = in[i * 5 + 1], z = in[i * 5 + 2], dop = in[i * 5 + 3], pk = in[i * 5 + 4];
+            const double x = (double)in[i * 5], y = (double)in[i * 5 + 1], z = (double)in[i * 5 + 2], dop = (double)in[i * 5 + 3],
+                         pk = (double)in[i * 5 + 4];
             const double r = sqrt((x * x + y * y) + z * z);
             double vx, vy, vz;
             if (r == 0) { vx = 0; vy = dop; vz = 0; }           // Utils.py:387-390
@@ -50,9 +55,9 @@ __global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const double *__r
         int off = base_s;
         for (int w = 0; w < wave; w++) off += wcnt[w];
         if (keep) {
-            double *d = dst + (size_t)(off + __popcll(b & lanemask_lt())) * 8;
+            double2 *d = reinterpret_cast<double2 *>(dst + (size_t)(off + __popcll(b & lanemask_lt())) * 8);   // (whole rows: 16-byte stores)
 #pragma unroll
-            for (int q = 0; q < 8; q++) d[q] = o[q];
+            for (int q = 0; q < 4; q++) d[q] = double2{o[2 * q], o[2 * q + 1]};
         }
         __syncthreads();
         if (tid == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
@@ -359,9 +364,10 @@ __global__ void k_reset(DevCfg cfg, DevState st, const int32_t *__restrict__ fla
     for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);
 }
 
-void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st)
+void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_normalize, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, raw, n_raw, out, n_out);
+    if (f32) mmw_launch(k_normalize<float>, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, reinterpret_cast<const float *>(raw), n_raw, out, n_out);
+    else mmw_launch(k_normalize<double>, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, reinterpret_cast<const double *>(raw), n_raw, out, n_out);
 }
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st)
 {

@@ -220,8 +220,8 @@ __device__ __forceinline__ void update_round(const Lds &L, TrackRec *trk, int j0
 
 using namespace scene;
 
-template <int NT, int PPT, int DX>
-__global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st, const double *__restrict__ pts_all, const int32_t *__restrict__ n_pts,
+template <int NT, int PPT, int DX, bool F32 = false>
+__global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st, const void *__restrict__ pts_all, const int32_t *__restrict__ n_pts,
                                                        const double *__restrict__ dt_all, int32_t *__restrict__ assoc_out,
                                                        int32_t *__restrict__ db_n_out, int32_t *__restrict__ db_labels_out, int UM_out, int parity)
 {
@@ -252,12 +252,11 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
     //  waiting for the point count: rows past it are allocated memory, loaded speculatively and ignored)
     auto load_points = [&]() {
         asm volatile("" : : : "memory");  // (compiler only: keeps these loads behind the ones requested so far)
-        const double2 *src2 = reinterpret_cast<const double2 *>(pts_all + (size_t)s * NP * 8);
+        const void *frame = frame_of(pts_all, s, NP, F32);   // (fp32 rows, mmw_step_f32: promoted as they are loaded)
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = q * NT + tid;
-#pragma unroll
-            for (int u = 0; u < 4; u++) pr[q][u] = (i < NP) ? src2[i * 4 + u] : double2{0.0, 0.0};
+            load_point_row<F32>(frame, i, i < NP, pr[q]);
         }
     };
     const int n = n_raw < 0 ? 0 : n_raw;  // MMW_EMPTY_FRAME: track() on an empty cloud
@@ -905,34 +904,42 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
 
 size_t scene_lds_bytes(const DevCfg &c) { return lds_layout<false>(c, nullptr, nullptr); }
 
-template <int NT, int PPT>
-static void launch_scene_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc,
+template <int NT, int PPT, bool F32>
+static void launch_scene_t(const DevCfg &cfg, const DevState &st, const void *pts, const int32_t *n_pts, const double *dt, int32_t *assoc,
                            int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
     if (cfg.dx == 9)
-        mmw_launch(k_scene<NT, PPT, 9>, dim3(cfg.n_scenes), dim3(NT), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
+        mmw_launch(k_scene<NT, PPT, 9, F32>, dim3(cfg.n_scenes), dim3(NT), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
                    UM, parity);
     else
-        mmw_launch(k_scene<NT, PPT, 6>, dim3(cfg.n_scenes), dim3(NT), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
+        mmw_launch(k_scene<NT, PPT, 6, F32>, dim3(cfg.n_scenes), dim3(NT), scene_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n, db_labels,
                    UM, parity);
 }
 
 // (NT = 256: eight waves per scene were tried -- one point per thread, a wave per Kalman filter, sums and min / max on different
 //  waves.  Two such workgroups per CU leave 128 VGPRs per lane: the kernel spills 80 of them and ran 57 us instead of 45.)
-void launch_scene(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc,
+void launch_scene(const DevCfg &cfg, const DevState &st, const void *pts, bool f32, const int32_t *n_pts, const double *dt, int32_t *assoc,
                   int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
     const int ppt = (cfg.max_pts + 255) / 256;
-    if (ppt <= 1) launch_scene_t<256, 1>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
-    else if (ppt == 2) launch_scene_t<256, 2>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
-    else launch_scene_t<256, 4>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    if (f32) {
+        if (ppt <= 1) launch_scene_t<256, 1, true>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+        else if (ppt == 2) launch_scene_t<256, 2, true>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+        else launch_scene_t<256, 4, true>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+        return;
+    }
+    if (ppt <= 1) launch_scene_t<256, 1, false>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else if (ppt == 2) launch_scene_t<256, 2, false>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else launch_scene_t<256, 4, false>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
 }
 
 hipError_t prepare_scene(const DevCfg &cfg)
 {
     const int lds = (int)scene_lds_bytes(cfg);
-    const void *fns[6] = {(const void *)k_scene<256, 1, 9>, (const void *)k_scene<256, 2, 9>, (const void *)k_scene<256, 4, 9>,
-                          (const void *)k_scene<256, 1, 6>, (const void *)k_scene<256, 2, 6>, (const void *)k_scene<256, 4, 6>};
+    const void *fns[12] = {(const void *)k_scene<256, 1, 9>, (const void *)k_scene<256, 2, 9>, (const void *)k_scene<256, 4, 9>,
+                           (const void *)k_scene<256, 1, 6>, (const void *)k_scene<256, 2, 6>, (const void *)k_scene<256, 4, 6>,
+                           (const void *)k_scene<256, 1, 9, true>, (const void *)k_scene<256, 2, 9, true>, (const void *)k_scene<256, 4, 9, true>,
+                           (const void *)k_scene<256, 1, 6, true>, (const void *)k_scene<256, 2, 6, true>, (const void *)k_scene<256, 4, 6, true>};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;

@@ -200,8 +200,9 @@ __device__ __forceinline__ double pw_leaf(const double *pa, const double *pb, do
 // INNER = mmw_config.seek_inner (per-track ring sizes, see k_inner in k_dbscan.hip): a template so that the default
 // instantiation carries none of it.
 // PRED = _predict_all at the head of this kernel instead of in k_predict (small contexts, mmw_kalman.hpp: pred_in_track).
-template <int PPT, bool INNER, bool PRED = false>
-__global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3)))) void k_track(DevCfg cfg, DevState st, const double *__restrict__ pts_all,
+// F32 = the frame's rows are fp32 (mmw_step_f32), promoted to fp64 as they are loaded (mmw_device.hpp: load_point_row).
+template <int PPT, bool INNER, bool PRED = false, bool F32 = false>
+__global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4 : 3)))) void k_track(DevCfg cfg, DevState st, const void *__restrict__ pts_all,
                                                     const int32_t *__restrict__ n_pts, const double *__restrict__ dt_all,
                                                     int32_t *__restrict__ assoc_out, int32_t *__restrict__ db_n_out,
                                                     int32_t *__restrict__ db_labels_out, int UM_out, int parity)
@@ -230,12 +231,11 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     const int my_slot = tid < cfg.t_cap ? st.order[(size_t)s * cfg.t_cap + tid] : 0;
     double2 pr[PPT][4];
     {
-        const double2 *src2 = reinterpret_cast<const double2 *>(pts_all + (size_t)s * NP * 8);
+        const void *frame = frame_of(pts_all, s, NP, F32);
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
             const int i = q * kThreads + tid;
-#pragma unroll
-            for (int u = 0; u < 4; u++) pr[q][u] = (i < NP) ? src2[i * 4 + u] : double2{0.0, 0.0};
+            load_point_row<F32>(frame, i, i < NP, pr[q]);
         }
     }
     const int n_raw = n_pts[s];
@@ -952,48 +952,64 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     WGTIME(1);
 }
 
-template <int PPT>
-static void launch_track_t(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+template <int PPT, bool F32>
+static void launch_track_t(const DevCfg &cfg, const DevState &st, const void *pts, const int32_t *n_pts, const double *dt,
                            int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
     if (pred_in_track(cfg)) {  // (never with seek_inner)
         if (cfg.var_ring)
-            mmw_launch(k_track<PPT, true, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc,
+            mmw_launch(k_track<PPT, true, true, F32>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc,
                        db_n, db_labels, UM, parity);
         else
-            mmw_launch(k_track<PPT, false, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc,
+            mmw_launch(k_track<PPT, false, true, F32>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc,
                        db_n, db_labels, UM, parity);
         return;
     }
     if (cfg.seek_inner || cfg.var_ring)
-        mmw_launch(k_track<PPT, true>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
+        mmw_launch(k_track<PPT, true, false, F32>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
                    db_labels, UM, parity);
     else
-        mmw_launch(k_track<PPT, false>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
+        mmw_launch(k_track<PPT, false, false, F32>, dim3(cfg.n_scenes), dim3(kThreads), track_lds_bytes(cfg), stream, cfg, st, pts, n_pts, dt, assoc, db_n,
                    db_labels, UM, parity);
 }
 
-void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+void launch_track(const DevCfg &cfg, const DevState &st, const void *pts, bool f32, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream)
 {
     const int ppt = (cfg.max_pts + kThreads - 1) / kThreads;
-    if (ppt <= 1) launch_track_t<1>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
-    else if (ppt == 2) launch_track_t<2>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
-    else launch_track_t<4>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    if (f32) {
+        if (ppt <= 1) launch_track_t<1, true>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+        else if (ppt == 2) launch_track_t<2, true>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+        else launch_track_t<4, true>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+        return;
+    }
+    if (ppt <= 1) launch_track_t<1, false>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else if (ppt == 2) launch_track_t<2, false>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
+    else launch_track_t<4, false>(cfg, st, pts, n_pts, dt, assoc, db_n, db_labels, UM, parity, stream);
 }
 
-hipError_t prepare_track(const DevCfg &cfg)
+template <int PPT, bool F32>
+static hipError_t prepare_track_t(int lds)
 {
-    const int lds = (int)track_lds_bytes(cfg);
-    const void *fns[12] = {(const void *)k_track<1, false>, (const void *)k_track<2, false>, (const void *)k_track<4, false>,
-                           (const void *)k_track<1, true>, (const void *)k_track<2, true>, (const void *)k_track<4, true>,
-                           (const void *)k_track<1, false, true>, (const void *)k_track<2, false, true>, (const void *)k_track<4, false, true>,
-                           (const void *)k_track<1, true, true>, (const void *)k_track<2, true, true>, (const void *)k_track<4, true, true>};
+    const void *fns[4] = {(const void *)k_track<PPT, false, false, F32>, (const void *)k_track<PPT, true, false, F32>,
+                          (const void *)k_track<PPT, false, true, F32>, (const void *)k_track<PPT, true, true, F32>};
     for (const void *f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t prepare_track(const DevCfg &cfg)
+{
+    const int lds = (int)track_lds_bytes(cfg);
+    hipError_t e = prepare_track_t<1, false>(lds);
+    if (e == hipSuccess) e = prepare_track_t<2, false>(lds);
+    if (e == hipSuccess) e = prepare_track_t<4, false>(lds);
+    if (e == hipSuccess) e = prepare_track_t<1, true>(lds);
+    if (e == hipSuccess) e = prepare_track_t<2, true>(lds);
+    if (e == hipSuccess) e = prepare_track_t<4, true>(lds);
+    return e;
 }
 
 }  // namespace mmw

@@ -22,11 +22,11 @@ void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts,
 void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int u_bound, int parity, int epoch, int32_t *labels,
                  int32_t *db_n, hipStream_t stream);
 void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side);
-void launch_track(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+void launch_track(const DevCfg &cfg, const DevState &st, const void *pts, bool f32, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
 size_t scene_lds_bytes(const DevCfg &c);
 hipError_t prepare_scene(const DevCfg &cfg);
-void launch_scene(const DevCfg &cfg, const DevState &st, const double *pts, const int32_t *n_pts, const double *dt,
+void launch_scene(const DevCfg &cfg, const DevState &st, const void *pts, bool f32, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_n, int32_t *db_labels, int UM, int parity, hipStream_t stream);
 size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples);
 size_t dbscan_only_lds_bytes(int UM);
@@ -41,7 +41,7 @@ size_t dbscan_huge_slab_bytes(int UM, int t_cap, int min_samples);
 void launch_dbscan_huge(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int32_t *labels, int32_t *db_n, hipStream_t stream);
 void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
-void launch_normalize(const DevCfg &cfg, const double *raw, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
+void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
                      hipStream_t st);
@@ -621,19 +621,32 @@ int mmw_memcpy_d2h(mmw_ctx *c, void *dst, const void *src, size_t bytes)
     return MMW_OK;
 }
 
-int mmw_normalize(mmw_ctx *c, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out)
+static int normalize_impl(mmw_ctx *c, const void *raw, bool f32, const int32_t *n_raw, double *pts, int32_t *n_out)
 {
     if (!c || !raw || !n_raw || !pts || !n_out) return fail(c, MMW_E_ARG, "mmw_normalize: null pointer");
+    if (((uintptr_t)pts & 15) != 0) return fail(c, MMW_E_ARG, "mmw_normalize: pts must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
-    prof_begin(c, MMW_K_NORMALIZE, ep);
-    launch_normalize(c->dc, raw, n_raw, pts, n_out, c->stream);
-    prof_end(c, ep);
+    prof_arm(c, MMW_K_NORMALIZE, ep);
+    launch_normalize(c->dc, raw, f32, n_raw, pts, n_out, c->stream);
+    prof_armed_done(c, ep);
     HIPCHK(c, hipGetLastError());
     return MMW_OK;
 }
+int mmw_normalize(mmw_ctx *c, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out) { return normalize_impl(c, raw, false, n_raw, pts, n_out); }
+int mmw_normalize_f32(mmw_ctx *c, const float *raw, const int32_t *n_raw, double *pts, int32_t *n_out) { return normalize_impl(c, raw, true, n_raw, pts, n_out); }
 
+static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n);
 int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
+{
+    return step_impl(c, pts, false, n_pts, dt, assoc, db_labels, db_n);
+}
+int mmw_step_f32(mmw_ctx *c, const float *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
+{
+    return step_impl(c, pts, true, n_pts, dt, assoc, db_labels, db_n);
+}
+
+static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
 {
     if (!c || !pts || !n_pts || !dt) return fail(c, MMW_E_ARG, "mmw_step: null input pointer");
     if (((uintptr_t)pts & 15) != 0) return fail(c, MMW_E_ARG, "mmw_step: pts must be 16-byte aligned");
@@ -667,8 +680,8 @@ int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *
     launch_predict(c->dc, c->st, n_pts, dt, c->step_parity, c->stream);
     prof_armed_done(c, ep);
     prof_arm(c, MMW_K_TRACK, ep);
-    if (c->dc.fused) launch_scene(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
-    else launch_track(c->dc, c->st, pts, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
+    if (c->dc.fused) launch_scene(c->dc, c->st, pts, f32, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
+    else launch_track(c->dc, c->st, pts, f32, n_pts, dt, assoc, db_n, db_labels, c->UM, c->step_parity, c->stream);
     prof_armed_done(c, ep);
     if (c->dc.seek_inner) launch_inner(c->dc, c->st, n_pts, db_n, c->stream);  // Tracking.py:656 active
     prof_arm(c, MMW_K_POST, ep);

@@ -141,6 +141,32 @@ __device__ inline unsigned long long *stats_slot(const DevState &st, int scene)
     return st.stats ? st.stats + (size_t)(scene & (kStatSlots - 1)) * kStatWords : nullptr;
 }
 
+// One row of a frame (8 columns: x, y, z, vx, vy, vz, doppler, peakVal) into registers.  fp64 rows (mmw_step) are four
+// 16-byte loads; fp32 rows (mmw_step_f32: 32 bytes per point, what a radar front end or a CSV reader produces) two, each
+// value promoted to fp64 in registers -- exactly; from there on both entries run the same instructions on the same bits.
+// Rows past the frame's capacity load nothing.
+template <bool F32>
+__device__ __forceinline__ void load_point_row(const void *frame, int i, bool valid, double2 (&r)[4])
+{
+    if constexpr (F32) {
+        const float4 *src = reinterpret_cast<const float4 *>(frame);
+        const float4 a = valid ? src[i * 2] : float4{0.f, 0.f, 0.f, 0.f}, b = valid ? src[i * 2 + 1] : float4{0.f, 0.f, 0.f, 0.f};
+        r[0] = double2{(double)a.x, (double)a.y};
+        r[1] = double2{(double)a.z, (double)a.w};
+        r[2] = double2{(double)b.x, (double)b.y};
+        r[3] = double2{(double)b.z, (double)b.w};
+    } else {
+        const double2 *src = reinterpret_cast<const double2 *>(frame);
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = valid ? src[i * 4 + u] : double2{0.0, 0.0};
+    }
+}
+// start of scene s's frame: rows of 8 values, fp64 or fp32
+__device__ __forceinline__ const void *frame_of(const void *pts_all, int s, int NP, bool f32)
+{
+    return reinterpret_cast<const char *>(pts_all) + (size_t)s * NP * (f32 ? 32 : 64);
+}
+
 __host__ __device__ inline size_t trk_ring_stride_track(const DevCfg &c) { return (size_t)c.ring * c.ring_rows * 8; }
 
 }  // namespace mmw

@@ -323,6 +323,75 @@ def test_normalize_golden_and_oracle():
     sb.close()
 
 
+def test_fp32_row_entry_is_bit_equal_to_the_fp64_entry():
+    """mmw_step_f32 (32-byte rows promoted to fp64 as the association kernel loads them, include/mmw.h) against mmw_step on the
+    promoted rows: every output and every track field bit-equal, every frame, in every layout; and against the oracle on the
+    last frame.  mmw_normalize_f32 likewise against mmw_normalize (Utils.py:342-434).  Ragged counts, skipped and empty frames."""
+    import torch
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    S, N, F, T = 40, 200, 12, 5
+    kw = dict(tr_max_tracks=T)
+    pts = np.zeros((F, S, N, 8), np.float32); cnt = np.zeros((F, S), np.int32); dts = np.zeros((F, S))
+    for s in range(S):
+        p, c, d = make_batch([6100 + s], F, N, s % (T + 1), ragged=(s % 2 == 0))
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    cnt[3, 5] = 0; cnt[4, 6] = -1; cnt[7, ::9] = 0
+    dev = torch.device("cuda:0")
+    a, b = _mk(S, N, **kw), _mk(S, N, **kw)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        a.follow_torch_stream(st); b.follow_torch_stream(st)
+        d_cnt = torch.from_numpy(cnt).to(dev); d_dt = torch.from_numpy(dts).to(dev)
+        out = [dict(a=torch.full((S, N), -7, dtype=torch.int32, device=dev), l=torch.full((S, a.UM), -7, dtype=torch.int32, device=dev),
+                    n=torch.full((S,), -7, dtype=torch.int32, device=dev)) for _ in range(2)]
+        for f in range(F):
+            p32 = torch.from_numpy(pts[f]).to(dev)
+            p64 = p32.double()
+            a.step_dev(p64.data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr(), out[0]["a"].data_ptr(), out[0]["l"].data_ptr(), out[0]["n"].data_ptr())
+            b.step_dev_f32(p32.data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr(), out[1]["a"].data_ptr(), out[1]["l"].data_ptr(), out[1]["n"].data_ptr())
+            st.synchronize()
+            for k in ("a", "l", "n"):
+                assert torch.equal(out[0][k], out[1][k]), (f, k)
+            na, nb = a.num_tracks(), b.num_tracks()
+            assert np.array_equal(na, nb), f
+            assert a.tracks(cap=max(int(na.max()), 1)).tobytes() == b.tracks(cap=max(int(na.max()), 1)).tobytes(), f
+    a.check(); b.check()
+    fa, oa = a.features_host(); fb, ob_ = b.features_host()
+    assert np.array_equal(oa, ob_) and np.array_equal(fa, fb)
+    ocfg = co.default_config(**kw)
+    ntr = b.num_tracks(); trk = b.tracks(cap=max(int(ntr.max()), 1))
+    for s in range(S):
+        sc = co.OracleScene(ocfg, N)
+        for f in range(F):
+            if cnt[f, s] != 0:   # (0: the frame never reaches track(); -1: track() on an empty cloud)
+                sc.track(pts[f, s, : max(int(cnt[f, s]), 0)].astype(np.float64), float(dts[f, s]))
+        assert ntr[s] == sc.n_tracks, s
+        assert_tracks_match(trk[s, : ntr[s]], sc.tracks(), ctx=f"scene {s}", exact=True)
+    # mmw_normalize_f32 against mmw_normalize on the promoted rows
+    rng = np.random.default_rng(12)
+    raw = np.zeros((S, N, 5), np.float32)
+    raw[..., 0] = rng.uniform(-4, 4, (S, N)); raw[..., 1] = rng.uniform(-0.5, 8, (S, N)); raw[..., 2] = rng.uniform(-2.5, 1.5, (S, N))
+    raw[..., 3] = rng.normal(0, 0.5, (S, N)); raw[..., 4] = rng.gamma(1.0, 30.0, (S, N))
+    raw[0, 0, :3] = 0.0                                       # r == 0 (Utils.py:387-390)
+    nraw = rng.integers(0, N + 1, S).astype(np.int32)
+    with torch.cuda.stream(st):
+        r32 = torch.from_numpy(raw).to(dev); r64 = r32.double(); dn = torch.from_numpy(nraw).to(dev)
+        o = [torch.zeros((S, N, 8), dtype=torch.float64, device=dev) for _ in range(2)]
+        no = [torch.zeros((S,), dtype=torch.int32, device=dev) for _ in range(2)]
+        a.normalize_dev(r64.data_ptr(), dn.data_ptr(), o[0].data_ptr(), no[0].data_ptr())
+        a.normalize_dev(r32.data_ptr(), dn.data_ptr(), o[1].data_ptr(), no[1].data_ptr(), f32=True)
+        st.synchronize()
+    assert torch.equal(no[0], no[1])
+    h0, h1, hn = o[0].cpu().numpy(), o[1].cpu().numpy(), no[0].cpu().numpy()
+    cfg = co.default_config()
+    for s in range(S):
+        assert np.array_equal(h0[s, : hn[s]], h1[s, : hn[s]]), s
+        assert np.array_equal(h1[s, : hn[s]], co.normalize(cfg, raw[s, : nraw[s]].astype(np.float64))), s
+    assert 0 < int(hn.sum()) < int(nraw.sum())                  # the scene filter kept some rows and dropped some
+    a.close(); b.close()
+
+
 def test_dbscan_golden():
     z = np.load(os.path.join(GOLDEN, "dbscan.npz"))
     sizes = [int(v) for v in z["sizes"]]
