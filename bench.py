@@ -251,6 +251,7 @@ def main():
                          "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
     ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-scene leg (configs[0]: the offline loop on one synthetic CSV experiment: bench_single.py)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host-fed legs (frames from pinned host memory every step: bench_ingest.py)")
     ap.add_argument("--fused-step", type=int, default=0, choices=(-1, 0, 1),
                     help="mmw_config.fused_step: 0 = the library's choice (k_scene for contexts whose scenes are all resident), 1 = on, -1 = off")
@@ -301,10 +302,39 @@ def main():
         full_host = generate(ids, F, N, args.tracks, workers=workers, population="full")
         if not args.no_cpu:
             cpu_full, finals_full = cpu_legs(*full_host, args.tracks, cores, W, args.py_scenes_per_core, args.py_frames, args.c_scenes)
+    def cpu_e2e_leg(p_, c_, d_, tracks_, what):
+        """the end-to-end loop on the CPU port: oracle/py_tracker.py + reference-shaped relative_coordinates / format_single_frame
+        + oracle/mars_torch.py (fp32, torch's CPU operators), one process per host core, on a bounded sample of the leg's scenes
+        and the GPU leg's own frame window start"""
+        from oracle.py_tracker import run_window_multiprocess
+        from mmwave_msc_amd.mars import random_keras_weights
+        procs = max(1, min(cores, p_.shape[1]))
+        ns = min(p_.shape[1], procs * 6)
+        w_ = min(W, p_.shape[0] // 2)
+        nf = max(1, min(p_.shape[0] - w_, 24))
+        el_, _, rows_ = run_window_multiprocess({"TR_MAX_TRACKS": tracks_}, p_[:w_ + nf, :ns], c_[:w_ + nf, :ns], d_[:w_ + nf, :ns], procs, w_,
+                                                posture_weights=random_keras_weights(0, 3), want_rows=True)
+        return {"value": round(ns * nf / el_, 2), "unit": "scene-frames/s", "cores": procs, "kind": "port", "samples_per_s": round(rows_ / el_, 1),
+                "sample": f"oracle/py_tracker.py (track + py_estimate_posture: the reference's relative_coordinates / format_single_frame shape) + "
+                          f"oracle/mars_torch.py (Keras' fp32 on torch's CPU operators, 1 thread per process): scenes 0..{ns - 1} of {what}, frames "
+                          f"{w_}..{w_ + nf - 1} timed after frames 0..{w_ - 1} untimed, {procs} processes, {el_:.1f} s wall"}
+
+    e2e_cpu = None
+    if single and not args.no_cpu and not args.no_e2e:
+        e2e_cpu = cpu_e2e_leg(pts, cnt, dts, args.tracks, "this workload")
     e2e_ref = None
     if single and not args.no_e2e_parity:
         from bench_e2e import oracle_reference  # CPU side of the configs[3] leg (oracle), before the GPU is initialised
         e2e_ref = oracle_reference(workers)
+        if not args.no_cpu:
+            e2e_ref["cpu_baseline"] = cpu_e2e_leg(e2e_ref["pts"], e2e_ref["cnt"], e2e_ref["dts"], e2e_ref["par"]["T"], "the configs[3] scenes")
+    single_prep = None
+    if single and not args.no_single:
+        try:
+            from bench_single import single_scene_cpu   # configs[0]: the CSV experiment, the CPU port and the checker
+            single_prep = single_scene_cpu()
+        except Exception as exc:
+            single_prep = {"error": repr(exc)[:300]}
 
     # ---- GPU ----
     import torch
@@ -547,6 +577,24 @@ def main():
         except Exception as exc:
             e2e_par = {"error": repr(exc)[:300]}
 
+    if isinstance(e2e, dict) and e2e_cpu is not None and "error" not in e2e:
+        e2e["cpu_baseline"] = e2e_cpu
+        e2e["speedup_vs_cpu_baseline"] = round(e2e["value"] / e2e_cpu["value"], 1)
+    if isinstance(e2e_par, dict) and e2e_ref is not None and "cpu_baseline" in e2e_ref and "error" not in e2e_par:
+        e2e_par["cpu_baseline"] = e2e_ref["cpu_baseline"]
+        e2e_par["speedup_vs_cpu_baseline"] = round(e2e_par["scene_frames_per_sec"] / e2e_ref["cpu_baseline"]["value"], 1)
+    # ---- configs[0]: one scene through the offline loop (CSV -> normalize_data -> track -> estimate_posture) ----
+    single_leg = None
+    if single_prep is not None:
+        if "error" in single_prep:
+            single_leg = single_prep
+        else:
+            try:
+                from bench_single import single_scene_gpu
+                single_leg = single_scene_gpu(single_prep, local_rank)
+            except Exception as exc:
+                single_leg = {"error": repr(exc)[:300]}
+
     # ---- host-fed: the same frames from pinned host memory every step (H2D one frame ahead; fp32 rows, fp64 rows, raw rows
     #      through mmw_normalize_f32; and the end-to-end form) ----
     ingest = None
@@ -663,6 +711,8 @@ def main():
             line["cold_start"] = cold
         if ingest is not None:
             line["ingest"] = ingest
+        if single_leg is not None:
+            line["single_scene"] = single_leg
         if e2e is not None:
             line["e2e"] = e2e
         if e2e_par is not None:

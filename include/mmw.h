@@ -226,9 +226,21 @@ int mmw_step(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double
  * over PCIe and out of HBM, and no conversion pass in front of the step. */
 int mmw_step_f32(mmw_ctx *ctx, const float *pts, const int32_t *n_pts, const double *dt,
                  int32_t *assoc, int32_t *db_labels, int32_t *db_n);
-/* mmw_step with host pointers (H2D, step, D2H; sync). */
+/* mmw_step with host pointers (H2D, step, D2H; sync): mmw_frame_host without the normalisation. */
 int mmw_step_host(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double *dt,
                   int32_t *assoc, int32_t *db_labels, int32_t *db_n);
+/* One frame of every scene from HOST memory in ONE round trip -- the body of the reference's loop (offline_main.py:40-57):
+ *   raw != NULL (pts NULL): raw[S][max_pts][5] = (x, y, z, doppler, peakVal), n[S] rows each -> Utils.normalize_data -> the kept
+ *                           rows -> TrackBuffer.track; a scene none of whose rows pass the scene filter is skipped
+ *                           (offline_main.py:56), as is a scene with n = 0
+ *   pts != NULL (raw NULL): pts[S][max_pts][8] normalised rows, n[S] as for mmw_step (0 = skipped, MMW_EMPTY_FRAME = track() on an
+ *                           empty cloud)
+ * dt[S] = trackbuffer.dt.  Outputs (host, each may be NULL): pts_out[S][max_pts][8] / n_out[S] = normalize_data's rows and
+ * their counts (raw form; n_out = n otherwise), assoc[S][max_pts], db_labels[S][ring*max_pts], db_n[S] as mmw_step,
+ * n_tracks[S] = len(effective_tracks) after the frame.  Uploads, kernels and read-backs are queued behind one another through
+ * pinned staging blocks and the stream is waited for ONCE; the return code is mmw_check's (per-scene errors, first one). */
+int mmw_frame_host(mmw_ctx *ctx, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out,
+                   int32_t *n_out, int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks);
 
 /* Utils.apply_DBscan (Utils.py:250-291) on arbitrary clouds: pts[S][max_n][8], n[S]
  * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts; max_n > 1920: the global-memory path). */
@@ -327,6 +339,15 @@ int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, con
  * the batch may hold anything: a row only feeds its own output row), k of 32, n of 128; lda, ldw >= 2 k.  hip_stream as above. */
 int mmw_mars_dense1_split(void *hip_stream, const void *a2, int64_t lda, const void *w2, int64_t ldw, const float *bias, float *out,
                           int32_t rows_padded, int32_t k, int32_t n);
+
+/* The head of the MARS CNN for a SMALL batch (n_rows <= 64: one scene's tracks, TrackBuffer.estimate_posture of the offline
+ * loop): Dense-1 + ReLU (train.py:49,87) and Dense-2 (train.py:54,92), both with their BatchNormalization folded in, in fp32
+ * fused multiply-adds -- Keras' own arithmetic.  The weight matrix is cut along the features over the whole chip (a tile kernel
+ * would stream it through one band of eight workgroups).  act[n_rows][lda] fp32 = the conv pair's output in Keras' Flatten
+ * order (mmw_mars_conv3d); w1[n1][ldw] fp32 = Dense-1's weights transposed (K contiguous), bias1[n1]; w2[57][n1], bias2[57];
+ * hidden[n_rows][n1] scratch; kp[n_rows][57].  All dev pointers, 16-byte aligned; k, lda, ldw multiples of 4. */
+int mmw_mars_head_small(void *hip_stream, const float *act, int64_t lda, const float *w1, int64_t ldw, const float *bias1, const float *w2,
+                        const float *bias2, float *hidden, float *kp, int32_t n_rows, int32_t k, int32_t n1);
 
 /* ReadIWR14xx.read (ReadDataIWR1443.py:27-201) on a byte buffer, host only (no context, no GPU work): the input
  * step before mmw_normalize.  Looks for the LAST 8-byte magic word 02 01 04 03 06 05 08 07 in buf[0 .. len-8),

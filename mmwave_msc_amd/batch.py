@@ -209,6 +209,28 @@ class SceneBatch:
                                        assoc.ctypes.data, labels.ctypes.data, dbn.ctypes.data))
         return assoc, labels, dbn
 
+    def frame_host(self, n: np.ndarray, dt: np.ndarray, raw: np.ndarray = None, pts: np.ndarray = None, want_rows: bool = False,
+                   want_labels: bool = True):
+        """mmw_frame_host: one frame of every scene from host memory in ONE round trip.  `raw`[S,NP,5] radar rows (normalised
+        on the device, Utils.normalize_data) or `pts`[S,NP,8] normalised rows; n[S], dt[S].  Returns a dict: assoc[S,NP],
+        db_n[S], n_out[S] (rows that reached track()), n_tracks[S], labels[S,UM] (want_labels), rows[S,NP,8] (want_rows, raw form)."""
+        assert (raw is None) != (pts is None)
+        src = np.ascontiguousarray(raw if raw is not None else pts, dtype=np.float64)
+        assert src.shape == (self.S, self.max_pts, 5 if raw is not None else 8), src.shape
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        out = {"assoc": np.full((self.S, self.max_pts), -1, dtype=np.int32), "db_n": np.full(self.S, -1, dtype=np.int32),
+               "n_out": np.zeros(self.S, dtype=np.int32), "n_tracks": np.zeros(self.S, dtype=np.int32)}
+        if want_labels:
+            out["labels"] = np.full((self.S, self.UM), -1, dtype=np.int32)
+        if want_rows and raw is not None:
+            out["rows"] = np.zeros((self.S, self.max_pts, 8))
+        self._chk(self.L.mmw_frame_host(self.h, src.ctypes.data if raw is not None else None, src.ctypes.data if raw is None else None,
+                                        n.ctypes.data, dt.ctypes.data, out["rows"].ctypes.data if "rows" in out else None,
+                                        out["n_out"].ctypes.data, out["assoc"].ctypes.data,
+                                        out["labels"].ctypes.data if want_labels else None, out["db_n"].ctypes.data, out["n_tracks"].ctypes.data))
+        return out
+
     def normalize_host(self, raw: np.ndarray, n_raw: np.ndarray):
         """Utils.normalize_data for all scenes: raw[S,NP,5] -> (pts[S,NP,8], n_out[S])."""
         raw = np.ascontiguousarray(raw, dtype=np.float64)

@@ -358,4 +358,114 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The head of the MARS CNN for a SMALL batch -- one scene's tracks (the drop-in's estimate_posture, Tracking.py:705-734:
+// at most a handful of rows): Dense-1 + ReLU and Dense-2 in Keras' own fp32 arithmetic, as two thin kernels.
+// A tile kernel is the wrong shape there: 8 rows make one band of eight 256 x 192 tiles, i.e. eight workgroups stream the whole
+// 37.7 MB weight matrix while 248 CUs idle (~100 us).  Here the matrix is cut along the FEATURES over the whole chip: a
+// workgroup owns kHeadCols = 8 output columns, walks K with 16-byte loads (its 8 weight rows: 196 KB, each byte of the matrix read
+// once, by one workgroup), multiplies every chunk into up to kHeadRows = 8 batch rows held in registers and reduces over the
+// lanes at the end: bound by how fast 256 CUs can pull the weights (~10 us), not by one band's latency.
+// Plain fp32 fused multiply-adds (what Keras' fp32 Dense does; no fp16 split, so no range word to look at); the summation
+// order differs from the tile kernels' -- 1e-7 relative, inside the 1e-4 tolerance of the keypoints.
+namespace head {
+constexpr int kHeadCols = 8, kHeadRows = 8, kHeadThreads = 256;
+}
+template <int ROWS>
+__global__ __launch_bounds__(head::kHeadThreads) void k_mars_head_dense1(const float *__restrict__ act, long long lda, const float *__restrict__ w,
+                                                                         long long ldw, const float *__restrict__ bias, float *__restrict__ hidden,
+                                                                         int n_rows, int K, int N)
+{
+    using namespace head;
+    __shared__ float red[kHeadThreads / 64][ROWS][kHeadCols];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * kHeadCols, r0 = blockIdx.y * ROWS;
+    float acc[ROWS][kHeadCols];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int c = 0; c < kHeadCols; c++) acc[r][c] = 0.f;
+    const float4 *W[kHeadCols];
+#pragma unroll
+    for (int c = 0; c < kHeadCols; c++) W[c] = reinterpret_cast<const float4 *>(w + (long long)(c0 + c < N ? c0 + c : N - 1) * ldw);
+    for (int k4 = tid; k4 < K / 4; k4 += kHeadThreads) {
+        float4 wv[kHeadCols], av[ROWS];
+#pragma unroll
+        for (int c = 0; c < kHeadCols; c++) wv[c] = W[c][k4];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) av[r] = reinterpret_cast<const float4 *>(act + (long long)(r0 + r < n_rows ? r0 + r : n_rows - 1) * lda)[k4];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++)
+#pragma unroll
+            for (int c = 0; c < kHeadCols; c++) {
+                float a = acc[r][c];
+                a = __builtin_fmaf(av[r].x, wv[c].x, a);
+                a = __builtin_fmaf(av[r].y, wv[c].y, a);
+                a = __builtin_fmaf(av[r].z, wv[c].z, a);
+                a = __builtin_fmaf(av[r].w, wv[c].w, a);
+                acc[r][c] = a;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+        for (int c = 0; c < kHeadCols; c++) {
+            float v = acc[r][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red[wave][r][c] = v;
+        }
+    __syncthreads();
+    if (tid < ROWS * kHeadCols) {
+        const int r = tid / kHeadCols, c = tid - r * kHeadCols;
+        if (r0 + r < n_rows && c0 + c < N) {
+            float v = bias[c0 + c];
+#pragma unroll
+            for (int wv = 0; wv < kHeadThreads / 64; wv++) v += red[wv][r][c];
+            hidden[(long long)(r0 + r) * N + c0 + c] = v > 0.f ? v : (v != v ? v : 0.f);   // ReLU (NaN stays NaN, as Keras')
+        }
+    }
+}
+
+// Dense-2 (BatchNormalization folded in, as mars.py lays it out): kp[b][j] = bias2[j] + sum_k hidden[b][k] w2[j][k].  A WAVE per
+// output (b, j), lanes along K with every load of the wave in flight at once (K = 1536: 24 per lane, three batches of eight): the
+// 57 x n_rows dot products are independent, and as a loop of one workgroup per row they were 100 us of dependent round trips.
+__global__ __launch_bounds__(256) void k_mars_head_dense2(const float *__restrict__ hidden, const float *__restrict__ w2, const float *__restrict__ bias2,
+                                                          float *__restrict__ kp, int K, int NOUT, int n_rows)
+{
+    const int lane = threadIdx.x & 63, item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_rows * NOUT) return;   // (wave-uniform)
+    const int b = item / NOUT, j = item - b * NOUT;
+    const float *h = hidden + (long long)b * K, *wr = w2 + (long long)j * K;
+    float a = 0.f;
+    int k = lane;
+    for (; k + 7 * 64 < K; k += 8 * 64) {
+        float hv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { hv[u] = h[k + u * 64]; wv[u] = wr[k + u * 64]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) a = __builtin_fmaf(hv[u], wv[u], a);
+    }
+    for (; k < K; k += 64) a = __builtin_fmaf(h[k], wr[k], a);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) kp[(long long)b * NOUT + j] = a + bias2[j];
+}
+
+int launch_mars_head_small(const float *act, long long lda, const float *w1, long long ldw, const float *bias1, const float *w2, const float *bias2,
+                           float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream)
+{
+    using namespace head;
+    const dim3 grid((N1 + kHeadCols - 1) / kHeadCols, (n_rows + kHeadRows - 1) / kHeadRows);
+    if (n_rows <= 2)
+        hipLaunchKernelGGL(k_mars_head_dense1<2>, dim3(grid.x, (n_rows + 1) / 2), dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1);
+    else if (n_rows <= 4)
+        hipLaunchKernelGGL(k_mars_head_dense1<4>, dim3(grid.x, (n_rows + 3) / 4), dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1);
+    else
+        hipLaunchKernelGGL(k_mars_head_dense1<kHeadRows>, grid, dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1);
+    hipLaunchKernelGGL(k_mars_head_dense2, dim3((n_rows * NOUT + 3) / 4), dim3(256), 0, stream, hidden, w2, bias2, kp, N1, NOUT, n_rows);
+    return 0;
+}
+
 }  // namespace mmw

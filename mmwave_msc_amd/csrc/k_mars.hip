@@ -30,6 +30,12 @@ __device__ __forceinline__ int padded_origin(int pos)  // position (d,h,w) -> in
 }
 
 constexpr float kSplitScale = 2048.0f;  // 2^11 (see k_mars_conv16 below)
+// SPLIT = workgroups per sample.  1: a workgroup takes whole samples, one after the other (the throughput form: thousands of
+// samples).  3: the form for a handful of samples (one scene's tracks, MarsCNN.forward_small) -- there the launch is ONE
+// sample's latency, 18 us of which are the 216 x 3 conv2 matrix instructions a wave issues for its three position tiles:
+// three workgroups share a sample, each computes conv1 for the whole volume (0.83 of 6.1 MFLOP, redundantly) and ONE conv2
+// tile per wave.
+template <int SPLIT>
 __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ feat, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2,
                                                        const float *__restrict__ b2, float *__restrict__ out, int B)
@@ -58,12 +64,15 @@ __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ 
     }
     const float bias1 = b1[lane & 15], bias2 = b2[lane & 31];
     // conv2 A operand: lane l reads channel (2*ks)%16 + (l>>5) at position (tile*32 + (l&31)) shifted by the tap
-    int a2base[3];
+    constexpr int TPW = 3 / SPLIT;                        // conv2 tiles (32 positions) per wave
+    const int part = SPLIT == 1 ? 0 : blockIdx.x % SPLIT;   // which third of the sample's conv2 tiles
+    const int tile0 = SPLIT == 1 ? wave * 3 : part * 2 + wave;
+    int a2base[TPW];
 #pragma unroll
-    for (int t = 0; t < 3; t++) a2base[t] = (lane >> 5) * kPV + padded_origin((wave * 3 + t) * 32 + (lane & 31));
+    for (int t = 0; t < TPW; t++) a2base[t] = (lane >> 5) * kPV + padded_origin((tile0 + t) * 32 + (lane & 31));
     __syncthreads();
 
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int b = SPLIT == 1 ? blockIdx.x : blockIdx.x / SPLIT; b < B; b += SPLIT == 1 ? gridDim.x : B) {
         // ---- input sample (channels-last [192][5]) into the padded volume ----
         const float *x = feat + (size_t)b * 960;
         for (int e = tid; e < 960; e += 128) {
@@ -92,16 +101,17 @@ __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ 
         }
         __syncthreads();
         // ---- conv2 + bias + relu -> out[b][pos][oc] : 6 tiles of 32 positions, 3 per wave ----
-        f32x16 c0, c1, c2;
+        f32x16 cc[TPW];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { c0[r] = 0.f; c1[r] = 0.f; c2[r] = 0.f; }
+        for (int t = 0; t < TPW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) cc[t][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < kK2; ks++) {
             const int tap = (2 * ks) / 16, ic0 = (2 * ks) % 16;
             const int koff = ic0 * kPV + (tap / 9) * 100 + ((tap / 3) % 3) * 10 + (tap % 3);  // compile-time constant
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1[a2base[0] + koff], w2r[ks], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1[a2base[1] + koff], w2r[ks], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1[a2base[2] + koff], w2r[ks], c2, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TPW; t++) cc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(H1[a2base[t] + koff], w2r[ks], cc[t], 0, 0, 0);
         }
         // C/D: col = lane&31 (out channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         float *o = out + (size_t)b * 192 * 32;
@@ -109,10 +119,11 @@ __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ 
         for (int r = 0; r < 16; r++) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int oc = lane & 31;
-            float v0 = c0[r] + bias2, v1 = c1[r] + bias2, v2 = c2[r] + bias2;
-            o[((wave * 3 + 0) * 32 + row) * 32 + oc] = v0 > 0.f ? v0 : 0.f;
-            o[((wave * 3 + 1) * 32 + row) * 32 + oc] = v1 > 0.f ? v1 : 0.f;
-            o[((wave * 3 + 2) * 32 + row) * 32 + oc] = v2 > 0.f ? v2 : 0.f;
+#pragma unroll
+            for (int t = 0; t < TPW; t++) {
+                const float v = cc[t][r] + bias2;
+                o[((tile0 + t) * 32 + row) * 32 + oc] = v > 0.f ? v : 0.f;
+            }
         }
         __syncthreads();  // both waves are done reading Xp / H1 before the next sample overwrites them
     }
@@ -122,8 +133,12 @@ void launch_mars_conv(const float *feat, const float *w1, const float *b1, const
                       hipStream_t stream)
 {
     if (B <= 0) return;
+    if (B <= 64) {   // a handful of samples: three workgroups per sample (one conv2 tile per wave), the launch is one sample's latency
+        hipLaunchKernelGGL(k_mars_conv<3>, dim3(B * 3), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
+        return;
+    }
     const int grid = B < 512 ? B : 512;  // 2 workgroups per CU, persistent over samples
-    hipLaunchKernelGGL(k_mars_conv, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
+    hipLaunchKernelGGL(k_mars_conv<1>, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
 }
 // ================================================================================================================
 // k_mars_conv16 -- the same two layers on the fp16 matrix cores, fp32-exact by operand splitting (the scheme of

@@ -60,6 +60,8 @@ void launch_mars_conv(const float *feat, const float *w1, const float *b1, const
                       hipStream_t stream);
 int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
                        hipStream_t stream);
+int launch_mars_head_small(const float *act, long long lda, const float *w1, long long ldw, const float *bias1, const float *w2, const float *bias2,
+                           float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream);
 void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
                         int B, int32_t *range_flag, hipStream_t stream);
 }  // namespace mmw
@@ -96,9 +98,14 @@ struct mmw_ctx {
     int32_t *d_db_list = nullptr, *d_db_count = nullptr, *d_q = nullptr;
     int step_parity = 0;
     int ring_frames_bound = 0;   // no scene's global ring holds more frames than this (host-side knowledge: steps since the last reset)
-    // host-convenience staging (lazy)
-    double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;
-    int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr;
+    // host-convenience staging (lazy): one device block in [rows | dt | n], one out [assoc | db_n | n_out | labels], their pinned
+    // host mirrors, and pinned copies of the scene headers and the queue words -- mmw_frame_host moves each with ONE copy
+    char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    double *d_raw = nullptr;          // [S][max_pts][5] raw rows of the fused normalise + track form
+    SceneHdr *h_hdr = nullptr;        // pinned [S]
+    int32_t *h_q = nullptr;           // pinned [kQWords]
+    double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;      // (views into d_in / d_out)
+    int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr, *d_nout = nullptr;
     mmw_track_record *d_export = nullptr; int export_cap = 0;
     // profiling
     unsigned prof_mask = 0;           // bit k: time kernel id k (mmw_profile_enable)
@@ -447,9 +454,11 @@ int mmw_destroy(mmw_ctx *c)
     if (c->side_stream) hipStreamSynchronize(c->side_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_pts, c->d_n,
-                    c->d_dt, c->d_assoc, c->d_labels, c->d_dbn, c->d_export, c->st.huge_scratch};
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_in, c->d_out, c->d_raw,
+                    c->d_export, c->st.huge_scratch};
     for (void *p : ptrs) if (p) hipFree(p);
+    void *pinned[] = {c->h_in, c->h_out, c->h_hdr, c->h_q};
+    for (void *p : pinned) if (p) hipHostFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
     if (c->h_rows) hipHostFree(c->h_rows);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
@@ -697,36 +706,110 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
     return MMW_OK;
 }
 
+// layout of the two staging blocks (bytes; every part 16-byte aligned)
+struct StageLayout { size_t in_rows, in_dt, in_n, in_bytes, out_assoc, out_dbn, out_nout, out_labels, out_bytes; };
+static StageLayout stage_layout(const mmw_ctx *c)
+{
+    const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    StageLayout L;
+    L.in_rows = 0;
+    L.in_dt = al(S * NP * 8 * sizeof(double));
+    L.in_n = L.in_dt + al(S * sizeof(double));
+    L.in_bytes = L.in_n + al(S * sizeof(int32_t));
+    L.out_assoc = 0;
+    L.out_dbn = al(S * NP * sizeof(int32_t));
+    L.out_nout = L.out_dbn + al(S * sizeof(int32_t));
+    L.out_labels = L.out_nout + al(S * sizeof(int32_t));
+    L.out_bytes = L.out_labels + al(S * (size_t)c->UM * sizeof(int32_t));
+    return L;
+}
+
 static int ensure_host_staging(mmw_ctx *c)
 {
-    if (c->d_pts) return MMW_OK;
+    if (c->d_in) return MMW_OK;
+    const StageLayout L = stage_layout(c);
     const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
-    HIPCHK(c, hipMalloc((void **)&c->d_pts, S * NP * 8 * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&c->d_n, S * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->d_dt, S * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&c->d_assoc, S * NP * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->d_labels, S * (size_t)c->UM * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->d_dbn, S * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_in, L.in_bytes));
+    HIPCHK(c, hipMalloc((void **)&c->d_out, L.out_bytes));
+    HIPCHK(c, hipMalloc((void **)&c->d_raw, S * NP * 5 * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_in, L.in_bytes, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_out, L.out_bytes, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_hdr, S * sizeof(SceneHdr), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_q, kQWords * sizeof(int32_t), hipHostMallocDefault));
+    c->d_pts = reinterpret_cast<double *>(c->d_in + L.in_rows);
+    c->d_dt = reinterpret_cast<double *>(c->d_in + L.in_dt);
+    c->d_n = reinterpret_cast<int32_t *>(c->d_in + L.in_n);
+    c->d_assoc = reinterpret_cast<int32_t *>(c->d_out + L.out_assoc);
+    c->d_dbn = reinterpret_cast<int32_t *>(c->d_out + L.out_dbn);
+    c->d_nout = reinterpret_cast<int32_t *>(c->d_out + L.out_nout);
+    c->d_labels = reinterpret_cast<int32_t *>(c->d_out + L.out_labels);
     return MMW_OK;
+}
+
+static int first_scene_error(mmw_ctx *c, const SceneHdr *h, size_t n, const int32_t *q);
+
+// One frame of every scene from host memory in ONE round trip: the inputs leave as one copy from a pinned block, the kernels
+// follow, the results, the scene headers (track counts, error bits) and the queue words come back as three copies into pinned
+// memory, and the stream is waited for once.  (mmw_step_host used to wait four times: the step, mmw_check's two read-backs.)
+int mmw_frame_host(mmw_ctx *c, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out, int32_t *n_out,
+                   int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks)
+{
+    if (!c || !n || !dt || (!raw && !pts) || (raw && pts)) return fail(c, MMW_E_ARG, "mmw_frame_host: exactly one of raw / pts, and n, dt");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_host_staging(c);
+    if (rc) return rc;
+    const StageLayout L = stage_layout(c);
+    const size_t S = c->dc.n_scenes, NP = c->dc.max_pts, UM = (size_t)c->UM;
+    // rows: only the scenes' valid rows travel inside their slots (the slots are max_pts apart); small frames stay small
+    const size_t row_doubles = raw ? 5 : 8;
+    double *h_rows = reinterpret_cast<double *>(c->h_in + L.in_rows);
+    size_t rows_span = 0;   // bytes of the row area that must be sent: up to the end of the last scene's valid rows
+    for (size_t s = 0; s < S; s++) {
+        const int cnt = n[s];
+        if (cnt > 0 && (size_t)cnt <= NP) {
+            memcpy(h_rows + s * NP * row_doubles, (raw ? raw : pts) + s * NP * row_doubles, (size_t)cnt * row_doubles * sizeof(double));
+            rows_span = (s * NP + (size_t)cnt) * row_doubles * sizeof(double);
+        }
+    }
+    memcpy(c->h_in + L.in_dt, dt, S * sizeof(double));
+    memcpy(c->h_in + L.in_n, n, S * sizeof(int32_t));
+    if (raw) {
+        if (rows_span) HIPCHK(c, hipMemcpyAsync(c->d_raw, h_rows, rows_span, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_in + L.in_dt, c->h_in + L.in_dt, L.in_bytes - L.in_dt, hipMemcpyHostToDevice, c->stream));
+        rc = mmw_normalize(c, c->d_raw, c->d_n, c->d_pts, c->d_nout);
+        if (rc) return rc;
+        rc = mmw_step(c, c->d_pts, c->d_nout, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
+    } else {
+        if (rows_span) HIPCHK(c, hipMemcpyAsync(c->d_in, c->h_in, rows_span, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_in + L.in_dt, c->h_in + L.in_dt, L.in_bytes - L.in_dt, hipMemcpyHostToDevice, c->stream));
+        rc = mmw_step(c, c->d_pts, c->d_n, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
+    }
+    if (rc) return rc;
+    // results: [assoc | db_n | n_out] always, the labels when asked for; headers and queue words for the error check
+    const size_t head = db_labels ? L.out_bytes : L.out_labels;
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, head, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->st.hdr, S * sizeof(SceneHdr), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_q, c->d_q, kQWords * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    double *h_pts_out = nullptr;
+    if (raw && pts_out) {   // normalize_data's rows (the reference's `effective_data`): into the pinned row area, now free again
+        h_pts_out = reinterpret_cast<double *>(c->h_in + L.in_rows);
+        HIPCHK(c, hipMemcpyAsync(h_pts_out, c->d_pts, S * NP * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (assoc) memcpy(assoc, c->h_out + L.out_assoc, S * NP * sizeof(int32_t));
+    if (db_n) memcpy(db_n, c->h_out + L.out_dbn, S * sizeof(int32_t));
+    if (n_out) memcpy(n_out, raw ? c->h_out + L.out_nout : c->h_in + L.in_n, S * sizeof(int32_t));
+    if (db_labels) memcpy(db_labels, c->h_out + L.out_labels, S * UM * sizeof(int32_t));
+    if (h_pts_out) memcpy(pts_out, h_pts_out, S * NP * 8 * sizeof(double));
+    if (n_tracks) for (size_t s = 0; s < S; s++) n_tracks[s] = c->h_hdr[s].n_tracks;
+    return first_scene_error(c, c->h_hdr, S, c->h_q);
 }
 
 int mmw_step_host(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
 {
     if (!c || !pts || !n_pts || !dt) return fail(c, MMW_E_ARG, "mmw_step_host: null input pointer");
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_host_staging(c);
-    if (rc) return rc;
-    const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
-    HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, S * NP * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_n, n_pts, S * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_dt, dt, S * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = mmw_step(c, c->d_pts, c->d_n, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
-    if (rc) return rc;
-    if (assoc) HIPCHK(c, hipMemcpyAsync(assoc, c->d_assoc, S * NP * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (db_labels) HIPCHK(c, hipMemcpyAsync(db_labels, c->d_labels, S * (size_t)c->UM * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (db_n) HIPCHK(c, hipMemcpyAsync(db_n, c->d_dbn, S * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return mmw_check(c);
+    return mmw_frame_host(c, nullptr, pts, n_pts, dt, nullptr, nullptr, assoc, db_labels, db_n, nullptr);
 }
 
 int mmw_dbscan(mmw_ctx *c, const double *pts, const int32_t *n, int32_t max_n, double eps, int32_t min_samples, int32_t *labels, int32_t *n_clusters)
@@ -810,13 +893,10 @@ static int read_headers(mmw_ctx *c, std::vector<SceneHdr> &h)
     return MMW_OK;
 }
 
-int mmw_check(mmw_ctx *c)
+// the first per-scene error of a header read-back (as mmw_check reports it), or a chain worker's give-up
+static int first_scene_error(mmw_ctx *c, const SceneHdr *h, size_t n, const int32_t *q)
 {
-    if (!c) return MMW_E_ARG;
-    std::vector<SceneHdr> h;
-    int rc = read_headers(c, h);
-    if (rc) return rc;
-    for (size_t s = 0; s < h.size(); s++) {
+    for (size_t s = 0; s < n; s++) {
         const int e = h[s].err;
         if (!e) continue;
         if (e & ERR_BADCOUNT) return fail(c, MMW_E_ARG, "scene %zu: n_pts outside [0, max_pts=%d]", s, c->dc.max_pts);
@@ -826,11 +906,20 @@ int mmw_check(mmw_ctx *c)
         if (e & ERR_DIVZERO) return fail(c, MMW_E_DIVZERO, "scene %zu: (N_est-1)*N == 0 in _get_Rc / N_est == 0", s);
         if (e & ERR_SINGULAR) return fail(c, MMW_E_SINGULAR, "scene %zu: singular 6x6 gate/innovation matrix", s);
     }
-    int32_t q[16];
-    HIPCHK(c, hipMemcpyAsync(q, c->d_q, sizeof(q), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (q[kQTimeout] != 0) return fail(c, MMW_E_HIP, "a DBSCAN chain worker gave up waiting (%d time(s)): device hung or oversubscribed", q[kQTimeout]);
     return MMW_OK;
+}
+
+int mmw_check(mmw_ctx *c)
+{
+    if (!c) return MMW_E_ARG;
+    std::vector<SceneHdr> h;
+    int rc = read_headers(c, h);
+    if (rc) return rc;
+    int32_t q[kQWords];
+    HIPCHK(c, hipMemcpyAsync(q, c->d_q, sizeof(q), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return first_scene_error(c, h.data(), h.size(), q);
 }
 
 int mmw_get_num_tracks(mmw_ctx *c, int32_t *n_tracks)
@@ -979,6 +1068,19 @@ int mmw_mars_dense1_split(void *hip_stream, const void *a2, int64_t lda, const v
         return fail(nullptr, MMW_E_HIP, "mmw_mars_dense1_split: hipFuncSetAttribute failed");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_dense1_split launch -> %s", hipGetErrorString(e));
+    return MMW_OK;
+}
+
+int mmw_mars_head_small(void *hip_stream, const float *act, int64_t lda, const float *w1, int64_t ldw, const float *bias1, const float *w2,
+                        const float *bias2, float *hidden, float *kp, int32_t n_rows, int32_t k, int32_t n1)
+{
+    if (n_rows < 0 || n_rows > 64 || k < 4 || (k & 3) != 0 || n1 < 1 || lda < k || ldw < k || ((lda | ldw) & 3) != 0 ||
+        (n_rows > 0 && (!act || !w1 || !bias1 || !w2 || !bias2 || !hidden || !kp)) || (((uintptr_t)act | (uintptr_t)w1) & 15) != 0)
+        return fail(nullptr, MMW_E_ARG, "mmw_mars_head_small: n_rows in [0, 64], k a multiple of 4, 16-byte aligned fp32 operands with leading dimensions >= k that are multiples of 4");
+    if (n_rows == 0) return MMW_OK;
+    launch_mars_head_small(act, lda, w1, ldw, bias1, w2, bias2, hidden, kp, n_rows, k, n1, MMW_NKP, (hipStream_t)hip_stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_head_small launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 

@@ -234,6 +234,32 @@ class MarsCNN(nn.Module):
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return h[:B]
 
+    SMALL_BATCH = 64   # mmw_mars_head_small's limit
+
+    def has_small_path(self) -> bool:
+        return self.use_hip_conv_f32
+
+    def forward_small(self, x: torch.Tensor) -> torch.Tensor:
+        """A handful of samples (one scene's tracks: the drop-in's estimate_posture): the fp32 conv kernel (mmw_mars_conv3d) and
+        the thin Dense-1 / Dense-2 kernels of mmw_mars_head_small -- Keras' own fp32 arithmetic, the weight matrix cut over the
+        whole chip instead of one band of tiles (~100 us less for 2 rows), no fp16 range to watch.  3-frame model, B <= 64."""
+        from . import _lib
+        if not (x.is_cuda and x.dtype == torch.float32 and self.use_hip_conv_f32 and x.shape[0] <= self.SMALL_BATCH):
+            raise ValueError("MarsCNN.forward_small: a CUDA fp32 batch of at most 64 samples of the 3-frame model")
+        L = _lib.load()
+        with torch.cuda.device(x.device):
+            act = self._hip_convs(x)
+            B = act.shape[0]
+            w1 = self.dense1_dhwc.weight
+            hidden = torch.empty((B, w1.shape[0]), dtype=torch.float32, device=x.device)
+            kp = torch.empty((B, N_KEYPOINTS), dtype=torch.float32, device=x.device)
+            rc = L.mmw_mars_head_small(torch.cuda.current_stream(x.device).cuda_stream, act.data_ptr(), act.stride(0), w1.data_ptr(), w1.stride(0),
+                                       self.dense1_dhwc.bias.data_ptr(), self.dense2.weight.data_ptr(), self.dense2.bias.data_ptr(),
+                                       hidden.data_ptr(), kp.data_ptr(), B, w1.shape[1], w1.shape[0])
+            if rc != 0:
+                raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
+        return kp
+
     def range_overflow(self, clear: bool = True) -> bool:
         """True when a split-arithmetic forward since the last call met an input or activation outside fp16's range (that
         sample's keypoints are meaningless; the other samples are not affected).  Reads one device word: synchronises."""

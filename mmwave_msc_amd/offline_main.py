@@ -43,9 +43,10 @@ def offline_main(experiment_path: str, model=None, on_frame: Optional[Callable] 
         else:
             trackbuffer.dt = det["posix"][0] / 1000 - trackbuffer.t
         trackbuffer.t = det["posix"][0] / 1000
-        effective_data = normalize_data(det)
-        if effective_data.shape[0] != 0:
-            trackbuffer.track(effective_data, batch)
+        # (the reference: effective_data = normalize_data(det); if effective_data.shape[0] != 0: trackbuffer.track(effective_data,
+        #  batch) -- offline_main.py:53-57.  Both calls exist here too (utils.normalize_data, TrackBuffer.track); the loop uses
+        #  their fused form, one round trip to the GPU per frame instead of two)
+        if trackbuffer.track_raw(det, batch) != 0:
             if model is not None:
                 trackbuffer.estimate_posture(model)
         if on_frame is not None:

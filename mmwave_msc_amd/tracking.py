@@ -145,6 +145,8 @@ class TrackBuffer:
         self._dx = const.MOTION_MODEL.KF_DIM[0]
         self.last_assoc = None       # _calc_dist_fun output of the last frame (-1 = None)
         self.last_db_labels = None   # apply_DBscan labels of the last frame, or None
+        self._n_tracks = 0           # len(effective_tracks) after the last frame (came back with the frame's results)
+        self._posture = None         # device buffers of estimate_posture's on-device path (a mars.MarsCNN on this GPU)
 
     def _ensure(self):
         if self._sb is None:
@@ -169,16 +171,51 @@ class TrackBuffer:
         pts = np.zeros((1, self._max_pts, 8))
         pts[0, :n] = pc
         # an empty cloud still IS a track() call (predict, ageing / expiry, _update_all, an empty ring frame): the C-ABI's
-        # count 0 means "frame skipped" (offline_main.py:56), MMW_EMPTY_FRAME means this
-        assoc, labels, dbn = sb.step_host(pts, np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]))
-        self.last_assoc = assoc[0, :n].copy()
-        self.last_db_labels = labels[0, : dbn[0]].copy() if dbn[0] >= 0 else None
+        # count 0 means "frame skipped" (offline_main.py:56), MMW_EMPTY_FRAME means this.  ONE round trip (mmw_frame_host).
+        r = sb.frame_host(np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]), pts=pts)
+        self._take(r, n)
+
+    def _take(self, r, n):
+        dbn = int(r["db_n"][0])
+        self.last_assoc = r["assoc"][0, :n].copy()
+        self.last_db_labels = r["labels"][0, :dbn].copy() if dbn >= 0 else None
+        self._n_tracks = int(r["n_tracks"][0])
         self._tracks_cache = None
+
+    def track_raw(self, detObj, batch: BatchedData, want_rows: bool = False):
+        """`effective_data = normalize_data(detObj)` + `track(effective_data, batch)` (offline_main.py:53-57) as ONE round trip to
+        the GPU: the raw rows go up, Utils.normalize_data and TrackBuffer.track run back to back on the device, the results come
+        down.  A frame none of whose rows pass the scene filter is skipped, as the reference's loop does.  Returns the number
+        of rows that reached track() -- or (rows, effective_data) with want_rows."""
+        sb = self._ensure()
+        if self._batch is None:
+            self._batch = batch
+            batch._bind(self)
+        elif batch is not self._batch:
+            raise ValueError("this TrackBuffer is bound to another BatchedData (one global ring per scene)")
+        raw = np.vstack((detObj["x"], detObj["y"], detObj["z"], detObj["doppler"], detObj["peakVal"])).T.astype(np.float64)
+        m = raw.shape[0]
+        if m > self._max_pts:
+            raise ValueError(f"frame has {m} points; TrackBuffer(max_pts={self._max_pts})")
+        buf = np.zeros((1, self._max_pts, 5))
+        buf[0, :m] = raw
+        r = sb.frame_host(np.array([m], np.int32), np.array([float(self.dt)]), raw=buf, want_rows=want_rows)
+        n = int(r["n_out"][0])
+        if n > 0:
+            self._take(r, n)
+        return (n, r["rows"][0, :n].copy()) if want_rows else n
 
     def estimate_posture(self, model):
         """Tracking.py:705-734.  `model` is either a `mars.MarsCNN` (runs on the GPU) or any
         object with a Keras-style `.predict(ndarray[B,3,8,8,5]) -> ndarray[B,57]`."""
         sb = self._ensure()
+        if self._n_tracks == 0 and self.last_assoc is not None:
+            return   # no track after the last frame: nothing to estimate (known from the frame's own results, no round trip)
+        if getattr(model, "use_hip_conv", False) and hasattr(model, "range_overflow"):
+            import torch
+            p0 = next(model.parameters(), None)
+            if p0 is not None and p0.is_cuda and p0.device.index == self._device:
+                return self._estimate_posture_on_device(model, torch)
         feat, owner = sb.features_host()
         if len(owner) == 0:
             return
@@ -187,6 +224,40 @@ class TrackBuffer:
         else:
             kp = np.asarray(model.predict(feat), dtype=np.float32)
         sb.set_keypoints_host(kp, owner)
+        self._tracks_cache = None
+
+    def _estimate_posture_on_device(self, model, torch):
+        """A mars.MarsCNN on this GPU: the feature tensors, the CNN and the keypoint scatter stay on the device (the tracker
+        runs on the model's torch stream); the host waits once for the row count -- the exact batch size of the matrix
+        kernels.  A handful of tracks (always, for one scene) run MarsCNN.forward_small -- Keras' fp32 arithmetic on thin kernels;
+        a larger batch the split-fp16 kernels, with one more wait for their range word (Keras' fp32 has no such limit: a batch
+        that left fp16's range is computed again in fp32, as predict() does)."""
+        sb = self._sb
+        dev = torch.device("cuda", self._device)
+        if self._posture is None:
+            cap = sb.track_cap
+            shape = (cap, sb.ring, 8, 8, 5) if sb.ring > 1 else (cap, 8, 8, 5)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                self._posture = dict(stream=st, feat=torch.zeros(shape, dtype=torch.float32, device=dev),
+                                     owner=torch.zeros((cap, 2), dtype=torch.int32, device=dev))
+            st.synchronize()
+            sb.follow_torch_stream(st)
+        P = self._posture
+        with torch.cuda.stream(P["stream"]), torch.no_grad():
+            n = sb.features_dev(P["feat"].data_ptr(), P["owner"].data_ptr(), P["feat"].shape[0])
+            if n == 0:
+                return
+            if n <= model.SMALL_BATCH and model.has_small_path():
+                kp = model.forward_small(P["feat"][:n])          # Keras' fp32 arithmetic on thin kernels: no range word, no wait
+            else:
+                kp = model(P["feat"][:n])
+                if model.arith == "f16x3" and model.range_overflow():
+                    model.range_fallbacks += 1
+                    kp = model(P["feat"][:n], arith=model.fp32_arith())
+                kp = kp.float().contiguous()
+            sb.set_keypoints_dev(kp.data_ptr(), P["owner"].data_ptr(), n)
+            P["kp"] = kp   # (alive until the scatter has run: the next call on this stream replaces it)
         self._tracks_cache = None
 
     @property

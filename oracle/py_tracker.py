@@ -26,6 +26,10 @@ from sklearn.cluster import DBSCAN
 class Params:
     """constants.py values used by the tracker (defaults = constants.py)."""
 
+    S_HEIGHT, S_TILT = 1.8, -5                      # constants.py:41-42
+    INTENSITY_MU, INTENSITY_STD = 27.0187, 70.351   # constants.py:108-109
+    MODEL_MIN_INPUT = 0                             # constants.py:111
+
     def __init__(self, **kw):
         self.FB_FRAMES_BATCH = 2
         self.DB_Z_WEIGHT, self.DB_RANGE_WEIGHT, self.DB_EPS, self.DB_MIN_SAMPLES_MIN = 0.4, 0.03, 0.3, 35
@@ -235,6 +239,59 @@ class PyScene:
         return len(self.tracks)
 
 
+def py_normalize(p: Params, det) -> np.ndarray:
+    """Utils.normalize_data + point_transform_to_standard_axis (Utils.py:294-434) with the reference's computational shape: a
+    Python loop over the points, two 4 x 4 products per vector, rows appended one at a time.  det: dict of equal-length
+    sequences x, y, z, doppler, peakVal.  Returns (N', 8) float64."""
+    rows = np.vstack((det["x"], det["y"], det["z"], det["doppler"], det["peakVal"])).T
+    shift = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, p.S_HEIGHT], [0, 0, 0, 1]])
+    a = np.radians(p.S_TILT)
+    rot = np.array([[1, 0, 0, 0], [0, np.cos(a), -np.sin(a), 0], [0, np.sin(a), np.cos(a), 0], [0, 0, 0, 1]])
+    out = np.empty((0, 8), dtype="float")
+    for k in range(len(rows)):
+        x, y, z, dop, peak = rows[k]
+        r = math.sqrt(x ** 2 + y ** 2 + z ** 2)
+        vel = (0, dop, 0) if r == 0 else (dop * x / r, dop * y / r, dop * z / r)
+        pos_t = np.dot(shift, np.dot(rot, np.array([x, y, z, 1])))
+        vel_t = np.dot(shift, np.dot(rot, np.array([vel[0], vel[1], vel[2], 0])))
+        row = np.append(np.array([pos_t[0], pos_t[1], pos_t[2], vel_t[0], vel_t[1], vel_t[2]]), (dop, peak))
+        if row[2] <= 2.5 and row[2] > 0 and row[1] > 0:
+            out = np.append(out, [row], axis=0)
+    return out
+
+
+def py_feature_maps(p: Params, sc: "PyScene"):
+    """The feature side of TrackBuffer.estimate_posture (Tracking.py:718-730): relative_coordinates + format_single_frame
+    (Utils.py:437-520) per eligible track, in the reference's shape -- a Python loop over the points for the shift, per frame
+    column pick, intensity normalisation, pad / cut to 64 rows, argsort by x.  Returns (maps[B, ring, 8, 8, 5] float64, owners)."""
+    ring = p.FB_FRAMES_BATCH + 1
+    maps, owners = [], []
+    for j, t in enumerate(sc.tracks):
+        if len(t.batch.effective_data) <= p.MODEL_MIN_INPUT:
+            continue
+        ref = [t.centroid[0], t.centroid[1], 0, 0, 0, 0, 0, 0]
+        grid = np.zeros((ring, 64, 5))
+        for k, frame in enumerate(t.batch.buffer):
+            rel = np.array([pt - ref for pt in frame])
+            sel = rel[:, [0, 1, 2, -2, -1]]
+            sel[:, 4] = (sel[:, 4] - p.INTENSITY_MU) / p.INTENSITY_STD
+            sel = np.concatenate((sel, np.zeros((64 - len(sel), 5))), axis=0) if len(sel) < 64 else sel[:64]
+            grid[k] = sel[np.argsort(sel[:, 0])]
+        maps.append(grid.reshape((64, 5)).reshape((8, 8, 5)) if ring == 1 else grid.reshape((ring, 8, 8, 5)))
+        owners.append(j)
+    return np.array(maps), owners
+
+
+def py_estimate_posture(p: Params, sc: "PyScene", model):
+    """TrackBuffer.estimate_posture (Tracking.py:705-734): `model` is anything with a Keras-style .predict."""
+    maps, owners = py_feature_maps(p, sc)
+    if len(maps) > 0:
+        kp = model.predict(maps)
+        for i, j in enumerate(owners):
+            sc.tracks[j].keypoints = kp[i]
+    return len(owners)
+
+
 def _worker(args):
     params_kw, frames, counts, dts = args
     out = []
@@ -268,7 +325,7 @@ def run_batch_multiprocess(params_kw, pts, cnt, dts, procs):
     return el, [x for r in res for x in r]
 
 
-def _window_proc(idx, q, params_kw, frames, counts, dts, warm, barrier):
+def _window_proc(idx, q, params_kw, frames, counts, dts, warm, barrier, posture_weights=None):
     import time
     try:  # one BLAS thread per process: the processes ARE the parallelism (numpy is already imported in the parent)
         from threadpoolctl import threadpool_limits
@@ -276,31 +333,42 @@ def _window_proc(idx, q, params_kw, frames, counts, dts, warm, barrier):
     except Exception:
         pass
     scenes = [PyScene(Params(**params_kw)) for _ in range(frames.shape[1])]
+    model = None
+    if posture_weights is not None:   # estimate_posture after every track() (offline_main.py:57-60): Keras' fp32 on this core
+        import torch
+        from .mars_torch import MarsTorchCPU
+        model = MarsTorchCPU(posture_weights, torch.float32, threads=1)
+    rows = 0
 
     def run(f0, f1):
+        nonlocal rows
         for s, sc in enumerate(scenes):
             for f in range(f0, f1):
                 c = int(counts[f, s])
                 if c:
                     sc.track(frames[f, s, :c].astype(np.float64), float(dts[f, s]))
+                    if model is not None:
+                        rows += py_estimate_posture(sc.p, sc, model)
 
     try:
         run(0, warm)
         barrier.wait()
+        rows = 0
         t0 = time.perf_counter()
         run(warm, frames.shape[0])
         t1 = time.perf_counter()
-        q.put((idx, t0, t1, [sc.n_tracks for sc in scenes]))
+        q.put((idx, t0, t1, [sc.n_tracks for sc in scenes], rows))
     except BaseException as exc:  # a dead worker must not leave the others at the barrier
         barrier.abort()
-        q.put((idx, None, None, repr(exc)))
+        q.put((idx, None, None, repr(exc), 0))
 
 
-def run_window_multiprocess(params_kw, pts, cnt, dts, procs, warm):
+def run_window_multiprocess(params_kw, pts, cnt, dts, procs, warm, posture_weights=None, want_rows=False):
     """The bench's CPU baseline: scenes sharded evenly over `procs` processes (started, and the first `warm`
     frames of every scene tracked, BEFORE the clock starts; a barrier lines the processes up), then frames
     warm.. timed.  Wall = last finish - first start on the shared monotonic clock.  pts[F,S,N,8].
-    Returns (wall seconds, final track counts by scene)."""
+    `posture_weights` (Keras-layout dict): estimate_posture after every track(), the CNN on torch's CPU operators.
+    Returns (wall seconds, final track counts by scene[, feature tensors pushed through the CNN in the window])."""
     import multiprocessing as mp
 
     S = pts.shape[1]
@@ -309,7 +377,7 @@ def run_window_multiprocess(params_kw, pts, cnt, dts, procs, warm):
     ctx = mp.get_context("fork")
     barrier = ctx.Barrier(len(shards))
     q = ctx.Queue()
-    ps = [ctx.Process(target=_window_proc, args=(i, q, params_kw, pts[:, sh], cnt[:, sh], dts[:, sh], int(warm), barrier))
+    ps = [ctx.Process(target=_window_proc, args=(i, q, params_kw, pts[:, sh], cnt[:, sh], dts[:, sh], int(warm), barrier, posture_weights))
           for i, sh in enumerate(shards)]
     for p in ps:
         p.start()
@@ -321,4 +389,5 @@ def run_window_multiprocess(params_kw, pts, cnt, dts, procs, warm):
         raise RuntimeError(f"cpu baseline worker failed: {bad[0][3]}")
     res.sort(key=lambda r: r[0])
     wall = max(r[2] for r in res) - min(r[1] for r in res)
-    return wall, [x for r in res for x in r[3]]
+    counts = [x for r in res for x in r[3]]
+    return (wall, counts, sum(r[4] for r in res)) if want_rows else (wall, counts)

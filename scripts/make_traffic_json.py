@@ -22,7 +22,7 @@ def table(path):
 big, small = sys.argv[1], sys.argv[2]
 res = {"4096x512x8": table(big), "512x512x8": table(small),
        "source": f"{big} / {small}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --no-cpu --no-e2e --no-e2e-parity "
-                 f"--no-cold --no-shards --no-full --no-ingest --steps 10 --warmup 10 (--chain-side-stream 2 at 4096 scenes, --scenes 512 for the shard)",
+                 f"--no-cold --no-shards --no-full --no-ingest --no-single --steps 10 --warmup 10 (--chain-side-stream 2 at 4096 scenes, --scenes 512 for the shard)",
        "_note": "KiB -> bytes; read side given raw and x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads: MI355X_MICROARCH.md). "
                 "Counter collection serialises the dispatches: with --chain-side-stream 2 the chain workers are launched all the same (k_chain has its "
                 "entry) but, alone on the chip, find nothing to claim and leave after their idle polls -- the DBSCAN bytes they move in the benchmarked "

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from tests._golden import GOLDEN, assert_feat_equal, close64, load_scenario
+from tests._golden import assert_tracks_match, GOLDEN, assert_feat_equal, close64, load_scenario
 
 pytestmark = pytest.mark.gpu
 KP_TOL = 1e-4
@@ -127,6 +127,102 @@ def test_estimate_posture_end_to_end():
         for i, j in enumerate(owner):
             assert np.abs(tracks[j].keypoints - ref[i]).max() <= KP_TOL
     tb.close()
+
+
+def test_frame_host_one_round_trip_equals_the_separate_calls():
+    """mmw_frame_host (normalize_data + track in one round trip; include/mmw.h) for a batch of scenes against mmw_normalize
+    followed by mmw_step_host, and against the oracle: rows, counts, association, labels, track counts and state bit-equal;
+    scenes whose rows are all filtered out are skipped (offline_main.py:56), errors come back with the same call."""
+    import bench_ingest
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    S, N, F, T = 12, 160, 10, 3
+    pts = np.zeros((F, S, N, 8), np.float32); cnt = np.zeros((F, S), np.int32); dts = np.zeros((F, S))
+    for s in range(S):
+        p, c, d = make_batch([7300 + s], F, N, s % (T + 1), ragged=(s % 2 == 1))
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    cfg = _lib.default_config(tr_max_tracks=T)
+    raw = bench_ingest.raw_rows_from_normalised(pts, float(cfg.tilt_cos), float(cfg.tilt_sin), float(cfg.s_height)).astype(np.float64)
+    raw[2, 4, :, 2] = 9.0                               # frame 2 of scene 4: every row above the scene filter -> the frame is skipped
+    cnt[5, 7] = 0
+    a, b = SceneBatch(cfg, S, N), SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
+    ocfg = co.default_config(tr_max_tracks=T)
+    scenes = [co.OracleScene(ocfg, N) for _ in range(S)]
+    for f in range(F):
+        r = a.frame_host(cnt[f], dts[f], raw=raw[f], want_rows=True)
+        rows, n_out = b.normalize_host(raw[f], cnt[f])
+        assoc, labels, dbn = b.step_host(rows, n_out, dts[f])
+        assert np.array_equal(r["n_out"], n_out) and np.array_equal(r["db_n"], dbn), f
+        assert np.array_equal(r["n_tracks"], b.num_tracks()), f
+        for s in range(S):
+            k = int(n_out[s])
+            assert np.array_equal(r["rows"][s, :k], rows[s, :k]), (f, s)
+            assert np.array_equal(r["assoc"][s, :k], assoc[s, :k]), (f, s)
+            if dbn[s] > 0:
+                assert np.array_equal(r["labels"][s, : dbn[s]], labels[s, : dbn[s]]), (f, s)
+            o_rows = co.normalize(ocfg, raw[f, s, : max(int(cnt[f, s]), 0)])
+            assert len(o_rows) == k
+            if k:
+                oa, ol = scenes[s].track(o_rows, float(dts[f, s]))
+                assert np.array_equal(r["assoc"][s, :k], oa), (f, s)
+        if f == 2:
+            assert int(r["n_out"][4]) == 0 and int(r["db_n"][4]) == -1      # every row filtered out: the frame never reached track()
+    ntr = a.num_tracks(); trk = a.tracks(cap=max(int(ntr.max()), 1))
+    for s in range(S):
+        assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"scene {s}", exact=True)
+    # a loud error in the same call: a count the context was not sized for
+    bad = cnt[0].copy(); bad[3] = N + 1
+    with pytest.raises(_lib.MmwError) as ei:
+        a.frame_host(bad, dts[0], pts=pts[0].astype(np.float64))
+    assert ei.value.code == _lib.E_ARG and "scene 3" in str(ei.value)
+    a.close(); b.close()
+
+
+def test_offline_loop_fused_calls_and_on_device_posture():
+    """TrackBuffer.track_raw (normalize_data + track, one round trip) + estimate_posture with a MarsCNN on the GPU (features, CNN
+    and keypoint scatter stay on the device) against the separate reference-shaped calls -- utils.normalize_data, TrackBuffer.track,
+    estimate_posture through a Keras-style .predict object -- frame by frame: same rows, association, tracks, keypoints within
+    the CNN tolerance of the fp64 oracle."""
+    import bench_ingest
+    from mmwave_msc_amd import constants as const
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.synth import make_scene
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    from mmwave_msc_amd.utils import normalize_data
+    from oracle.mars_np import mars_forward_np
+    w = random_keras_weights(seed=8, frames=3)
+    model = MarsCNN.from_keras_weights(w).to("cuda:0")
+
+    class KerasLike:   # the reference's model object: .predict(ndarray) -> ndarray (Tracking.py:732), here the fp64 oracle CNN
+        def predict(self, x, verbose=0):
+            return mars_forward_np(w, np.asarray(x, dtype=np.float64)).astype(np.float32)
+
+    p, c, d = make_scene(77, 14, 220, 2, ragged=True)
+    ang = np.radians(const.S_TILT)
+    raw = bench_ingest.raw_rows_from_normalised(p, float(np.cos(ang)), float(np.sin(ang)), float(const.S_HEIGHT)).astype(np.float64)
+    fused, fb = TrackBuffer(max_pts=256), BatchedData()
+    plain, pb = TrackBuffer(max_pts=256), BatchedData()
+    for f in range(14):
+        n = int(c[f])
+        det = {k: list(raw[f, :n, i]) for i, k in enumerate(("x", "y", "z", "doppler", "peakVal"))}
+        fused.dt = plain.dt = float(d[f])
+        kept, rows = fused.track_raw(det, fb, want_rows=True)
+        eff = normalize_data(det)
+        assert kept == eff.shape[0] and np.array_equal(rows, eff), f
+        if eff.shape[0]:
+            plain.track(eff, pb)
+            assert np.array_equal(fused.last_assoc, plain.last_assoc), f
+        fused.estimate_posture(model)
+        plain.estimate_posture(KerasLike())
+        ta, tb_ = fused.effective_tracks, plain.effective_tracks
+        assert len(ta) == len(tb_), f
+        for x, y in zip(ta, tb_):
+            assert np.array_equal(x.state.x, y.state.x) and np.array_equal(x.state.P, y.state.P) and x.uid == y.uid, f
+            assert np.abs(x.keypoints - y.keypoints).max() <= KP_TOL * max(1.0, float(np.abs(y.keypoints).max())), f
+    assert len(fused.effective_tracks) >= 1
+    fused.close(); plain.close()
 
 
 def test_device_pointer_posture_path_is_ordered_with_torch():
