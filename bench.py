@@ -206,14 +206,25 @@ def dry_run(rank, world, lo, hi, S_total, scaling, slots):
     import torch.distributed as dist
 
     from mmwave_msc_amd._lib import SUMMARY_DTYPE
-    from mmwave_msc_amd.dist import all_gather_tables, summaries_to_tensor, tensor_to_summaries
+    from mmwave_msc_amd.dist import ShardedTracker, tensor_to_summaries
 
     if world > 1:
         dist.init_process_group(backend="gloo")
-    tab = np.zeros((hi - lo, slots), dtype=SUMMARY_DTYPE)
-    tab["scene"] = np.arange(lo, hi)[:, None]
-    tab["slot"] = np.arange(slots)[None, :]
-    glob = tensor_to_summaries(all_gather_tables(summaries_to_tensor(tab)), slots)
+
+    class TableOnly:   # stands in for the rank-local SceneBatch: a track table whose rows carry their global scene id
+        def __init__(self, cfg, n_local, max_pts, device):
+            self.S = n_local
+
+        def track_table_host(self, n_slots, scene_base=0):
+            tab = np.zeros((self.S, n_slots), dtype=SUMMARY_DTYPE)
+            tab["scene"] = (scene_base + np.arange(self.S))[:, None]
+            tab["slot"] = np.arange(n_slots)[None, :]
+            return tab
+
+    n_arg = S_total if scaling == "strong" else S_total // world
+    st = ShardedTracker(None, n_arg, 1, scaling=scaling, batch_factory=TableOnly)
+    assert (st.lo, st.hi, st.n_total) == (lo, hi, S_total), (st.lo, st.hi, st.n_total, lo, hi, S_total)
+    glob = tensor_to_summaries(st.gather_table(slots), slots)
     ok = glob.shape[0] == S_total and bool(np.array_equal(glob["scene"][:, 0], np.arange(S_total)))
     if world > 1:
         t = torch.tensor([1.0 if ok else 0.0])
@@ -251,6 +262,10 @@ def main():
                          "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
     ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
+    ap.add_argument("--rows", choices=("f32", "f64"), default="f32",
+                    help="how the resident frames are stored in HBM: f32 (default: 32 B per point, mmw_step_f32 promotes them to fp64 as they are "
+                         "loaded -- exact, the synthetic rows are fp32-representable; every output is bit-equal to the fp64 entry's) or f64 "
+                         "(64 B per point, mmw_step: what rounds 1-3 timed)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scene leg (configs[0]: the offline loop on one synthetic CSV experiment: bench_single.py)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host-fed legs (frames from pinned host memory every step: bench_ingest.py)")
     ap.add_argument("--fused-step", type=int, default=0, choices=(-1, 0, 1),
@@ -342,7 +357,7 @@ def main():
 
     from mmwave_msc_amd import _lib
     from mmwave_msc_amd.batch import SceneBatch
-    from mmwave_msc_amd.dist import all_gather_tables, SUMMARY_WORDS
+    from mmwave_msc_amd.dist import ShardedTracker
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
@@ -354,26 +369,40 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
     n_ranks_seen = dist.get_world_size() if world > 1 else 1
-    sb = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream, fused_step=args.fused_step),
-                    S, N, device=local_rank)
+    # this rank's share of the job: the product's own object (mmwave_msc_amd/dist.py) -- rank-local SceneBatch + the all-gather
+    shard = ShardedTracker(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream, fused_step=args.fused_step),
+                           args.scenes, N, scaling=scaling, device=local_rank, rank=rank, world=world)
+    assert (shard.lo, shard.hi, shard.n_total) == (lo, hi, S_total)
+    sb = shard.sb
     # one real stream for torch and the context: uploads, the CNN of the posture leg and the mmw_* calls on device
     # tensors are then ordered by the stream itself (torch's default stream would read as "context's own stream")
     side = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(side)
     sb.follow_torch_stream(side)
-    d_pts = torch.empty((F, S, N, 8), dtype=torch.float64, device=dev)
-    for f in range(F):
-        d_pts[f] = torch.from_numpy(pts[f]).to(dev).double()
+    rows32 = args.rows == "f32"
+    row_dtype = torch.float32 if rows32 else torch.float64
+
+    def resident(host_frames):
+        """the frames of a leg in HBM before its clock starts: as they are (fp32 rows) or promoted to fp64"""
+        d = torch.empty(host_frames.shape, dtype=row_dtype, device=dev)
+        for f_ in range(host_frames.shape[0]):
+            t_ = torch.from_numpy(host_frames[f_]).to(dev)
+            d[f_] = t_ if rows32 else t_.double()
+        return d
+
+    def stepper(ctx):
+        return ctx.step_dev_f32 if rows32 else ctx.step_dev
+
+    d_pts = resident(pts)
     d_cnt = torch.from_numpy(cnt).to(dev)
     d_dt = torch.from_numpy(dts).to(dev)
     d_assoc = torch.empty((S, N), dtype=torch.int32, device=dev)
     d_lab = torch.empty((S, sb.UM), dtype=torch.int32, device=dev)
     d_dbn = torch.empty((S,), dtype=torch.int32, device=dev)
     slots = args.tracks
-    d_table = torch.zeros((S * slots, SUMMARY_WORDS), dtype=torch.int32, device=dev)
 
     def step(f):
-        sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr(),
+        stepper(sb)(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr(),
                     d_assoc.data_ptr(), d_lab.data_ptr(), d_dbn.data_ptr())
 
     def barrier():
@@ -446,8 +475,7 @@ def main():
             sb.profile(False)
         step(f)
     sb.profile(True)
-    sb.track_table_dev(d_table.data_ptr(), slots, scene_base=lo)
-    gathered = all_gather_tables(d_table)
+    gathered = shard.gather_table(slots)
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
@@ -478,7 +506,7 @@ def main():
         a_, l_, b_ = d_assoc[:n_ctx], d_lab[:n_ctx], d_dbn[:n_ctx]
 
         def st_(f):
-            ctx.step_dev(p_dev[f][:n_ctx].data_ptr(), c_dev[f][:n_ctx].data_ptr(), t_dev[f][:n_ctx].data_ptr(),
+            stepper(ctx)(p_dev[f][:n_ctx].data_ptr(), c_dev[f][:n_ctx].data_ptr(), t_dev[f][:n_ctx].data_ptr(),
                          a_.data_ptr(), l_.data_ptr(), b_.data_ptr())
         for f in range(W):
             st_(f)
@@ -534,9 +562,7 @@ def main():
     full = None
     if full_host is not None:
         fp_, fc_, fd_ = full_host
-        d_fp = torch.empty((F, S, N, 8), dtype=torch.float64, device=dev)
-        for f in range(F):
-            d_fp[f] = torch.from_numpy(fp_[f]).to(dev).double()
+        d_fp = resident(fp_)
         d_fc, d_fd = torch.from_numpy(fc_).to(dev), torch.from_numpy(fd_).to(dev)
         ctx = SceneBatch(_lib.default_config(tr_max_tracks=args.tracks, chain_side_stream=args.chain_side_stream, fused_step=args.fused_step),
                          S, N, device=local_rank)
@@ -625,22 +651,26 @@ def main():
         dom = max(step_ms, key=step_ms.get)
         dom_ms, dom_bytes = step_ms[dom], step_bytes[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        # roofline.traffic = HBM bytes per launch from the PMC counters.  Counter collection needs its own rocprofv3 --pmc passes
+        # (it serialises the kernels; this process cannot read the counters): `scripts/gpu_round.sh pmc` runs them on THIS
+        # command and scripts/make_traffic_json.py records the source hash of the build they ran on.  The number is quoted
+        # only when that hash is the running library's (mmw_version()); for any other build the line says null.
+        traffic, traffic_src = None, "null: no PMC passes of this build (profiles/traffic.json absent or from other sources)"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             try:
                 tj = json.load(open(tpath))
+                lib_hash = _lib.load().mmw_version().decode().rsplit("src:", 1)[-1]
                 key = f"{S}x{N}x{args.tracks}"
                 ent = tj.get(key, {}).get(_lib.load().mmw_kernel_name(dom).decode())
-                # FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, bytes per launch, from a
-                # separate rocprofv3 --pmc run of this workload (profiles/README.md)
-                traffic = ent.get("hbm_bytes_per_launch_fetch_x2") if isinstance(ent, dict) else ent
-                if traffic is not None:
-                    import hashlib
-                    raw = open(tpath, "rb").read()
-                    blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()[:12]   # = git hash-object: a stale file is visible
-                    traffic_src = (f"profiles/traffic.json[{key}] (git blob {blob}; {tj.get('source', 'separate rocprofv3 --pmc passes')}); "
-                                   f"not measured in this run")
+                if tj.get("src_hash") == lib_hash and isinstance(ent, dict):
+                    # FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, bytes per launch
+                    traffic = ent.get("hbm_bytes_per_launch_fetch_x2")
+                    traffic_src = (f"profiles/traffic.json[{key}]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
+                                   f"this build (src:{lib_hash}); {tj.get('source', '')}")
+                elif tj.get("src_hash") != lib_hash:
+                    traffic_src = (f"null: profiles/traffic.json was collected on src:{tj.get('src_hash')}, this library is src:{lib_hash} "
+                                   f"(run scripts/gpu_round.sh pmc + scripts/make_traffic_json.py on this build)")
             except Exception:
                 traffic = None
         # B_trk = 64N + 4N + 4U + 2*T*1200 + 64*U_new per scene-frame, with the run's own means
@@ -649,7 +679,8 @@ def main():
         mean_U = float(stats[4]) / max(float(stats[3]), 1.0)
         db_frac = float(stats[3]) / sf      # apply_DBscan calls per scene-frame
         u_new = mean_U / sb.ring            # unassigned rows appended per frame ~ a ring-th of the clustered cloud
-        b_trk = 64.0 * N + 4.0 * N + 4.0 * mean_U * db_frac + 2.0 * mean_T * 1200.0 + 64.0 * u_new
+        row_b = 32.0 if rows32 else 64.0   # (SURVEY.md §8(d) prices the points at 64 B: fp64 rows; stored as fp32 they are 32)
+        b_trk = row_b * N + 4.0 * N + 4.0 * mean_U * db_frac + 2.0 * mean_T * 1200.0 + 64.0 * u_new
         # fp64 operations of the step's tracker arithmetic, counted from the device work counters
         flop_track = gate_evals / K * FLOP_PER_GATE + (S * N) * FLOP_PER_POINT_STATS
         flop_step = flop_track + tracks_in / K * (FLOP_PER_TRACK_PREDICT + FLOP_PER_TRACK_UPDATE)
@@ -660,6 +691,8 @@ def main():
             "config": {
                 "workload": workload_label(S_total, N, args.tracks, world, scaling, S),
                 "scenes_total": S_total, "scenes_per_gpu": S, "points_per_frame": N, "max_tracks": args.tracks, "frames_resident": F,
+                "rows": ("fp32 in HBM (32 B per point), promoted to fp64 in registers by mmw_step_f32: exact, outputs bit-equal to the fp64 entry's"
+                         if rows32 else "fp64 in HBM (64 B per point), mmw_step"),
                 "parallelism": f"scenes sharded over {world} GPU(s), {scaling} scaling, no data-path collective; "
                                f"all-gather of the track table once per run",
                 "n_ranks_seen": n_ranks_seen, "gathered_table_rows": gathered_rows,
@@ -723,7 +756,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    sb.close()
+    shard.close()
 
 
 if __name__ == "__main__":

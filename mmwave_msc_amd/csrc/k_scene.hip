@@ -893,7 +893,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
         int ring_rows = 0;
         for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
         unsigned long long *sl = stats_slot(st, s);
-        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * nun + 64 * ring_rows));
+        atomicAdd(&sl[0], (unsigned long long)((F32 ? 32 : 64) * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * nun + 64 * ring_rows));
         atomicAdd(&sl[2], 1ULL);
         atomicAdd(&sl[5], (unsigned long long)Tin);
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         int ring_rows = 0;
         for (int j = 0; j < Tin; j++) ring_rows += min(L.cls_n[j + 1], cfg.ring_rows);
         unsigned long long *sl = stats_slot(st, s);
-        atomicAdd(&sl[0], (unsigned long long)(64 * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * L.cls_n[0] + 64 * ring_rows));
+        atomicAdd(&sl[0], (unsigned long long)((F32 ? 32 : 64) * n + 4 * n + Tin * kTrackBytesPerTrack + 64 * L.cls_n[0] + 64 * ring_rows));
         atomicAdd(&sl[2], 1ULL);
         atomicAdd(&sl[5], (unsigned long long)Tin);
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);

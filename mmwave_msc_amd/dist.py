@@ -51,3 +51,114 @@ def all_gather_tables(local: torch.Tensor, counts=None) -> torch.Tensor:
     if all(r == mx for r in all_rows):
         return out
     return torch.cat([out[r * mx: r * mx + all_rows[r]] for r in range(world)])
+
+
+def job_shard(n_scenes: int, rank: int, world: int, scaling: str = "strong"):
+    """(lo, hi, total): the global scene ids [lo, hi) of `rank` and the job's scene count.  strong: `n_scenes` is the whole job,
+    cut into contiguous blocks (BASELINE configs[2] / [4]); weak: every rank owns `n_scenes` scenes."""
+    if scaling == "strong":
+        lo, hi = shard_range(n_scenes, rank, world)
+        return lo, hi, int(n_scenes)
+    return rank * int(n_scenes), (rank + 1) * int(n_scenes), int(n_scenes) * int(world)
+
+
+class ShardedTracker:
+    """One rank's share of a job of many scenes, one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI):
+    the rank-local `SceneBatch` for the scenes [lo, hi), optionally the `PosturePipeline` behind it, and the ONE exchange of the
+    design -- the all-gather of the fixed-size track table (nothing in Tracking.py crosses scenes, so there is no
+    data-path collective).
+
+        st = ShardedTracker(cfg, n_scenes, max_pts, scaling="strong")      # after init_process_group, or single process
+        st.step_dev(pts_ptr, n_ptr, dt_ptr, ...)                           # rank-local frames [hi - lo][max_pts][8]
+        st.after_step()                                                    # estimate_posture, pipelined (if a model was given)
+        table = st.gather_table(slots)                                     # [n_scenes_total * slots, SUMMARY_WORDS], by global scene id
+
+    `batch_factory(cfg, n_local, max_pts, device)` builds the rank-local batch (default: `SceneBatch`); the CPU tests pass a stand-in
+    with `track_table_host`, which is all `gather_table` needs off the GPU."""
+
+    def __init__(self, cfg, n_scenes: int, max_pts: int, scaling: str = "strong", device=None, model=None, posture_cap=None,
+                 rank=None, world=None, batch_factory=None, stream=None):
+        init = dist.is_available() and dist.is_initialized()
+        self.rank = int(rank if rank is not None else (dist.get_rank() if init else 0))
+        self.world = int(world if world is not None else (dist.get_world_size() if init else 1))
+        self.scaling = scaling
+        self.lo, self.hi, self.n_total = job_shard(n_scenes, self.rank, self.world, scaling)
+        self.S = self.hi - self.lo
+        if self.S < 1:
+            raise ValueError(f"rank {self.rank}: no scenes to own ({self.n_total} scenes over {self.world} ranks)")
+        self.device = device
+        if batch_factory is None:
+            from .batch import SceneBatch
+            batch_factory = lambda c, s, n, d: SceneBatch(c, s, n, device=0 if d is None else int(d))   # noqa: E731
+        self.sb = batch_factory(cfg, self.S, int(max_pts), device)
+        self._table = None
+        self.pipe = None
+        if stream is not None:
+            self.sb.follow_torch_stream(stream)
+        if model is not None:
+            from .posture import PosturePipeline
+            cap = int(posture_cap if posture_cap is not None else self.S * self.sb.track_cap)
+            self.pipe = PosturePipeline(self.sb, model, cap, tracker_stream=stream)
+
+    def step_dev(self, pts_ptr, n_ptr, dt_ptr, assoc_ptr=None, labels_ptr=None, dbn_ptr=None, f32: bool = False):
+        (self.sb.step_dev_f32 if f32 else self.sb.step_dev)(pts_ptr, n_ptr, dt_ptr, assoc_ptr, labels_ptr, dbn_ptr)
+
+    def after_step(self):
+        if self.pipe is not None:
+            self.pipe.after_step()
+
+    def drain(self):
+        if self.pipe is not None:
+            self.pipe.drain()
+
+    def gather_table(self, slots: int) -> torch.Tensor:
+        """Every rank's track summaries (`slots` per scene, scene ids global) all-gathered, ordered by global scene id."""
+        if hasattr(self.sb, "track_table_dev") and getattr(self.sb, "h", None) is not None:
+            dev = torch.device("cuda", self.sb.device)
+            if self._table is None or self._table.shape[0] != self.S * int(slots):
+                self._table = torch.zeros((self.S * int(slots), SUMMARY_WORDS), dtype=torch.int32, device=dev)
+            self.sb.track_table_dev(self._table.data_ptr(), int(slots), scene_base=self.lo)
+            if self.world > 1 and dist.get_backend() != "nccl":   # (gloo: host tensors; the table must have been written first)
+                self.sb.synchronize()
+                return all_gather_tables(self._table.cpu())
+            return all_gather_tables(self._table)
+        return all_gather_tables(summaries_to_tensor(self.sb.track_table_host(int(slots), scene_base=self.lo)))
+
+    def close(self):
+        if self.pipe is not None:
+            self.pipe.close()
+            self.pipe = None
+        if self.sb is not None and hasattr(self.sb, "close"):
+            self.sb.close()
+        self.sb = None
+
+
+class LocalShardedTracker:
+    """The same job in ONE process: G contexts (one per entry of `devices`; several may name the same GPU), each stepped from its
+    own host thread -- the form SURVEY.md §8(e) allows beside one process per GPU (the C-ABI takes the device; a context is used
+    from one thread at a time, different contexts from different threads concurrently).  `run(fn)` calls fn(g, shard) for every
+    shard on its thread; `gather_table` concatenates the shards' tables (no collective: one address space)."""
+
+    def __init__(self, cfg_factory, n_scenes: int, max_pts: int, devices, scaling: str = "strong"):
+        from concurrent.futures import ThreadPoolExecutor
+        from .batch import SceneBatch
+        self.G = len(devices)
+        self.shards = []
+        for g, dev in enumerate(devices):
+            lo, hi, total = job_shard(n_scenes, g, self.G, scaling)
+            self.shards.append(dict(g=g, lo=lo, hi=hi, device=int(dev), sb=SceneBatch(cfg_factory(), hi - lo, int(max_pts), device=int(dev))))
+        self.n_total = total
+        self._pool = ThreadPoolExecutor(max_workers=self.G)
+
+    def run(self, fn):
+        """fn(g, shard_dict) on every shard's own thread; returns the results in shard order (exceptions propagate)."""
+        return [f.result() for f in [self._pool.submit(fn, sh["g"], sh) for sh in self.shards]]
+
+    def gather_table(self, slots: int) -> np.ndarray:
+        tabs = self.run(lambda g, sh: sh["sb"].track_table_host(int(slots), scene_base=sh["lo"]))
+        return np.concatenate(tabs, axis=0)
+
+    def close(self):
+        for sh in self.shards:
+            sh["sb"].close()
+        self._pool.shutdown()

@@ -2,7 +2,11 @@
 """profiles/traffic.json (what bench.py quotes as roofline.traffic) from the PMC summaries of scripts/gpu_round.sh pmc / pmc512:
     python scripts/make_traffic_json.py profiles/r03a_pmc_summary.json profiles/r03a_pmc512_summary.json > profiles/traffic.json"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmwave_msc_amd._lib import source_hash  # noqa: E402
 
 KEYS = {"k_track": "k_track", "k_scene": "k_track", "k_predict": "k_predict", "k_post": "k_post", "k_dbscan_big": "k_dbscan_big", "k_chain": "k_chain"}
 
@@ -21,6 +25,8 @@ def table(path):
 
 big, small = sys.argv[1], sys.argv[2]
 res = {"4096x512x8": table(big), "512x512x8": table(small),
+       # the build the counters were collected on: bench.py quotes them only for a library built from the same sources
+       "src_hash": source_hash(),
        "source": f"{big} / {small}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --no-cpu --no-e2e --no-e2e-parity "
                  f"--no-cold --no-shards --no-full --no-ingest --no-single --steps 10 --warmup 10 (--chain-side-stream 2 at 4096 scenes, --scenes 512 for the shard)",
        "_note": "KiB -> bytes; read side given raw and x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads: MI355X_MICROARCH.md). "

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -66,6 +67,54 @@ def test_all_gather_track_tables_even_shards():
 
 def test_all_gather_track_tables_uneven_shards():
     _run(total=7, slots=3)
+
+
+def _sharded_worker(rank, world, port, total, slots, scaling, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmwave_msc_amd.dist import ShardedTracker, job_shard, tensor_to_summaries
+
+    class Standin:   # the rank-local batch off the GPU: its table is all gather_table needs
+        def __init__(self, cfg, n_local, max_pts, device):
+            self.S, self.steps = n_local, 0
+
+        def step_dev(self, *a):
+            self.steps += 1
+
+        def track_table_host(self, n_slots, scene_base=0):
+            return _fake_table(scene_base, scene_base + self.S, n_slots)
+
+    st = ShardedTracker(None, total, 64, scaling=scaling, batch_factory=Standin)
+    lo, hi, n_total = job_shard(total, rank, world, scaling)
+    ok = (st.lo, st.hi, st.n_total, st.S) == (lo, hi, n_total, hi - lo) and st.rank == rank and st.world == world
+    st.step_dev(0, 0, 0)
+    st.after_step()      # (no model: nothing to do)
+    tab = tensor_to_summaries(st.gather_table(slots), slots)
+    want = _fake_table(0, n_total, slots)
+    ok = ok and st.sb.steps == 1 and tab.shape == want.shape and all(np.array_equal(tab[n], want[n]) for n in want.dtype.names)
+    st.close()
+    q.put((rank, bool(ok), int(tab.shape[0])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,scaling,rows", [(9, "strong", 9), (5, "weak", 10)])
+def test_sharded_tracker_object_over_two_gloo_ranks(total, scaling, rows):
+    """mmwave_msc_amd.dist.ShardedTracker -- what `bench.py --gpus N` is a client of -- with a stand-in for the rank-local batch:
+    shard arithmetic (strong: uneven blocks; weak: `total` scenes per rank), stepping, and the all-gather of the track table
+    into the global table ordered by scene id."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, total, 3, scaling, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
+    assert all(r[2] == rows for r in res), res
 
 
 def _bench(*argv, env=None):

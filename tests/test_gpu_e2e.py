@@ -291,3 +291,55 @@ def test_baseline_configs_at_their_size_vs_oracle(S, N, T, F):
         assert np.array_equal(rn[s, : ln[s]], ob.scenes[s].batch_ring()), s
     sb.check()
     sb.close()
+
+
+def test_local_sharded_tracker_two_contexts_on_two_threads_vs_oracle():
+    """mmwave_msc_amd.dist.LocalShardedTracker: the job in ONE process, two contexts stepped concurrently from two host threads
+    (both on this GPU: the C-ABI's contract is one thread per context, any number of contexts) -- every scene equals its
+    oracle run, and the concatenated track table is the global one, ordered by scene id."""
+    import torch
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.dist import LocalShardedTracker
+    from mmwave_msc_amd.synth import make_batch
+    from oracle import c_oracle as co
+    S, N, F, T = 37, 192, 9, 4
+    pts = np.zeros((F, S, N, 8), np.float32); cnt = np.zeros((F, S), np.int32); dts = np.zeros((F, S))
+    for s in range(S):
+        p, c, d = make_batch([8800 + s], F, N, 1 + s % T, ragged=(s % 3 == 0))
+        pts[:, s], cnt[:, s], dts[:, s] = p[:, 0], c[:, 0], d[:, 0]
+    lt = LocalShardedTracker(lambda: _lib.default_config(tr_max_tracks=T), S, N, devices=[0, 0])
+    assert [(sh["lo"], sh["hi"]) for sh in lt.shards] == [(0, 19), (19, 37)] and lt.n_total == S
+
+    def run_shard(g, sh):
+        sb, lo, hi = sh["sb"], sh["lo"], sh["hi"]
+        dev = torch.device("cuda", sh["device"])
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            sb.follow_torch_stream(st)
+            d_cnt = torch.from_numpy(np.ascontiguousarray(cnt[:, lo:hi])).to(dev)
+            d_dt = torch.from_numpy(np.ascontiguousarray(dts[:, lo:hi])).to(dev)
+            for f in range(F):
+                p32 = torch.from_numpy(np.ascontiguousarray(pts[f, lo:hi])).to(dev)
+                sb.step_dev_f32(p32.data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+                st.synchronize()
+        sb.check()
+        return sb.num_tracks()
+
+    counts = np.concatenate(lt.run(run_shard))
+    ob = co.OracleBatch(co.default_config(tr_max_tracks=T), S, N)
+    co.batch_run_f32(ob, pts, cnt, dts, 0)
+    tab = lt.gather_table(T)
+    assert tab.shape == (S, T) and np.array_equal(tab["scene"][:, 0], np.arange(S))
+    for sh in lt.shards:
+        ntr = sh["sb"].num_tracks()
+        trk = sh["sb"].tracks(cap=max(int(ntr.max()), 1))
+        for s in range(sh["lo"], sh["hi"]):
+            want = ob.scenes[s].tracks()
+            k = s - sh["lo"]
+            assert counts[s] == ntr[k] == len(want), s
+            for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "lifetime", "point_num", "is_static", "ring_n"):
+                assert np.array_equal(trk[k, : ntr[k]][name], want[name]), (s, name)
+            alive = min(len(want), T)
+            assert int(tab["alive"][s].sum()) == alive, s
+            assert np.array_equal(tab["x"][s, :alive], want["x"][:alive].astype(np.float32)), s
+    lt.close()
