@@ -262,10 +262,11 @@ def main():
                          "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
     ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
-    ap.add_argument("--rows", choices=("f32", "f64"), default="f32",
-                    help="how the resident frames are stored in HBM: f32 (default: 32 B per point, mmw_step_f32 promotes them to fp64 as they are "
-                         "loaded -- exact, the synthetic rows are fp32-representable; every output is bit-equal to the fp64 entry's) or f64 "
-                         "(64 B per point, mmw_step: what rounds 1-3 timed)")
+    ap.add_argument("--rows", choices=("f32", "f64"), default="f64",
+                    help="how the resident frames are stored in HBM: f64 (default: 64 B per point, mmw_step -- the reference's float64 arrays, "
+                         "what rounds 1-3 timed) or f32 (32 B per point, mmw_step_f32 promotes them to fp64 as they are loaded -- exact, the "
+                         "synthetic rows are fp32-representable; every output is bit-equal; the step is not faster for it, k_track is bound by "
+                         "its chains, not by bytes: profiles/NOTEBOOK.md)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-scene leg (configs[0]: the offline loop on one synthetic CSV experiment: bench_single.py)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the host-fed legs (frames from pinned host memory every step: bench_ingest.py)")
     ap.add_argument("--fused-step", type=int, default=0, choices=(-1, 0, 1),
