@@ -331,7 +331,23 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
  * bit 0 set when an input or an activation of magnitude >= 65 504 (or a non-finite input) was split -- that sample's
  * outputs are then meaningless, where Keras' fp32 would have been finite; nothing clears it but the caller. */
 int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
-                        const float *b2, void *out16, int64_t ld_out, int32_t n, int32_t *range_flag);
+                        const float *b2, void *out16, int64_t ld_out, int32_t n, int32_t *range_flag, int32_t *sample_flags);
+/* ... per sample: sample_flags (device int32[2 + MMW_RANGE_FIXUP_CAP], may be NULL; zero it once) is the fix-up list: [0] counts
+ * the samples whose input or activations left fp16's range (running, atomic), [2 ..] are the indices of the first
+ * MMW_RANGE_FIXUP_CAP of them, in any order.
+ * mmw_mars_range_fixup recomputes exactly those samples in Keras' own fp32 arithmetic and overwrites their rows of kp[n][57] --
+ * all on the device and the given stream, no host wait: the listed samples' feature tensors are copied, run through the fp32
+ * conv pair (mmw_mars_conv3d's kernel) and the thin Dense-1 / Dense-2 kernels of mmw_mars_head_small with a row count only the
+ * device knows (workgroups past it leave at once: a frame without such samples pays four empty launches), and scattered back;
+ * the list is emptied for the next call ([1] = the number taken).  More than MMW_RANGE_FIXUP_CAP flagged samples in one call:
+ * bit 1 of *range_flag is raised and the surplus keeps its meaningless rows.
+ * define_CNN_3D only (feat[n][3][8][8][5]); cw1 / cb1 / cw2 / cb2 = the conv kernels in Keras layout (fp32), w1[1536][ldw] /
+ * bias1 / w2[57][1536] / bias2 as for mmw_mars_head_small; scratch = MMW_RANGE_FIXUP_SCRATCH bytes of device memory. */
+#define MMW_RANGE_FIXUP_CAP 64
+#define MMW_RANGE_FIXUP_SCRATCH (512 + 64 * (960 + 6144 + 1536 + 57) * 4)
+int mmw_mars_range_fixup(void *hip_stream, const float *feat, int32_t *sample_flags, int32_t n, const float *cw1, const float *cb1,
+                         const float *cw2, const float *cb2, const float *w1, int64_t ldw, const float *bias1, const float *w2, const float *bias2,
+                         void *scratch, float *kp, int32_t *range_flag);
 /* Dense-1 of the MARS CNN (train.py:49,87: Dense(512 k, relu); BatchNormalization folded in) on split-fp16 operands, one
  * kernel: out = relu(bias + hi . W_hi + 2^-11 (hi . W_lo' + lo' . W_hi)), fp32 accumulation and output (k_dense.hip).
  * a2 [rows_padded][lda] fp16 as mmw_mars_conv_split writes it; w2 [n][ldw] fp16 = the transposed weights (K contiguous)

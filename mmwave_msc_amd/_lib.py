@@ -33,7 +33,7 @@ EXPORTS = [
     "mmw_kernel_name", "mmw_version", "mmw_stats_get", "mmw_stats_reset", "mmw_format_frames", "mmw_stats_get_ext", "mmw_mars_conv3d",
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
-    "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small",
+    "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small", "mmw_mars_range_fixup",
 ]
 
 
@@ -214,7 +214,8 @@ def load():
         "mmw_set_chain_side_stream": (C.c_int, [vp, i32]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
         "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),
-        "mmw_mars_conv_split": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, C.c_int64, i32, vp]),
+        "mmw_mars_conv_split": (C.c_int, [vp, i32, vp, vp, vp, vp, vp, vp, C.c_int64, i32, vp, vp]),
+        "mmw_mars_range_fixup": (C.c_int, [vp, vp, vp, i32, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]),
         "mmw_mars_dense1_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, i32, i32, i32]),
         "mmw_mars_head_small": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, i32, i32, i32]),
         "mmw_parse_uart": (C.c_int, [vp, C.c_size_t, vp, vp, vp, i32, vp, vp, vp, vp]),

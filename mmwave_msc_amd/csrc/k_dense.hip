@@ -375,9 +375,13 @@ constexpr int kHeadCols = 8, kHeadRows = 8, kHeadThreads = 256;
 template <int ROWS>
 __global__ __launch_bounds__(head::kHeadThreads) void k_mars_head_dense1(const float *__restrict__ act, long long lda, const float *__restrict__ w,
                                                                          long long ldw, const float *__restrict__ bias, float *__restrict__ hidden,
-                                                                         int n_rows, int K, int N)
+                                                                         int n_rows, int K, int N, const int32_t *__restrict__ dev_rows)
 {
     using namespace head;
+    if (dev_rows != nullptr) {   // a row count only the device knows (the range fix-up): row tiles past it leave at once
+        n_rows = dev_rows[0] < n_rows ? dev_rows[0] : n_rows;
+        if ((int)blockIdx.y * ROWS >= n_rows) return;
+    }
     __shared__ float red[kHeadThreads / 64][ROWS][kHeadCols];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * kHeadCols, r0 = blockIdx.y * ROWS;
@@ -432,8 +436,9 @@ __global__ __launch_bounds__(head::kHeadThreads) void k_mars_head_dense1(const f
 // output (b, j), lanes along K with every load of the wave in flight at once (K = 1536: 24 per lane, three batches of eight): the
 // 57 x n_rows dot products are independent, and as a loop of one workgroup per row they were 100 us of dependent round trips.
 __global__ __launch_bounds__(256) void k_mars_head_dense2(const float *__restrict__ hidden, const float *__restrict__ w2, const float *__restrict__ bias2,
-                                                          float *__restrict__ kp, int K, int NOUT, int n_rows)
+                                                          float *__restrict__ kp, int K, int NOUT, int n_rows, const int32_t *__restrict__ dev_rows)
 {
+    if (dev_rows != nullptr) n_rows = dev_rows[0] < n_rows ? dev_rows[0] : n_rows;
     const int lane = threadIdx.x & 63, item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_rows * NOUT) return;   // (wave-uniform)
     const int b = item / NOUT, j = item - b * NOUT;
@@ -454,17 +459,17 @@ __global__ __launch_bounds__(256) void k_mars_head_dense2(const float *__restric
 }
 
 int launch_mars_head_small(const float *act, long long lda, const float *w1, long long ldw, const float *bias1, const float *w2, const float *bias2,
-                           float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream)
+                           float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream, const int32_t *dev_rows)
 {
     using namespace head;
     const dim3 grid((N1 + kHeadCols - 1) / kHeadCols, (n_rows + kHeadRows - 1) / kHeadRows);
     if (n_rows <= 2)
-        hipLaunchKernelGGL(k_mars_head_dense1<2>, dim3(grid.x, (n_rows + 1) / 2), dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1);
+        hipLaunchKernelGGL(k_mars_head_dense1<2>, dim3(grid.x, (n_rows + 1) / 2), dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1, dev_rows);
     else if (n_rows <= 4)
-        hipLaunchKernelGGL(k_mars_head_dense1<4>, dim3(grid.x, (n_rows + 3) / 4), dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1);
+        hipLaunchKernelGGL(k_mars_head_dense1<4>, dim3(grid.x, (n_rows + 3) / 4), dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1, dev_rows);
     else
-        hipLaunchKernelGGL(k_mars_head_dense1<kHeadRows>, grid, dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1);
-    hipLaunchKernelGGL(k_mars_head_dense2, dim3((n_rows * NOUT + 3) / 4), dim3(256), 0, stream, hidden, w2, bias2, kp, N1, NOUT, n_rows);
+        hipLaunchKernelGGL(k_mars_head_dense1<kHeadRows>, grid, dim3(kHeadThreads), 0, stream, act, lda, w1, ldw, bias1, hidden, n_rows, K, N1, dev_rows);
+    hipLaunchKernelGGL(k_mars_head_dense2, dim3((n_rows * NOUT + 3) / 4), dim3(256), 0, stream, hidden, w2, bias2, kp, N1, NOUT, n_rows, dev_rows);
     return 0;
 }
 

@@ -38,8 +38,10 @@ constexpr float kSplitScale = 2048.0f;  // 2^11 (see k_mars_conv16 below)
 template <int SPLIT>
 __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ feat, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2,
-                                                       const float *__restrict__ b2, float *__restrict__ out, int B)
+                                                       const float *__restrict__ b2, float *__restrict__ out, int B, const int32_t *__restrict__ dev_rows)
 {
+    // (dev_rows: a row count that only the device knows -- the range fix-up's flagged samples: workgroups past it leave at once)
+    if (dev_rows != nullptr && (SPLIT == 1 ? (int)blockIdx.x : (int)blockIdx.x / SPLIT) >= dev_rows[0]) return;
     __shared__ float Xp[5 * kPV];    // input, channel-major, zero border
     __shared__ float H1[16 * kPV];   // relu(conv1), channel-major, zero border
     __shared__ float W1s[136 * 16];  // conv1 kernel [k = tap*5+ic][oc], row 135 = zero padding of K
@@ -130,15 +132,15 @@ __global__ __launch_bounds__(128, 1) void k_mars_conv(const float *__restrict__ 
 }
 
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
-                      hipStream_t stream)
+                      hipStream_t stream, const int32_t *dev_rows)
 {
     if (B <= 0) return;
     if (B <= 64) {   // a handful of samples: three workgroups per sample (one conv2 tile per wave), the launch is one sample's latency
-        hipLaunchKernelGGL(k_mars_conv<3>, dim3(B * 3), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
+        hipLaunchKernelGGL(k_mars_conv<3>, dim3(B * 3), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B, dev_rows);
         return;
     }
     const int grid = B < 512 ? B : 512;  // 2 workgroups per CU, persistent over samples
-    hipLaunchKernelGGL(k_mars_conv<1>, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B);
+    hipLaunchKernelGGL(k_mars_conv<1>, dim3(grid), dim3(128), 0, stream, feat, w1, b1, w2, b2, out, B, (const int32_t *)nullptr);
 }
 // ================================================================================================================
 // k_mars_conv16 -- the same two layers on the fp16 matrix cores, fp32-exact by operand splitting (the scheme of
@@ -222,15 +224,15 @@ __device__ unsigned long long g_conv_stamps[8];
 #define CSTAMP(k)
 #endif
 
+constexpr int kRangeFixCap = 64;   // = MMW_RANGE_FIXUP_CAP (include/mmw.h)
 template <int NZ>
 __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict__ feat, const float *__restrict__ w1,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
                                                         const float *__restrict__ b2, _Float16 *__restrict__ out, long long ld_out, int B,
-                                                        int32_t *__restrict__ range_flag)
+                                                        int32_t *__restrict__ range_flag, int32_t *__restrict__ sample_flags)
 {
     using C = Conv16<NZ>;
-    bool over = false;   // an input outside fp16's range was split (range_flag) ...
-    float amax = 0.f;    // ... largest activation magnitude split so far
+    bool any_over = false;   // some sample of this wave left fp16's range (range_flag; per sample: sample_flags)
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the wave's LDS region and sample index stay out of the VGPRs)
     // ---- LDS carve-up ----
@@ -319,6 +321,8 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
             for (int c = 0; c < 5; c++) xin[q][c] = feat[(size_t)b * C::kPos * 5 + (q * 64 + lane) * 5 + c];
     }
     for (; b < B; b += stride) {
+        bool over = false;   // an input of THIS sample outside fp16's range was split ...
+        float amax = 0.f;    // ... largest activation magnitude of this sample split so far
         // ---- this sample's input into the padded channels-last volume, split ----
         if (C::kStageOverX) {  // the previous sample's staging tile lay over the first cells of X8: borders back to zero
             uint4 *z = reinterpret_cast<uint4 *>(Xhi);
@@ -513,9 +517,16 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
             }
             CSTAMP(4);  // conv2 epilogue + stores
         }
+        // this sample's verdict: its keypoints are meaningless under the split arithmetic (the caller recomputes exactly these
+        // samples in fp32: mars.MarsCNN.forward, mmw_mars_range_fixup)
+        const bool bad = __any(over || !(amax < 65504.0f));
+        if (bad && sample_flags && lane == 0) {   // appended to the fix-up's list (any order; [0] = running count, [2 ..] = sample indices)
+            const int pos = atomicAdd(&sample_flags[0], 1);
+            if (pos < kRangeFixCap) sample_flags[2 + pos] = b;
+        }
+        any_over |= bad;
     }
-    over |= !(amax < 65504.0f);
-    if (range_flag && __any(over) && lane == 0) atomicOr(range_flag, 1);
+    if (range_flag && any_over && lane == 0) atomicOr(range_flag, 1);
 }
 #ifdef MMW_STAMPS
 extern "C" int mmw_diag_conv_stamps(unsigned long long *out /*[8]*/, int reset)
@@ -528,7 +539,7 @@ extern "C" int mmw_diag_conv_stamps(unsigned long long *out /*[8]*/, int reset)
 
 template <int NZ>
 static void launch_conv16_t(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
-                            int B, int32_t *range_flag, hipStream_t stream)
+                            int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream)
 {
     static bool prepared = false;
     if (!prepared) {
@@ -538,15 +549,61 @@ static void launch_conv16_t(const float *feat, const float *w1, const float *b1,
     int grid = (B + 3) / 4;
     if (grid > 256) grid = 256;  // one workgroup of four sample-waves per CU, persistent over samples
     hipLaunchKernelGGL(k_mars_conv16<NZ>, dim3(grid), dim3(256), Conv16<NZ>::kLds, stream, feat, w1, b1, w2, b2,
-                       reinterpret_cast<_Float16 *>(out16), ld_out, B, range_flag);
+                       reinterpret_cast<_Float16 *>(out16), ld_out, B, range_flag, sample_flags);
 }
 
 void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
-                        int B, int32_t *range_flag, hipStream_t stream)
+                        int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream)
 {
     if (B <= 0) return;
-    if (nz == 3) launch_conv16_t<3>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, stream);
-    else launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, stream);
+    if (nz == 3) launch_conv16_t<3>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, sample_flags, stream);
+    else launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, sample_flags, stream);
+}
+
+// ---- samples that left fp16's range under the split arithmetic, recomputed in Keras' own fp32 -- on the device, no host wait ----
+// k_range_gather: the samples k_mars_conv16 appended to the fix-up list (list[0] = how many, list[2 ..] = which; the first
+// `cap` of them count): list[1] = the number taken, the running count back to zero for the next call, bit 1 of the range word
+// when there were more, and copies of their feature tensors.  One workgroup.
+__global__ __launch_bounds__(256) void k_range_gather(const float *__restrict__ feat, int32_t *__restrict__ list, int n, int per,
+                                                       int cap, float *__restrict__ small, int32_t *__restrict__ range_flag)
+{
+    __shared__ int used_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int total = list[0];
+        const int used = total < cap ? total : cap;
+        list[1] = used;
+        list[0] = 0;
+        if (total > cap && range_flag) atomicOr(range_flag, 2);   // more flagged samples than the fix-up holds: the rest stay meaningless
+        used_s = used;
+    }
+    __syncthreads();
+    const int m = used_s;
+    for (int r = 0; r < m; r++) {
+        const int i = list[2 + r];
+        if (i < 0 || i >= n) continue;
+        const float *src = feat + (size_t)i * per;
+        for (int e = tid; e < per; e += 256) small[(size_t)r * per + e] = src[e];
+    }
+}
+// k_range_scatter: the recomputed keypoints over the rows the split arithmetic left meaningless
+__global__ __launch_bounds__(64) void k_range_scatter(const float *__restrict__ kp_small, const int32_t *__restrict__ list, float *__restrict__ kp,
+                                                      int nout, int n)
+{
+    const int r = blockIdx.x;
+    if (r >= list[1]) return;
+    const int i = list[2 + r];
+    if (i < 0 || i >= n) return;
+    for (int j = threadIdx.x; j < nout; j += 64) kp[(size_t)i * nout + j] = kp_small[(size_t)r * nout + j];
+}
+
+void launch_range_gather(const float *feat, int32_t *list, int n, int per, int cap, float *small, int32_t *range_flag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_range_gather, dim3(1), dim3(256), 0, stream, feat, list, n, per, cap, small, range_flag);
+}
+void launch_range_scatter(const float *kp_small, const int32_t *list, float *kp, int cap, int nout, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_range_scatter, dim3(cap), dim3(64), 0, stream, kp_small, list, kp, nout, n);
 }
 
 }  // namespace mmw

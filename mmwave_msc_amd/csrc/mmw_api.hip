@@ -57,13 +57,15 @@ void launch_probe_set(int32_t *w, hipStream_t st);
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
-                      hipStream_t stream);
+                      hipStream_t stream, const int32_t *dev_rows = nullptr);
+void launch_range_gather(const float *feat, int32_t *list, int n, int per, int cap, float *small, int32_t *range_flag, hipStream_t stream);
+void launch_range_scatter(const float *kp_small, const int32_t *list, float *kp, int cap, int nout, int n, hipStream_t stream);
 int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
                        hipStream_t stream);
 int launch_mars_head_small(const float *act, long long lda, const float *w1, long long ldw, const float *bias1, const float *w2, const float *bias2,
-                           float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream);
+                           float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream, const int32_t *dev_rows = nullptr);
 void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
-                        int B, int32_t *range_flag, hipStream_t stream);
+                        int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream);
 }  // namespace mmw
 
 using namespace mmw;
@@ -1046,12 +1048,12 @@ int mmw_mars_conv3d(void *hip_stream, const float *feat, const float *w1, const 
 }
 
 int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, const float *w1, const float *b1, const float *w2,
-                        const float *b2, void *out16, int64_t ld_out, int32_t n, int32_t *range_flag)
+                        const float *b2, void *out16, int64_t ld_out, int32_t n, int32_t *range_flag, int32_t *sample_flags)
 {
     if ((frames != 3 && frames != 1) || n < 0 || ld_out < 2 * (int64_t)frames * 2048 || (ld_out & 7) != 0 || ((uintptr_t)out16 & 15) != 0 ||
         (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out16)))
         return fail(nullptr, MMW_E_ARG, "mmw_mars_conv_split: bad argument (frames must be 3 or 1, ld_out >= 2 * frames * 2048 and a multiple of 8)");
-    launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, ld_out, n, range_flag, (hipStream_t)hip_stream);
+    launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, ld_out, n, range_flag, sample_flags, (hipStream_t)hip_stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv_split launch -> %s", hipGetErrorString(e));
     return MMW_OK;
@@ -1081,6 +1083,30 @@ int mmw_mars_head_small(void *hip_stream, const float *act, int64_t lda, const f
     launch_mars_head_small(act, lda, w1, ldw, bias1, w2, bias2, hidden, kp, n_rows, k, n1, MMW_NKP, (hipStream_t)hip_stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_head_small launch -> %s", hipGetErrorString(e));
+    return MMW_OK;
+}
+
+int mmw_mars_range_fixup(void *hip_stream, const float *feat, int32_t *sample_flags, int32_t n, const float *cw1, const float *cb1,
+                         const float *cw2, const float *cb2, const float *w1, int64_t ldw, const float *bias1, const float *w2, const float *bias2,
+                         void *scratch, float *kp, int32_t *range_flag)
+{
+    constexpr int kCap = MMW_RANGE_FIXUP_CAP, kPer = 3 * 8 * 8 * 5, kFlat = 3 * 64 * 32;
+    if (n < 0 || (n > 0 && (!feat || !sample_flags || !cw1 || !cb1 || !cw2 || !cb2 || !w1 || !bias1 || !w2 || !bias2 || !scratch || !kp)) ||
+        ldw < kFlat || (ldw & 3) != 0 || (((uintptr_t)scratch | (uintptr_t)w1) & 15) != 0)
+        return fail(nullptr, MMW_E_ARG, "mmw_mars_range_fixup: bad argument");
+    if (n == 0) return MMW_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    // scratch: small_feat[64][960], act[64][6144], hidden[64][1536], kp_small[64][57] floats (behind 512 spare bytes);
+    // sample_flags = the fix-up list k_mars_conv16 appended to: [0] running count, [1] taken by this call, [2 ..] sample indices
+    float *small = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + 512);
+    float *act = small + (size_t)kCap * kPer, *hidden = act + (size_t)kCap * kFlat, *kps = hidden + (size_t)kCap * 1536;
+    const int32_t *taken = sample_flags + 1;
+    launch_range_gather(feat, sample_flags, n, kPer, kCap, small, range_flag, st);
+    launch_mars_conv(small, cw1, cb1, cw2, cb2, act, kCap, st, taken);
+    launch_mars_head_small(act, kFlat, w1, ldw, bias1, w2, bias2, hidden, kps, kCap, kFlat, 1536, MMW_NKP, st, taken);
+    launch_range_scatter(kps, sample_flags, kp, kCap, MMW_NKP, n, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_range_fixup launch -> %s", hipGetErrorString(e));
     return MMW_OK;
 }
 

@@ -91,6 +91,9 @@ class MarsCNN(nn.Module):
         self.arith = arith
         self.arith_fallback = None   # why a model asked for as "f16x3" runs "f32" (from_keras_weights: weights beyond fp16's range)
         self.range_fallbacks = 0     # predict() calls recomputed in fp32 because an input / activation left fp16's range
+        self.range_recomputed = 0    # range_overflow() reads that found the device-side fp32 fix-up had run (3-frame model)
+        self._sflags = None          # per-sample range verdicts of the split conv kernel (device int32, kept zero between calls)
+        self._fix_scratch = None     # mmw_mars_range_fixup's device scratch
         self.frames = int(frames)
         self.three_d = self.frames > 1
         conv = nn.Conv3d if self.three_d else nn.Conv2d
@@ -207,9 +210,14 @@ class MarsCNN(nn.Module):
         rows = (x.shape[0] + 255) // 256 * 256
         ld = 2 * flat + self.ROW_PAD
         out = torch.empty((rows, ld), dtype=torch.float16, device=x.device)
+        sflags = None
+        if self.has_range_fixup():   # the list the fp32 fix-up behind Dense-2 works off (forward): [count, taken, 64 sample indices]
+            if self._sflags is None or self._sflags.device != x.device:
+                self._sflags = torch.zeros((2 + 64,), dtype=torch.int32, device=x.device)
+            sflags = self._sflags.data_ptr()
         rc = L.mmw_mars_conv_split(torch.cuda.current_stream(x.device).cuda_stream, self.frames, x.data_ptr(), self.k_w1.data_ptr(),
                                    self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), out.data_ptr(), ld, x.shape[0],
-                                   self.range_flag.data_ptr())
+                                   self.range_flag.data_ptr(), sflags)
         if rc != 0:
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return out[: x.shape[0], : 2 * flat]
@@ -233,6 +241,25 @@ class MarsCNN(nn.Module):
         if rc != 0:
             raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
         return h[:B]
+
+    def has_range_fixup(self) -> bool:
+        """The split arithmetic repairs itself (3-frame model): samples that left fp16's range are recomputed in fp32 on the device."""
+        return self.use_hip_conv_f32
+
+    def _range_fixup(self, x: torch.Tensor, kp: torch.Tensor):
+        """mmw_mars_range_fixup behind a split-arithmetic forward: the flagged samples' rows of kp recomputed in Keras' fp32 -- no host
+        wait; a batch without such samples pays four empty launches."""
+        from . import _lib
+        L = _lib.load()
+        if self._fix_scratch is None or self._fix_scratch.device != x.device:
+            self._fix_scratch = torch.empty((512 + 64 * (960 + 6144 + 1536 + 57) * 4,), dtype=torch.uint8, device=x.device)   # MMW_RANGE_FIXUP_SCRATCH
+        w1 = self.dense1_dhwc.weight
+        rc = L.mmw_mars_range_fixup(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), self._sflags.data_ptr(), x.shape[0],
+                                    self.k_w1.data_ptr(), self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), w1.data_ptr(), w1.stride(0),
+                                    self.dense1_dhwc.bias.data_ptr(), self.dense2.weight.data_ptr(), self.dense2.bias.data_ptr(),
+                                    self._fix_scratch.data_ptr(), kp.data_ptr(), self.range_flag.data_ptr())
+        if rc != 0:
+            raise _lib.MmwError(rc, (L.mmw_last_error(None) or b"").decode())
 
     SMALL_BATCH = 64   # mmw_mars_head_small's limit
 
@@ -261,12 +288,17 @@ class MarsCNN(nn.Module):
         return kp
 
     def range_overflow(self, clear: bool = True) -> bool:
-        """True when a split-arithmetic forward since the last call met an input or activation outside fp16's range (that
-        sample's keypoints are meaningless; the other samples are not affected).  Reads one device word: synchronises."""
-        hit = bool(int(self.range_flag.item()))
-        if hit and clear:
+        """True when a split-arithmetic forward since the last call left some sample's keypoints MEANINGLESS: an input or
+        activation outside fp16's range that was not repaired.  The 3-frame model repairs such samples itself (forward():
+        mmw_mars_range_fixup recomputes them in fp32 on the device), so for it this only reports a batch with more than 64 of
+        them; the single-frame model has no fp32 kernel and reports every one.  `range_recomputed` says how often the repair
+        ran.  Reads one device word: synchronises."""
+        word = int(self.range_flag.item())
+        if word and clear:
             self.range_flag.zero_()
-        return hit
+        if word & 1:
+            self.range_recomputed += 1
+        return bool(word & 2) if self.has_range_fixup() else bool(word & 1)
 
     def fp32_arith(self) -> str:
         """What replaces the split arithmetic where it cannot be used (weights / activations beyond fp16's range): the fp32
@@ -287,9 +319,12 @@ class MarsCNN(nn.Module):
                                  "arith='torch' torch's convolutions")
             with torch.cuda.device(x.device):
                 if arith == "f16x3":
-                    h = self._dense1_split(self._hip_convs_split(x))
-                else:
-                    h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
+                    xc = x.contiguous()
+                    kp = self.dense2(self._dense1_split(self._hip_convs_split(xc))).contiguous()
+                    if self.has_range_fixup():
+                        self._range_fixup(xc, kp)   # samples outside fp16's range: their rows again, in fp32 (Keras' arithmetic)
+                    return kp
+                h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
             return self.dense2(h)
         if self.three_d:
             h = x.permute(0, 4, 1, 2, 3)

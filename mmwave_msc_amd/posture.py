@@ -149,8 +149,10 @@ class PosturePipeline:
         if getattr(self.model, "arith", None) == "f16x3" and hasattr(self.model, "range_overflow") and self.model.range_overflow():
             import warnings
             self.range_overflowed = True
-            warnings.warn("MarsCNN (split-fp16 arithmetic): an input or activation left fp16's range during this run; the keypoints of "
-                          "the samples concerned are meaningless -- use MarsCNN(arith='f32') for such data", RuntimeWarning, stacklevel=2)
+            warnings.warn("MarsCNN (split-fp16 arithmetic): inputs or activations left fp16's range during this run and were NOT repaired (the "
+                          "single-frame model has no fp32 kernel; the 3-frame model repairs up to 64 samples per batch on the device): the "
+                          "keypoints of the samples concerned are meaningless -- use MarsCNN(arith='f32' / 'torch') for such data",
+                          RuntimeWarning, stacklevel=2)
 
     def close(self):
         """drain(), then hand the tracker back as it was found: its side-stream workers on again if this pipeline turned
