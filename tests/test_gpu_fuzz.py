@@ -103,3 +103,57 @@ def test_random_configuration_vs_oracle(seed, layout):
                 assert np.array_equal(sb.track_ring_frame(s, t, k), scenes[s].track_ring_frame(t, k)[: sb.ring_rows]), (seed, s, t, k)
     sb.close()
     case["seen"] = seen
+
+
+@pytest.mark.parametrize("layout", ["track_wise", "per_scene", "one_workgroup"])
+@pytest.mark.parametrize("seed", [5, 56])
+def test_scene_reset_after_a_reference_exception_vs_oracle(seed, layout):
+    """Two of the random configurations run into the reference's ZeroDivisionError (`_get_Rc`, Tracking.py:299-312: KF_ENABLE_EST
+    with a one-point cluster).  The scene gets its sticky error bit; `mmw_reset_scenes` must give exactly that scene a fresh
+    TrackBuffer / BatchedData -- in the track-wise Kalman layout too, where the update lists of the frame before the reset
+    still name the scene's (now stale, inf / NaN) records: they must not be predicted again, or the error bit comes straight
+    back on the fresh scene -- while every other scene carries on; all scenes equal their oracles to the end."""
+    from mmwave_msc_amd import _lib
+    from oracle import c_oracle as co
+    case = draw_case(seed)
+    kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
+    pts, cnt, dts = scene_inputs(case)
+    sb = make_checked(S, N, layout, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    resets = 0
+    for f in range(F):
+        want, failed = [None] * S, []
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c != 0:
+                try:
+                    want[s] = scenes[s].track(pts[f, s, : max(c, 0)].astype(np.float64), float(dts[f, s]))
+                except RuntimeError:
+                    failed.append(s)
+        if failed:
+            with pytest.raises(_lib.MmwError):
+                sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+            mask = np.zeros(S, bool)
+            mask[failed] = True
+            assert np.array_equal(sb.errors() != 0, mask), (seed, f)
+            sb.reset_scenes(mask)
+            assert not sb.errors().any()
+            for s in failed:
+                scenes[s] = co.OracleScene(cfg, N)
+            resets += len(failed)
+        else:
+            assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+            for s in range(S):
+                if want[s] is not None:
+                    n = max(int(cnt[f, s]), 0)
+                    assert np.array_equal(assoc[s, :n], want[s][0]), (seed, f, s)
+        assert not sb.errors().any(), (seed, f, sb.errors())
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=max(int(ntr.max()), 1))
+        for s in range(S):
+            assert ntr[s] == scenes[s].n_tracks, (seed, f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"seed {seed} f{f} s{s}", exact=True)
+    assert resets >= 1
+    sb.check()
+    sb.close()
