@@ -458,6 +458,7 @@ def main():
 
     for f in range(W):
         step(f)
+    shard.gather_table(slots)   # (untimed: allocates the table and the collective's buffers; the timed gather below reuses them)
     torch.cuda.synchronize()
     sb.check()
     sb.stats_reset()
