@@ -90,7 +90,11 @@ typedef struct mmw_config {
                                        the association kernel, whatever they have not taken by its end in the post kernel), -1 = post
                                        kernel only, 1 = always with the side stream (tests run both), 2 = as 1 without the check that
                                        the side stream really runs beside the context's (profilers that serialise kernels fail it: the
-                                       workers then start, find nothing to claim in time and leave -- correct, and visible as a launch) */
+                                       workers then start, find nothing to claim in time and leave -- correct, and visible as a launch),
+                                       3 = as 1, and the workers of a step do not start before the step's first kernel does (an event
+                                       recorded on the context's stream at the head of every step: ~7 us per step; for callers that
+                                       queue their own work on the context's stream between steps -- by default the side stream paces
+                                       itself by the steps' stop epochs and its workers may poll empty queues a little early) */
     double db_spread_thres;         /* DB_SPREAD_THRES :77 */
     double db_inner_eps;            /* DB_INNER_EPS :78 */
     double m_x, m_y, m_z;           /* M_X, M_Y, M_Z :31-33  monitoring point (calc_projection_points, Utils.py:180-219) */

@@ -82,7 +82,8 @@ struct mmw_ctx {
     int UM;                      // ring * max_pts
     hipStream_t own_stream, stream;
     hipStream_t side_stream = nullptr;   // k_chain beside k_track (contexts with dc.side_worker)
-    hipEvent_t side_gate = nullptr;      // recorded on the context's stream at the head of a step: k_chain does not start before it
+    hipEvent_t side_gate = nullptr;      // (gate_side only) recorded on the context's stream at the head of a step: k_chain does not start before it
+    int gate_side = 0;                   // mmw_config.chain_side_stream == 3
     int side_wanted = 0;                 // what the configuration / mmw_set_chain_side_stream asked for
     int fused_wanted = 0;                // the one-workgroup step (k_scene) is what this context runs unless a ring was resized or the side workers were asked for
     int side_trusted = 0;                // mmw_config.chain_side_stream == 2: the side stream is used without the concurrency check
@@ -416,7 +417,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     }
     c->stream = c->own_stream;
     c->side_wanted = d.side_worker;
-    c->side_trusted = (d.side_worker && cfg->chain_side_stream >= 2) ? 1 : 0;   // 2: taken on trust (counter collection serialises kernels: the probe would say no)
+    c->side_trusted = (d.side_worker && cfg->chain_side_stream == 2) ? 1 : 0;   // 2: taken on trust (counter collection serialises kernels: the probe would say no)
+    c->gate_side = (d.side_worker && cfg->chain_side_stream == 3) ? 1 : 0;
     c->side_probed = c->side_trusted;
     if (d.side_worker && create_side_streams(c) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
     size_t lds_b = dbscan_only_lds_bytes(c->UM);
@@ -682,8 +684,16 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
         if (!ok) c->dc.side_worker = c->dc.big_live = 0;
     }
     if (c->dc.side_worker) {
-        HIPCHK(c, hipEventRecord(c->side_gate, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_gate, 0));
+        // No event between the two streams: the side stream paces itself -- the workers of step f leave when k_post(f) has raised
+        // its stop epoch, the workers of step f + 1 start behind them and find empty queues until k_track(f + 1) pushes (idle polls
+        // with s_sleep: eight workgroups, ~70 us early in a back-to-back loop).  The event recorded at the head of every step (so
+        // that they would not start early) was a marker packet on the context's stream: 7 us of idle chip per step in the
+        // kernel trace (profiles/NOTEBOOK.md, round 4).  gate_side = 1 (callers with their own work on the context's stream,
+        // mmw_config.chain_side_stream = 3) keeps the event.
+        if (c->gate_side) {
+            HIPCHK(c, hipEventRecord(c->side_gate, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_gate, 0));
+        }
         launch_chain(c->dc, c->st, c->UM, u_bound, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
     }
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
