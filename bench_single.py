@@ -114,6 +114,7 @@ def gpu_single_scene(path, weights, device=0):
     tb.close()
     # the two calls timed (the posture one until its keypoints are in the track records: stream synchronised)
     tb2, batch = TrackBuffer(max_pts=256, device=device), BatchedData()
+    attached = tb2.attach_posture_model(model)   # as offline_main does: estimate_posture rides in track_raw's round trip
 
     def nt(det, dt):
         tb2.dt = dt
@@ -127,8 +128,10 @@ def gpu_single_scene(path, weights, device=0):
     tb2.close()
     skip = min(10, frames // 4)
     res = {"value": round(frames / loop_s, 1), "unit": "frames/s", "frames": frames,
-           "loop": "mmwave_msc_amd.offline_main: OfflineManager (CSV) -> TrackBuffer.track_raw (normalize_data + track, one round trip) -> "
-                   "estimate_posture (features, MARS CNN and keypoint scatter on the device)",
+           "loop": "mmwave_msc_amd.offline_main: OfflineManager (CSV) -> TrackBuffer.track_raw (normalize_data + track + the attached "
+                   "model's estimate_posture: features, MARS CNN in fp32 and keypoint scatter on the device, ONE round trip) -> "
+                   "estimate_posture (finds its work done)",
+           "posture_in_track_round_trip": bool(attached),
            "loop_us_per_frame": round(loop_s / frames * 1e6, 1),
            "track_us_per_frame_median": round(float(np.median(lt[skip:])) * 1e6, 1),
            "posture_us_per_frame_median": round(float(np.median(lp[skip:])) * 1e6, 1),

@@ -246,6 +246,27 @@ int mmw_step_host(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const d
 int mmw_frame_host(mmw_ctx *ctx, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out,
                    int32_t *n_out, int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks);
 
+/* The loop body WITH its posture estimate (offline_main.py:53-60: normalize_data, track, estimate_posture) in one round trip,
+ * for the one-scene context of the drop-in's TrackBuffer.  mmw_attach_posture hands the context the define_CNN_3D model
+ * (train.py:71-106, BatchNormalization folded into the Dense layers; fp32 DEVICE pointers that stay valid and unchanged in place
+ * until detached with NULL): the conv kernels in Keras layout (kd,kh,kw,in,out), dense1_w[1536][dense1_ld] = Dense-1 transposed
+ * (K = 6144 contiguous, Keras' Flatten order), dense2_w[57][1536].  Needs n_scenes == 1, FB_FRAMES_BATCH == 2 (the 3-frame
+ * model), track_cap <= 64.
+ * mmw_frame_posture_host = mmw_frame_host, and behind the step on the same stream -- unless the frame was skipped --
+ * TrackBuffer.estimate_posture (Tracking.py:705-734): the feature tensors of the tracks with more than MODEL_MIN_INPUT ring
+ * points, the CNN in Keras' own fp32 arithmetic (mmw_mars_conv3d's kernel, mmw_mars_head_small's kernels, with a row count
+ * only the device knows) and track.keypoints = its rows.  *posture_rows (host, may be NULL) = the tracks estimated.  Still ONE
+ * wait for the stream. */
+typedef struct mmw_posture_model {
+    const float *conv1_w, *conv1_b, *conv2_w, *conv2_b;
+    const float *dense1_w;
+    int64_t dense1_ld;
+    const float *dense1_b, *dense2_w, *dense2_b;
+} mmw_posture_model;
+int mmw_attach_posture(mmw_ctx *ctx, const mmw_posture_model *model);
+int mmw_frame_posture_host(mmw_ctx *ctx, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out,
+                           int32_t *n_out, int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks, int32_t *posture_rows);
+
 /* Utils.apply_DBscan (Utils.py:250-291) on arbitrary clouds: pts[S][max_n][8], n[S]
  * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts; max_n > 1920: the global-memory path). */
 int mmw_dbscan(mmw_ctx *ctx, const double *pts, const int32_t *n, int32_t max_n, double eps,

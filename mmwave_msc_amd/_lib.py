@@ -34,7 +34,15 @@ EXPORTS = [
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
     "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small", "mmw_mars_range_fixup",
+    "mmw_attach_posture", "mmw_frame_posture_host",
 ]
+
+
+class MmwPostureModel(C.Structure):
+    """struct mmw_posture_model (include/mmw.h): device pointers of define_CNN_3D's weights, BatchNormalization folded."""
+    _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+                ("dense1_w", C.c_void_p), ("dense1_ld", C.c_int64), ("dense1_b", C.c_void_p), ("dense2_w", C.c_void_p),
+                ("dense2_b", C.c_void_p)]
 
 
 class MmwConfig(C.Structure):
@@ -180,6 +188,8 @@ def load():
         "mmw_step_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
         "mmw_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
         "mmw_frame_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "mmw_frame_posture_host": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "mmw_attach_posture": (C.c_int, [vp, vp]),
         "mmw_normalize_f32": (C.c_int, [vp, vp, vp, vp, vp]),
         "mmw_dbscan": (C.c_int, [vp, vp, vp, i32, C.c_double, i32, vp, vp]),
         "mmw_features": (C.c_int, [vp, vp, vp, i32, i32p]),

@@ -209,8 +209,23 @@ class SceneBatch:
                                        assoc.ctypes.data, labels.ctypes.data, dbn.ctypes.data))
         return assoc, labels, dbn
 
+    def attach_posture(self, model=None):
+        """mmw_attach_posture: hands the context a `mars.MarsCNN` (3-frame model, on this GPU) so that `frame_host(posture=True)`
+        runs TrackBuffer.estimate_posture behind the step in the same round trip; None detaches.  The context keeps the
+        weights' device pointers: the model must stay where it is (in-place updates are fine) until detached."""
+        if model is None:
+            self._chk(self.L.mmw_attach_posture(self.h, None))
+            self._posture_model = None
+            return
+        w1 = model.dense1_dhwc.weight
+        m = _lib.MmwPostureModel(model.k_w1.data_ptr(), model.k_b1.data_ptr(), model.k_w2.data_ptr(), model.k_b2.data_ptr(),
+                                 w1.data_ptr(), w1.stride(0), model.dense1_dhwc.bias.data_ptr(), model.dense2.weight.data_ptr(),
+                                 model.dense2.bias.data_ptr())
+        self._chk(self.L.mmw_attach_posture(self.h, C.byref(m)))
+        self._posture_model = model   # (keeps the tensors alive)
+
     def frame_host(self, n: np.ndarray, dt: np.ndarray, raw: np.ndarray = None, pts: np.ndarray = None, want_rows: bool = False,
-                   want_labels: bool = True):
+                   want_labels: bool = True, posture: bool = False):
         """mmw_frame_host: one frame of every scene from host memory in ONE round trip.  `raw`[S,NP,5] radar rows (normalised
         on the device, Utils.normalize_data) or `pts`[S,NP,8] normalised rows; n[S], dt[S].  Returns a dict: assoc[S,NP],
         db_n[S], n_out[S] (rows that reached track()), n_tracks[S], labels[S,UM] (want_labels), rows[S,NP,8] (want_rows, raw form)."""
@@ -225,10 +240,16 @@ class SceneBatch:
             out["labels"] = np.full((self.S, self.UM), -1, dtype=np.int32)
         if want_rows and raw is not None:
             out["rows"] = np.zeros((self.S, self.max_pts, 8))
-        self._chk(self.L.mmw_frame_host(self.h, src.ctypes.data if raw is not None else None, src.ctypes.data if raw is None else None,
-                                        n.ctypes.data, dt.ctypes.data, out["rows"].ctypes.data if "rows" in out else None,
-                                        out["n_out"].ctypes.data, out["assoc"].ctypes.data,
-                                        out["labels"].ctypes.data if want_labels else None, out["db_n"].ctypes.data, out["n_tracks"].ctypes.data))
+        args = (self.h, src.ctypes.data if raw is not None else None, src.ctypes.data if raw is None else None,
+                n.ctypes.data, dt.ctypes.data, out["rows"].ctypes.data if "rows" in out else None,
+                out["n_out"].ctypes.data, out["assoc"].ctypes.data,
+                out["labels"].ctypes.data if want_labels else None, out["db_n"].ctypes.data, out["n_tracks"].ctypes.data)
+        if posture:   # ... and estimate_posture with the attached model behind the step (mmw_frame_posture_host)
+            rows = C.c_int32(0)
+            self._chk(self.L.mmw_frame_posture_host(*args, C.byref(rows)))
+            out["posture_rows"] = int(rows.value)
+        else:
+            self._chk(self.L.mmw_frame_host(*args))
         return out
 
     def normalize_host(self, raw: np.ndarray, n_raw: np.ndarray):

@@ -1627,11 +1627,70 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
     q_acquire();
 }
 
+// Next frame's schedule for k_track: scenes by descending track count -- a counting sort over the scene headers by ONE 256-thread
+// workgroup of k_post (its own block: as a chore of the last worker block, two passes of one dependent load per 256 scenes, it was
+// the longest chain of the launch -- 18 us at 4096 scenes); the order inside a count is irrelevant.  (Scenes without tracks
+// FIRST -- they are the ones that cluster their whole ring, 100-250 us on a chain worker -- was tried: no measurable gain in either
+// window, and they are the filler k_track's tail wants.)  The key is n_upd, which nothing in this launch writes: n_tracks may be
+// raised by a spawning worker between the two passes, and a scene counted in one bin but scattered into another would break the
+// permutation.  ... and the number of tracks in this frame's update lists, for the next k_predict: its idle waves leave on
+// one word (bin 0 of the counts is otherwise unused; 4096 workgroups adding to it in k_track cost 12 us).
+// hist: LDS, t_cap + 3 ints.  Loads in batches of eight per thread, all in flight at once.
+__device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevState &st, int parity, int *hist)
+{
+    const int tid = threadIdx.x, nb = cfg.t_cap + 1, S = cfg.n_scenes;
+    int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
+    int part = 0;
+    for (int t = 1 + tid; t <= cfg.t_cap; t += 256) part += t * cnt[t];
+    for (int i = tid; i <= nb + 1; i += 256) hist[i] = 0;
+    __syncthreads();
+    if (part) atomicAdd(&hist[nb + 1], part);
+    for (int base = 0; base < S; base += 256 * 8) {
+        int key[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sc = base + u * 256 + tid;
+            key[u] = sc < S ? st.hdr[sc].n_upd : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (base + u * 256 + tid < S) {
+                const int t = key[u] < 0 ? 0 : (key[u] > cfg.t_cap ? cfg.t_cap : key[u]);
+                atomicAdd(&hist[nb - 1 - t], 1);  // bin 0 = most tracks
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cnt[0] = hist[nb + 1];
+        int run = 0;
+        for (int b = 0; b < nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (int base = 0; base < S; base += 256 * 8) {
+        int key[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sc = base + u * 256 + tid;
+            key[u] = sc < S ? st.hdr[sc].n_upd : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sc = base + u * 256 + tid;
+            if (sc < S) {
+                const int t = key[u] < 0 ? 0 : (key[u] > cfg.t_cap ? cfg.t_cap : key[u]);
+                st.perm[(size_t)(parity ^ 1) * S + atomicAdd(&hist[nb - 1 - t], 1)] = sc;
+            }
+        }
+    }
+}
+
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
 //   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
 //                    <= 256 points k_track's cell count could not rule out): the exact pair count, then for
 //                    the handful of scenes per step that survive it the BallTree, a latency chain of ~60 us
 //                    that would otherwise leave the chip idle;
+//   block G0         next frame's schedule for k_track (post_schedule_sort above; not in the fused step)
 //   the others       _update_all (Tracking.py:598-603) of four (scene, quarter) units each, one wave per unit
 //                    (update_tracks_wave, mmw_kalman.hpp) -- the bulk work the BallTree scenes hide under.
 // The two touch disjoint state: the update covers the hdr->n_upd tracks that existed before this frame's
@@ -1645,45 +1704,38 @@ __global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const 
                                               int32_t *__restrict__ db_n_out)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#if defined(MMW_STAMPS) && defined(MMW_STAMPS_POST)   // diagnostic build: start / end of every workgroup of this launch (scripts/wg_times_post.py)
+    struct WgStamp {
+        unsigned long long *w;
+        __device__ WgStamp(const DevState &st) : w(nullptr) {
+            if (threadIdx.x == 0 && blockIdx.x < 2048) {
+                w = st.stats + kStatSlots * kStatWords + 256 + blockIdx.x * 4;
+                w[0] = __builtin_amdgcn_s_memrealtime();
+                w[1] = __builtin_amdgcn_s_memtime();
+            }
+        }
+        __device__ ~WgStamp() { if (w) { w[2] = __builtin_amdgcn_s_memrealtime(); w[3] = __builtin_amdgcn_s_memtime(); } }
+    } wg_stamp(st);
+#endif
     if ((int)blockIdx.x < G0) {
         __builtin_amdgcn_s_setprio(3);  // the latency chain goes first whenever it has an instruction ready
-        if ((int)blockIdx.x == G0 - 1 && !cfg.fused) {  // (k_scene reads no schedule: every scene is resident)
-            // (the worker least likely to have a scene) next frame's schedule for k_track: scenes by descending
-            // track count -- a counting sort over the scene headers; the order inside a count is irrelevant.
-            // (Scenes without tracks FIRST -- they are the ones that cluster their whole ring, 100-250 us on a chain
-            // worker -- was tried: no measurable gain in either window, and they are the filler k_track's tail wants.)
-            // The key is n_upd, which nothing in this launch writes: n_tracks may be raised by a spawning worker
-            // between the two passes, and a scene counted in one bin but scattered into another would break the
-            // permutation.
-            // ... and the number of tracks in this frame's update lists, for the next k_predict: its idle waves leave
-            // on one word (bin 0 of the counts is otherwise unused; 4096 workgroups adding to it in k_track cost 12 us)
-            if (threadIdx.x == 255) {
-                int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
-                int tot = 0;
-                for (int t = 1; t <= cfg.t_cap; t++) tot += t * cnt[t];
-                cnt[0] = tot;
-            }
-            int *hist = reinterpret_cast<int *>(lds_raw);  // [t_cap + 2]
-            const int nb = cfg.t_cap + 1;
-            for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
-            __syncthreads();
-            for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
-                int t = st.hdr[s].n_upd;
-                t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
-                atomicAdd(&hist[nb - 1 - t], 1);  // bin 0 = most tracks
-            }
-            __syncthreads();
+        // Side-stream workers (the large contexts): k_track is complete, so the queues' counts are final and their heads only grow --
+        // one round trip tells a worker block that nothing is left to claim, and it is gone: its workgroup slot is one the Kalman
+        // update behind it is waiting for (the four dependent atomics / loads of the queue protocol kept all 256 of them for 17 us).
+        // Block 0 stays: it releases k_chain and holds the launch until every claimed cloud is finished.
+        if (cfg.side_worker && blockIdx.x != 0) {
+            // (k_chain moves the head WHILE this is read: one thread decides for the workgroup -- waves that read different
+            //  heads would part ways in front of the worker loop's barriers)
+            int *leave = reinterpret_cast<int *>(lds_raw);
             if (threadIdx.x == 0) {
-                int run = 0;
-                for (int b = 0; b < nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
+                const int c3 = st.db_count[parity * 4 + 3], c0 = q_load(&st.q[parity * 8 + kQCount]), h0 = q_load(&st.q[parity * 8 + kQHead]);
+                const int cb = UMb > 0 ? q_load(&st.q[kQBig + parity * 8 + kQCount]) - q_load(&st.q[kQBig + parity * 8 + kQHead]) : 0;
+                *leave = (c3 == 0 && h0 >= c0 && cb <= 0) ? 1 : 0;
             }
             __syncthreads();
-            for (int s = threadIdx.x; s < cfg.n_scenes; s += 256) {
-                int t = st.hdr[s].n_upd;
-                t = t < 0 ? 0 : (t > cfg.t_cap ? cfg.t_cap : t);
-                st.perm[(size_t)(parity ^ 1) * cfg.n_scenes + atomicAdd(&hist[nb - 1 - t], 1)] = s;
-            }
-            __syncthreads();
+            const int go = *leave;
+            __syncthreads();  // (the word is the worker loop's LDS again from here)
+            if (go) return;
         }
         // No side-stream workers this step (small contexts, the start-up frames, a profiler): what the work list and the two
         // queues hold now is all there is, and nobody else can have claimed any of it -- three counters in one round trip, and
@@ -1730,8 +1782,12 @@ __global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const 
         }
         return;
     }
+    if ((int)blockIdx.x == G0) {  // (not launched by the fused step: k_scene reads no schedule, every scene is resident)
+        post_schedule_sort(cfg, st, parity, reinterpret_cast<int *>(lds_raw));
+        return;
+    }
     const int wave = threadIdx.x >> 6;
-    const int unit = ((int)blockIdx.x - G0) * 4 + wave;
+    const int unit = ((int)blockIdx.x - G0 - 1) * 4 + wave;
     if (unit >= cfg.n_scenes * nq) return;
     double *scratch = reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch;
     if (tracks_dense(cfg, nq)) {  // four real tracks per wave, from the lists k_track built this frame
@@ -2032,7 +2088,8 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
         constexpr int kSmallContextWorkers = 64;  // (32 .. 128 measured equal)
         if (G0 > kSmallContextWorkers) G0 = kSmallContextWorkers;
     }
-    const dim3 grid(G0 + (units + 3) / 4);
+    const int upd_blocks = (units + 3) / 4;
+    const dim3 grid(G0 + (units > 0 ? 1 + upd_blocks : 0));  // workers | the schedule sort | _update_all
     if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
     else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
 }

@@ -152,14 +152,16 @@ __device__ inline void sort_rows_store(int lane, double v0, double v1, double v2
 // this kernel took 120 us for 18 k tracks: 0.27 of the HBM rate for 290 MB.)
 __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const int32_t *__restrict__ row_off,
                                                   float *__restrict__ feat, int32_t *__restrict__ owner, int32_t *__restrict__ uid,
-                                                  int cap_rows)
+                                                  int cap_rows, const int32_t *__restrict__ n_in, int32_t *__restrict__ total_out)
 {
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const SceneHdr *hdr = st.hdr + s;
     const int32_t *order = st.order + (size_t)s * cfg.t_cap;
     const TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
-    const int T = hdr->n_tracks, ring = cfg.ring;   // (T <= t_cap <= 64: one lane per track)
-    const int row0 = row_off[s];
+    // (n_in: this frame's row counts -- the posture chain of mmw_frame_posture_host: a scene whose frame was skipped is not
+    //  estimated, offline_main.py:56-60.  row_off NULL + total_out: the one-scene context, which needs no scan in front)
+    const int T = (n_in && n_in[s] == 0) ? 0 : hdr->n_tracks, ring = cfg.ring;   // (T <= t_cap <= 64: one lane per track)
+    const int row0 = row_off ? row_off[s] : 0;
     int slot = 0, rlen = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0, rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, uidv = 0;
     double cx = 0.0, cy = 0.0;
     bool elig = false;
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const
         if (uid) uid[my_row] = uidv;
     }
     const int ne = __popcll(um);
+    if (total_out && tid == 0) *total_out = ne;
     for (int item = wave; item < ne * ring; item += 4) {   // (uniform per wave)
         const int i = item / ring, k = item - i * ring;
         unsigned long long m = um;
@@ -240,10 +243,12 @@ __global__ __launch_bounds__(256) void k_format_frames(DevCfg cfg, const double 
     sort_rows_store(lane, v0, v1, v2, v3, v4, feat + (size_t)item * 64 * 5);
 }
 
-__global__ void k_set_kp(DevCfg cfg, DevState st, const float *__restrict__ kp, const int32_t *__restrict__ owner, int n_rows)
+__global__ void k_set_kp(DevCfg cfg, DevState st, const float *__restrict__ kp, const int32_t *__restrict__ owner, int n_rows,
+                         const int32_t *__restrict__ dev_rows)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = g / 64, e = g % 64;
+    if (dev_rows) n_rows = min(n_rows, *dev_rows);   // (a row count only the device knows: the launch covers the capacity)
     if (row >= n_rows || e >= MMW_NKP) return;
     const int s = owner[row * 2], j = owner[row * 2 + 1];
     if (s < 0 || s >= cfg.n_scenes) return;
@@ -387,19 +392,19 @@ void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hi
     hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cfg, row_off);
 }
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
-                     hipStream_t st)
+                     hipStream_t st, const int32_t *n_in, int32_t *total_out)
 {
-    hipLaunchKernelGGL(k_features, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, s, row_off, feat, owner, uid, cap);
+    hipLaunchKernelGGL(k_features, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, s, row_off, feat, owner, uid, cap, n_in, total_out);
 }
 void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t *counts, const double *ref, float *feat, int B, hipStream_t st)
 {
     if (B <= 0) return;
     hipLaunchKernelGGL(k_format_frames, dim3((B * cfg.ring + 3) / 4), dim3(256), 0, st, cfg, frames, counts, ref, feat, B);
 }
-void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st)
+void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st, const int32_t *dev_rows)
 {
     if (n_rows <= 0) return;
-    hipLaunchKernelGGL(k_set_kp, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, st, cfg, s, kp, owner, n_rows);
+    hipLaunchKernelGGL(k_set_kp, dim3((n_rows * 64 + 255) / 256), dim3(256), 0, st, cfg, s, kp, owner, n_rows, dev_rows);
 }
 void launch_set_kp_uid(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, const int32_t *uid, int n_rows,
                        hipStream_t st)

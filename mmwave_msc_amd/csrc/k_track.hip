@@ -38,6 +38,10 @@ constexpr int kProbeScene = 460;   // (a block index: st.perm puts the scenes wi
             st.stats[kStatSlots * kStatWords + (threadIdx.x >> 6) * 64 + (id)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 // WGTIME(k): s_memrealtime (100 MHz, chip-wide) and s_memtime of every workgroup's start (k = 0) and end (k = 1)
+// (-DMMW_STAMPS_POST: k_post's workgroups write these words instead, k_dbscan.hip)
+#ifdef MMW_STAMPS_POST
+#define WGTIME(k)
+#else
 #define WGTIME(k)                                                                             \
     do {                                                                                      \
         if (threadIdx.x == 0 && blockIdx.x < 2048) {                                          \
@@ -45,6 +49,7 @@ constexpr int kProbeScene = 460;   // (a block index: st.perm puts the scenes wi
             st.stats[kStatSlots * kStatWords + 256 + blockIdx.x * 4 + (k) * 2 + 1] = __builtin_amdgcn_s_memtime(); \
         }                                                                                     \
     } while (0)
+#endif
 #else
 #define STAMP(k)
 #define PROBE(id)
@@ -97,7 +102,7 @@ __host__ __device__ __forceinline__ size_t track_lds_layout(const DevCfg &c, cha
     if constexpr (WRITE) L->field = (type *)(base + off);    \
     off = align16(off + sizeof(type) * (size_t)(count));
     if constexpr (WRITE) L->p6 = (double *)(base + off);
-    const int work_c = (4096 + kCloudGrid * 4 + 64) / 8;  // (3)
+    const int work_c = (12288 + 256 * 4 + 64) / 8;  // (3): [P4 of the pair count 4096 | grid 4096 + mm | ... | pair counts at 12288 + mm2]
     const int work_ab = work_a > work_b ? work_a : work_b;
     CARVE(work, double, work_ab > work_c ? work_ab : work_c)
     CARVE(cen, double, c.t_cap * 6)
@@ -895,6 +900,17 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         unsigned long long *mm = reinterpret_cast<unsigned long long *>(grid + kCloudGrid);
         if (Udb <= 256) {
             listed = !cloud_cells_prove_no_core(cfg, Udb, sx, sy, sz, mm, &L.misc[12], grid);
+            if (listed) {  // (uniform)
+                // second stage, the exact pair count, while this thread still holds its point of the cloud: 1-2 us here, and
+                // only the handful of clouds per step that can hold a core point travel to the DBSCAN workers.  (Left to the
+                // workers, a step's ~10^3 undecided clouds were a backlog the 8 side-stream workgroups could not clear beside
+                // this launch: k_post's 256 worker blocks spent their first 19 us on it, in workgroup slots the Kalman update
+                // was waiting for.)
+                float4 *P4 = reinterpret_cast<float4 *>(L.work);                                   // [256]
+                int *pcnt = reinterpret_cast<int *>(reinterpret_cast<char *>(L.work) + 12288);     // [256], behind the grid
+                unsigned long long *mm2 = reinterpret_cast<unsigned long long *>(pcnt + 256);      // [3]
+                listed = !cloud_pairs_prove_no_core_xyz<kThreads>(cfg, Udb, sx, sy, sz, P4, pcnt, mm2, &L.misc[14]);
+            }
         } else {  // large clouds (no tracks yet, or lost): rows from the global ring (the fence above made this frame's visible)
             const int *gs = L.misc + 4, *gn = L.misc + 8;
             const int nfr = L.misc[3], big = 0x7fffffff;

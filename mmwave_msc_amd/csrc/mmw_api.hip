@@ -44,11 +44,12 @@ void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const dou
 void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
-                     hipStream_t st);
+                     hipStream_t st, const int32_t *n_in = nullptr, int32_t *total_out = nullptr);
 void launch_set_kp_uid(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, const int32_t *uid, int n_rows,
                        hipStream_t st);
 void launch_format_frames(const DevCfg &cfg, const double *frames, const int32_t *counts, const double *ref, float *feat, int B, hipStream_t st);
-void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st);
+void launch_set_kp(const DevCfg &cfg, const DevState &s, const float *kp, const int32_t *owner, int n_rows, hipStream_t st,
+                   const int32_t *dev_rows = nullptr);
 void launch_export(const DevCfg &cfg, const DevState &s, mmw_track_record *out, int cap, hipStream_t st);
 void launch_table(const DevCfg &cfg, const DevState &s, mmw_track_summary *out, int slots, int base, hipStream_t st);
 void launch_reset(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
@@ -108,8 +109,14 @@ struct mmw_ctx {
     SceneHdr *h_hdr = nullptr;        // pinned [S]
     int32_t *h_q = nullptr;           // pinned [kQWords]
     double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;      // (views into d_in / d_out)
-    int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr, *d_nout = nullptr;
+    int32_t *d_assoc = nullptr, *d_labels = nullptr, *d_dbn = nullptr, *d_nout = nullptr, *d_prows = nullptr;
     mmw_track_record *d_export = nullptr; int export_cap = 0;
+    // mmw_attach_posture: the model and the chain's buffers ([cap] rows: feature tensors, owners, conv output, hidden, keypoints)
+    bool has_model = false;
+    mmw_posture_model model = {};
+    char *d_pchain = nullptr;
+    float *pc_feat = nullptr, *pc_act = nullptr, *pc_hidden = nullptr, *pc_kp = nullptr;
+    int32_t *pc_owner = nullptr;
     // profiling
     unsigned prof_mask = 0;           // bit k: time kernel id k (mmw_profile_enable)
     std::vector<EventPair> pending;
@@ -458,7 +465,7 @@ int mmw_destroy(mmw_ctx *c)
     if (c->side_stream) hipStreamSynchronize(c->side_stream);
     prof_fold(c);
     for (auto &ep : c->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_in, c->d_out, c->d_raw,
+    void *ptrs[] = {c->st.hdr, c->st.order, c->st.trk, c->st.trk_ring, c->st.g_ring, c->d_posture, c->d_row_off, c->d_stats, c->d_db_list, c->d_db_count, c->d_q, c->d_probe, c->st.gate_buf, c->st.perm, c->st.upd_count, c->st.upd_list, c->st.spc_count, c->st.spc_list, c->st.inner_buf, c->d_in, c->d_out, c->d_raw, c->d_pchain,
                     c->d_export, c->st.huge_scratch};
     for (void *p : ptrs) if (p) hipFree(p);
     void *pinned[] = {c->h_in, c->h_out, c->h_hdr, c->h_q};
@@ -719,7 +726,7 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
 }
 
 // layout of the two staging blocks (bytes; every part 16-byte aligned)
-struct StageLayout { size_t in_rows, in_dt, in_n, in_bytes, out_assoc, out_dbn, out_nout, out_labels, out_bytes; };
+struct StageLayout { size_t in_rows, in_dt, in_n, in_bytes, out_assoc, out_dbn, out_nout, out_prows, out_labels, out_bytes; };
 static StageLayout stage_layout(const mmw_ctx *c)
 {
     const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
@@ -732,7 +739,8 @@ static StageLayout stage_layout(const mmw_ctx *c)
     L.out_assoc = 0;
     L.out_dbn = al(S * NP * sizeof(int32_t));
     L.out_nout = L.out_dbn + al(S * sizeof(int32_t));
-    L.out_labels = L.out_nout + al(S * sizeof(int32_t));
+    L.out_prows = L.out_nout + al(S * sizeof(int32_t));
+    L.out_labels = L.out_prows + 16;
     L.out_bytes = L.out_labels + al(S * (size_t)c->UM * sizeof(int32_t));
     return L;
 }
@@ -755,6 +763,7 @@ static int ensure_host_staging(mmw_ctx *c)
     c->d_assoc = reinterpret_cast<int32_t *>(c->d_out + L.out_assoc);
     c->d_dbn = reinterpret_cast<int32_t *>(c->d_out + L.out_dbn);
     c->d_nout = reinterpret_cast<int32_t *>(c->d_out + L.out_nout);
+    c->d_prows = reinterpret_cast<int32_t *>(c->d_out + L.out_prows);
     c->d_labels = reinterpret_cast<int32_t *>(c->d_out + L.out_labels);
     return MMW_OK;
 }
@@ -764,10 +773,11 @@ static int first_scene_error(mmw_ctx *c, const SceneHdr *h, size_t n, const int3
 // One frame of every scene from host memory in ONE round trip: the inputs leave as one copy from a pinned block, the kernels
 // follow, the results, the scene headers (track counts, error bits) and the queue words come back as three copies into pinned
 // memory, and the stream is waited for once.  (mmw_step_host used to wait four times: the step, mmw_check's two read-backs.)
-int mmw_frame_host(mmw_ctx *c, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out, int32_t *n_out,
-                   int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks)
+static int frame_impl(mmw_ctx *c, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out, int32_t *n_out,
+                      int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks, bool posture, int32_t *posture_rows)
 {
     if (!c || !n || !dt || (!raw && !pts) || (raw && pts)) return fail(c, MMW_E_ARG, "mmw_frame_host: exactly one of raw / pts, and n, dt");
+    if (posture && !c->has_model) return fail(c, MMW_E_ARG, "mmw_frame_posture_host: no model attached (mmw_attach_posture)");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_host_staging(c);
     if (rc) return rc;
@@ -798,7 +808,20 @@ int mmw_frame_host(mmw_ctx *c, const double *raw, const double *pts, const int32
         rc = mmw_step(c, c->d_pts, c->d_n, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
     }
     if (rc) return rc;
-    // results: [assoc | db_n | n_out] always, the labels when asked for; headers and queue words for the error check
+    if (posture) {
+        // TrackBuffer.estimate_posture behind the step, unless the frame was skipped (k_features reads the frame's row count): the
+        // rows are counted on the device, every launch covers the capacity and its surplus workgroups leave on that word
+        const mmw_posture_model &m = c->model;
+        const int cap = c->dc.t_cap;
+        constexpr int kFlat = 3 * 64 * 32;
+        launch_features(c->dc, c->st, nullptr, c->pc_feat, c->pc_owner, nullptr, cap, c->stream, raw ? c->d_nout : c->d_n, c->d_prows);
+        launch_mars_conv(c->pc_feat, m.conv1_w, m.conv1_b, m.conv2_w, m.conv2_b, c->pc_act, cap, c->stream, c->d_prows);
+        launch_mars_head_small(c->pc_act, kFlat, m.dense1_w, m.dense1_ld, m.dense1_b, m.dense2_w, m.dense2_b, c->pc_hidden, c->pc_kp, cap, kFlat, 1536,
+                               MMW_NKP, c->stream, c->d_prows);
+        launch_set_kp(c->dc, c->st, c->pc_kp, c->pc_owner, cap, c->stream, c->d_prows);
+        HIPCHK(c, hipGetLastError());
+    }
+    // results: [assoc | db_n | n_out | posture rows] always, the labels when asked for; headers and queue words for the error check
     const size_t head = db_labels ? L.out_bytes : L.out_labels;
     HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_out, head, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->st.hdr, S * sizeof(SceneHdr), hipMemcpyDeviceToHost, c->stream));
@@ -815,13 +838,50 @@ int mmw_frame_host(mmw_ctx *c, const double *raw, const double *pts, const int32
     if (db_labels) memcpy(db_labels, c->h_out + L.out_labels, S * UM * sizeof(int32_t));
     if (h_pts_out) memcpy(pts_out, h_pts_out, S * NP * 8 * sizeof(double));
     if (n_tracks) for (size_t s = 0; s < S; s++) n_tracks[s] = c->h_hdr[s].n_tracks;
+    if (posture_rows) *posture_rows = posture ? *reinterpret_cast<const int32_t *>(c->h_out + L.out_prows) : 0;
     return first_scene_error(c, c->h_hdr, S, c->h_q);
+}
+
+int mmw_frame_host(mmw_ctx *c, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out, int32_t *n_out,
+                   int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks)
+{
+    return frame_impl(c, raw, pts, n, dt, pts_out, n_out, assoc, db_labels, db_n, n_tracks, false, nullptr);
+}
+
+int mmw_frame_posture_host(mmw_ctx *c, const double *raw, const double *pts, const int32_t *n, const double *dt, double *pts_out, int32_t *n_out,
+                           int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks, int32_t *posture_rows)
+{
+    return frame_impl(c, raw, pts, n, dt, pts_out, n_out, assoc, db_labels, db_n, n_tracks, true, posture_rows);
+}
+
+int mmw_attach_posture(mmw_ctx *c, const mmw_posture_model *m)
+{
+    if (!c) return fail(c, MMW_E_ARG, "mmw_attach_posture: null context");
+    if (!m) { c->has_model = false; return MMW_OK; }
+    if (c->dc.n_scenes != 1 || c->dc.ring != 3 || c->dc.t_cap > 64)
+        return fail(c, MMW_E_ARG, "mmw_attach_posture: a one-scene context of the 3-frame model (FB_FRAMES_BATCH = 2) with track_cap <= 64");
+    if (!m->conv1_w || !m->conv1_b || !m->conv2_w || !m->conv2_b || !m->dense1_w || !m->dense1_b || !m->dense2_w || !m->dense2_b ||
+        m->dense1_ld < 3 * 64 * 32 || (m->dense1_ld & 3) != 0 || ((uintptr_t)m->dense1_w & 15) != 0)
+        return fail(c, MMW_E_ARG, "mmw_attach_posture: null weight pointer, or Dense-1 not 16-byte aligned with a leading dimension >= 6144 that is a multiple of 4");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_pchain) {
+        const size_t cap = (size_t)c->dc.t_cap, per = 960 + 6144 + 1536 + 64;   // floats per row: features, conv output, hidden, keypoints (57, padded)
+        HIPCHK(c, hipMalloc((void **)&c->d_pchain, cap * (per * sizeof(float) + 2 * sizeof(int32_t))));
+        c->pc_feat = reinterpret_cast<float *>(c->d_pchain);
+        c->pc_act = c->pc_feat + cap * 960;
+        c->pc_hidden = c->pc_act + cap * 6144;
+        c->pc_kp = c->pc_hidden + cap * 1536;
+        c->pc_owner = reinterpret_cast<int32_t *>(c->pc_kp + cap * 64);
+    }
+    c->model = *m;
+    c->has_model = true;
+    return MMW_OK;
 }
 
 int mmw_step_host(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
 {
     if (!c || !pts || !n_pts || !dt) return fail(c, MMW_E_ARG, "mmw_step_host: null input pointer");
-    return mmw_frame_host(c, nullptr, pts, n_pts, dt, nullptr, nullptr, assoc, db_labels, db_n, nullptr);
+    return frame_impl(c, nullptr, pts, n_pts, dt, nullptr, nullptr, assoc, db_labels, db_n, nullptr, false, nullptr);
 }
 
 int mmw_dbscan(mmw_ctx *c, const double *pts, const int32_t *n, int32_t max_n, double eps, int32_t min_samples, int32_t *labels, int32_t *n_clusters)

@@ -101,6 +101,89 @@ __device__ __forceinline__ void update_math(TrackRec *rec, bool live, const doub
         }
     }
     wave_sync();
+    if constexpr (LP == 16) {
+        // The batched kernels (four tracks per wave; k_post is bound by the instructions it issues, not by latency): lane c < DX
+        // owns ROW c of K and C1 and COLUMN c of A and P, with the other index unrolled -- the identity's entries and the
+        // m < 6 tests are compile-time, the operands every lane shares (S^-1, Rc, rows of K / A / C1) are LDS broadcasts, and nothing
+        // is spent on k / 9, k % 9 and selects (81 elements dealt over 16 lanes took six rounds, the last with one lane).
+        // Per element: the same operations in the same order as below.
+        const bool act = live && c < DX;
+        if (act) {  // K = P H^T S^-1, row c
+            double prow[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) prow[m] = Pw[c * 9 + m];
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) {
+                double a = prow[0] * W[wSI + cc];
+#pragma unroll
+                for (int m = 1; m < 6; m++) a += prow[m] * W[wSI + m * 6 + cc];
+                W[wK + c * 6 + cc] = a;
+            }
+        }
+        wave_sync();
+        if (act) {
+            const double *Kw = W + wK, *yw = W + wY, *Rcw = W + wRc;
+            double pcol[DX];
+#pragma unroll
+            for (int m = 0; m < DX; m++) pcol[m] = Pw[m * 9 + c];
+#pragma unroll
+            for (int i = 0; i < DX; i++) {  // A = (I - K H) P, column c
+                double a = 0.0;
+#pragma unroll
+                for (int m = 0; m < DX; m++) {
+                    const double d = (i == m) ? 1.0 : 0.0;
+                    const double ikh = m < 6 ? d - Kw[i * 6 + m] : d;
+                    a = (m == 0) ? ikh * pcol[0] : a + ikh * pcol[m];
+                }
+                W[wA + i * 9 + c] = a;
+            }
+            double krow[6];
+#pragma unroll
+            for (int m = 0; m < 6; m++) krow[m] = Kw[c * 6 + m];
+            {  // x = x + K y
+                double a = krow[0] * yw[0];
+#pragma unroll
+                for (int m = 1; m < 6; m++) a += krow[m] * yw[m];
+                double xnew = R[rX + c] + a;
+                if (c == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
+                    const double var = R[rCen] - xnew;
+                    if (!(var == 0.0) && R[rLife] == 0.0) xnew += var * 0.4;
+                }
+                rec->x[c] = xnew;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 6; cc++) {  // C1 = K R, row c, into the S^-1 area (last read before the barrier above)
+                double a = krow[0] * Rcw[cc];
+#pragma unroll
+                for (int m = 1; m < 6; m++) a += krow[m] * Rcw[m * 6 + cc];
+                W[wC1 + c * 6 + cc] = a;
+            }
+        }
+        wave_sync();
+        if (act) {  // P = A (I-KH)^T + C1 K^T, column c
+            const double *Aw = W + wA, *Kw = W + wK, *C1w = W + wC1;
+            double kcc[6], ikh[DX];
+#pragma unroll
+            for (int m = 0; m < 6; m++) kcc[m] = Kw[c * 6 + m];
+#pragma unroll
+            for (int m = 0; m < DX; m++) {
+                const double d = (c == m) ? 1.0 : 0.0;
+                ikh[m] = m < 6 ? d - kcc[m] : d;
+            }
+#pragma unroll
+            for (int i = 0; i < DX; i++) {
+                double b = Aw[i * 9] * ikh[0];
+#pragma unroll
+                for (int m = 1; m < DX; m++) b += Aw[i * 9 + m] * ikh[m];
+                double c2 = C1w[i * 6] * kcc[0];
+#pragma unroll
+                for (int m = 1; m < 6; m++) c2 += C1w[i * 6 + m] * kcc[m];
+                rec->P[i * 9 + c] = b + c2;
+            }
+        }
+        wave_sync();
+        return;
+    }
     if (live) {
         for (int k = c; k < DX * 6; k += LP) {  // K = P H^T S^-1
             const int i = k / 6, cc = k - i * 6;

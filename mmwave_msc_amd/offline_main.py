@@ -30,6 +30,8 @@ def offline_main(experiment_path: str, model=None, on_frame: Optional[Callable] 
         model = MarsCNN.load(os.fspath(model)).to(f"cuda:{device}")
     sensor_data = OfflineManager(experiment_path)
     trackbuffer = TrackBuffer(max_pts=max_pts, device=device)
+    if model is not None and hasattr(model, "has_small_path"):
+        trackbuffer.attach_posture_model(model)   # this loop estimates after every tracked frame: one round trip per frame
     batch = BatchedData()
     first_iter = True
     seen = 0

@@ -147,6 +147,9 @@ class TrackBuffer:
         self.last_db_labels = None   # apply_DBscan labels of the last frame, or None
         self._n_tracks = 0           # len(effective_tracks) after the last frame (came back with the frame's results)
         self._posture = None         # device buffers of estimate_posture's on-device path (a mars.MarsCNN on this GPU)
+        self._raw_buf = None         # track_raw's upload block [1, max_pts, 5]
+        self._fused_model = None     # attach_posture_model: estimate_posture runs inside track() / track_raw()'s round trip
+        self._posture_done = False   # ... and has run for the last frame
 
     def _ensure(self):
         if self._sb is None:
@@ -155,6 +158,29 @@ class TrackBuffer:
             self._dx = const.MOTION_MODEL.KF_DIM[0]
             self._sb = SceneBatch(cfg, 1, self._max_pts, self._device)
         return self._sb
+
+    def attach_posture_model(self, model):
+        """The loop body of offline_main.py:53-60 as ONE round trip: with a `mars.MarsCNN` (3-frame model, on this GPU) attached,
+        `track()` / `track_raw()` queue `estimate_posture(model)` behind the step -- feature tensors, CNN (Keras' fp32 arithmetic)
+        and the keypoint assignment on the device -- before they wait for the frame's results, and the loop's own
+        `estimate_posture(model)` call finds the work done.  A caller that does NOT estimate the posture after every tracked
+        frame should not attach.  None detaches.  Returns True when the model was attached."""
+        sb = self._ensure()
+        if model is None:
+            sb.attach_posture(None)
+            self._fused_model = None
+            return False
+        ok = getattr(model, "has_small_path", lambda: False)() and sb.ring == 3 and sb.track_cap <= 64
+        if ok:
+            p0 = next(model.parameters(), None)
+            ok = p0 is not None and p0.is_cuda and p0.device.index == self._device
+        if not ok:
+            return False
+        import torch
+        torch.cuda.synchronize(self._device)   # (the weights may have been uploaded on another stream a moment ago)
+        sb.attach_posture(model)
+        self._fused_model = model
+        return True
 
     # -- reference API -----------------------------------------------------------
     def track(self, pointcloud, batch: BatchedData):
@@ -172,10 +198,12 @@ class TrackBuffer:
         pts[0, :n] = pc
         # an empty cloud still IS a track() call (predict, ageing / expiry, _update_all, an empty ring frame): the C-ABI's
         # count 0 means "frame skipped" (offline_main.py:56), MMW_EMPTY_FRAME means this.  ONE round trip (mmw_frame_host).
-        r = sb.frame_host(np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]), pts=pts)
+        r = sb.frame_host(np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]), pts=pts,
+                          posture=self._fused_model is not None)
         self._take(r, n)
 
     def _take(self, r, n):
+        self._posture_done = "posture_rows" in r
         dbn = int(r["db_n"][0])
         self.last_assoc = r["assoc"][0, :n].copy()
         self.last_db_labels = r["labels"][0, :dbn].copy() if dbn >= 0 else None
@@ -193,13 +221,16 @@ class TrackBuffer:
             batch._bind(self)
         elif batch is not self._batch:
             raise ValueError("this TrackBuffer is bound to another BatchedData (one global ring per scene)")
-        raw = np.vstack((detObj["x"], detObj["y"], detObj["z"], detObj["doppler"], detObj["peakVal"])).T.astype(np.float64)
-        m = raw.shape[0]
+        m = len(detObj["x"])
         if m > self._max_pts:
             raise ValueError(f"frame has {m} points; TrackBuffer(max_pts={self._max_pts})")
-        buf = np.zeros((1, self._max_pts, 5))
-        buf[0, :m] = raw
-        r = sb.frame_host(np.array([m], np.int32), np.array([float(self.dt)]), raw=buf, want_rows=want_rows)
+        buf = self._raw_buf   # (only the first m rows travel)
+        if buf is None:
+            buf = self._raw_buf = np.zeros((1, self._max_pts, 5))
+        for i, k in enumerate(("x", "y", "z", "doppler", "peakVal")):
+            buf[0, :m, i] = detObj[k]
+        r = sb.frame_host(np.array([m], np.int32), np.array([float(self.dt)]), raw=buf, want_rows=want_rows,
+                          posture=self._fused_model is not None)
         n = int(r["n_out"][0])
         if n > 0:
             self._take(r, n)
@@ -209,6 +240,9 @@ class TrackBuffer:
         """Tracking.py:705-734.  `model` is either a `mars.MarsCNN` (runs on the GPU) or any
         object with a Keras-style `.predict(ndarray[B,3,8,8,5]) -> ndarray[B,57]`."""
         sb = self._ensure()
+        if self._posture_done and model is self._fused_model:
+            self._posture_done = False
+            return   # attach_posture_model: done behind the step, in the frame's own round trip
         if self._n_tracks == 0 and self.last_assoc is not None:
             return   # no track after the last frame: nothing to estimate (known from the frame's own results, no round trip)
         if getattr(model, "use_hip_conv", False) and hasattr(model, "range_overflow"):

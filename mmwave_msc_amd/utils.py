@@ -80,7 +80,7 @@ class OfflineManager:
         while len(self.pointclouds) < want:
             path = os.path.join(self.experiment_path, f"{self.pointer[1]}.csv")
             if not os.path.isfile(path):
-                return
+                break
             stopped_inside = False
             with open(path, "r") as fh:
                 for row_no, row in enumerate(csv.reader(fh)):
@@ -101,6 +101,16 @@ class OfflineManager:
                         break
             if not stopped_inside:
                 self.pointer = [0, self.pointer[1] + 1]
+        self._finish_frames()
+
+    def _finish_frames(self):
+        """The columns of a parsed frame as float64 arrays (the reference keeps Python lists; its live source, ReadDataIWR1443,
+        hands numpy arrays under the same keys): the consumers index and stack them either way, and the per-frame calls do not
+        pay a list -> array conversion of five columns each time (tens of microseconds of a 150 us frame)."""
+        for slot in self.pointclouds.values():
+            for k in self._KEYS[:5]:
+                if isinstance(slot[k], list):
+                    slot[k] = np.asarray(slot[k], dtype=np.float64)
 
     def get_data(self):
         self.frame_count += 1

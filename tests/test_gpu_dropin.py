@@ -225,6 +225,63 @@ def test_offline_loop_fused_calls_and_on_device_posture():
     fused.close(); plain.close()
 
 
+def test_attached_posture_model_one_round_trip_per_frame():
+    """TrackBuffer.attach_posture_model: track_raw() queues estimate_posture behind the step (mmw_frame_posture_host: feature
+    tensors, fp32 CNN and keypoint assignment with a row count only the device knows) and the loop's own estimate_posture() call
+    is a no-op.  Against the unattached loop (the same kernels launched call by call): every keypoint BIT-equal; against the
+    fp64 oracle CNN: within the CNN tolerance; frames that are skipped (no row passes the scene filter) and frames without
+    tracks leave the keypoints alone."""
+    import bench_ingest
+    from mmwave_msc_amd import constants as const
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.synth import make_scene
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    from oracle.mars_np import mars_forward_np
+    w = random_keras_weights(seed=9, frames=3)
+    model = MarsCNN.from_keras_weights(w).to("cuda:0")
+
+    class KerasLike:
+        def predict(self, x, verbose=0):
+            return mars_forward_np(w, np.asarray(x, dtype=np.float64)).astype(np.float32)
+
+    p, c, d = make_scene(91, 16, 220, 3, ragged=True)
+    ang = np.radians(const.S_TILT)
+    raw = bench_ingest.raw_rows_from_normalised(p, float(np.cos(ang)), float(np.sin(ang)), float(const.S_HEIGHT)).astype(np.float64)
+    att, ab = TrackBuffer(max_pts=256), BatchedData()
+    dev, db = TrackBuffer(max_pts=256), BatchedData()
+    ora, ob = TrackBuffer(max_pts=256), BatchedData()
+    assert att.attach_posture_model(model) is True
+    assert att.attach_posture_model(KerasLike()) is False and att._fused_model is model   # (not a MarsCNN: refused, nothing changes)
+    estimated = 0
+    for f in range(16):
+        n = int(c[f])
+        if f == 9:   # a frame none of whose rows pass the scene filter: skipped by the loop (offline_main.py:56), nothing estimated
+            det = {k: [100.0] * 5 for k in ("x", "y", "z", "doppler", "peakVal")}
+        else:
+            det = {k: list(raw[f, :n, i]) for i, k in enumerate(("x", "y", "z", "doppler", "peakVal"))}
+        for tb, bb, m in ((att, ab, model), (dev, db, model), (ora, ob, KerasLike())):
+            tb.dt = float(d[f])
+            kept = tb.track_raw(det, bb)
+            assert (kept == 0) == (f == 9)
+            if kept:
+                if tb is att:
+                    assert tb._posture_done
+                tb.estimate_posture(m)
+                if tb is att:
+                    assert not tb._posture_done
+        ta, td, to = att.effective_tracks, dev.effective_tracks, ora.effective_tracks
+        assert len(ta) == len(td) == len(to), f
+        for x, y, z in zip(ta, td, to):
+            assert np.array_equal(x.state.x, y.state.x) and np.array_equal(x.state.P, y.state.P) and x.uid == y.uid, f
+            assert np.array_equal(x.keypoints, y.keypoints), f
+            assert np.abs(x.keypoints - z.keypoints).max() <= KP_TOL * max(1.0, float(np.abs(z.keypoints).max())), f
+            estimated += int(not np.array_equal(x.keypoints, np.asarray(const.MODEL_DEFAULT_POSTURE, dtype=np.float32)))
+    assert len(att.effective_tracks) >= 2 and estimated >= 10
+    att.attach_posture_model(None)
+    assert att._fused_model is None
+    att.close(); dev.close(); ora.close()
+
+
 def test_device_pointer_posture_path_is_ordered_with_torch():
     """features_dev -> torch CNN -> set_keypoints_dev with NO host synchronisation in between, torch on its default
     stream: the context must run on that very stream (SceneBatch.follow_torch_stream; include/mmw.h
