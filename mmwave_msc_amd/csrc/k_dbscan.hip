@@ -1473,7 +1473,10 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
 // k_dbscan_big (large) follow on the context's stream, take whatever is left and wait for the claimed items to finish --
 // correctness never depends on k_chain having run.  `epoch` = this step's number: k_post raises q[kQStop] to it when it
 // starts, i.e. when no more pushes can come.  Every wait is bounded.
-constexpr int kChainBlocks = 8;
+#ifndef MMW_CHAIN_BLOCKS   // (scripts/chain_blocks.sh: diagnostic builds with another count)
+#define MMW_CHAIN_BLOCKS 12
+#endif
+constexpr int kChainBlocks = MMW_CHAIN_BLOCKS;
 constexpr int kSpinLimit = 1 << 18;  // polls of ~0.3 us: how long a side-stream worker keeps trying to claim from a non-empty queue
 // Waits that MUST succeed (an entry behind its count: a few instructions in the pushing workgroup; the end of a claimed item: one
 // BallTree chain) are bounded by TIME, not by iterations -- the 100 MHz s_memrealtime counter; a slow clock or a profiler that
@@ -2097,7 +2100,8 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
 // The chain workers beside k_track and k_post (a second stream; see k_chain)
 void launch_chain(const DevCfg &cfg, const DevState &st, int UM, int u_bound, int parity, int epoch, int32_t *labels, int32_t *db_n, hipStream_t side)
 {
-    // (4 .. 12 workgroups trade 1 % between the 40- and the 160-frame window: profiles/README.md)
+    // (2 / 4 / 8 / 12 / 16 workgroups, now that the pair counts run in k_track and only BallTree chains arrive: 0.2025 / 0.195 / 0.190 /
+    //  0.189 / 0.190 ms per step in a 100-step window, 0.210 / 0.203 / 0.194 / 0.192 / 0.192 in a 150-step one: profiles/NOTEBOOK.md)
 #ifdef MMW_STAMPS
     static const int want = getenv("MMW_CHAIN_BLOCKS") ? atoi(getenv("MMW_CHAIN_BLOCKS")) : kChainBlocks;  // diagnostic build only
 #else

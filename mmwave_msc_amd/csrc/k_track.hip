@@ -42,11 +42,15 @@ constexpr int kProbeScene = 460;   // (a block index: st.perm puts the scenes wi
 #ifdef MMW_STAMPS_POST
 #define WGTIME(k)
 #else
+// (2048 slots: a launch of more workgroups stamps every second / fourth ... one)
 #define WGTIME(k)                                                                             \
     do {                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.x < 2048) {                                          \
-            st.stats[kStatSlots * kStatWords + 256 + blockIdx.x * 4 + (k) * 2] = __builtin_amdgcn_s_memrealtime(); \
-            st.stats[kStatSlots * kStatWords + 256 + blockIdx.x * 4 + (k) * 2 + 1] = __builtin_amdgcn_s_memtime(); \
+        int wg_sh = 0;                                                                        \
+        while (((int)gridDim.x >> wg_sh) > 2048) wg_sh++;                                     \
+        if (threadIdx.x == 0 && (blockIdx.x & ((1u << wg_sh) - 1)) == 0) {                    \
+            const unsigned wg_slot = blockIdx.x >> wg_sh;                                     \
+            st.stats[kStatSlots * kStatWords + 256 + wg_slot * 4 + (k) * 2] = __builtin_amdgcn_s_memrealtime(); \
+            st.stats[kStatSlots * kStatWords + 256 + wg_slot * 4 + (k) * 2 + 1] = __builtin_amdgcn_s_memtime(); \
         }                                                                                     \
     } while (0)
 #endif
