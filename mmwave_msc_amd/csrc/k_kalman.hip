@@ -42,21 +42,24 @@ __device__ __forceinline__ DenseBins dense_bins(const DevCfg &cfg, const DevStat
 __device__ __forceinline__ bool dense_pick(const DevCfg &cfg, const DevState &st, int parity, const DenseBins &B, int unit, int lane, int g,
                                            int &my_s, int &my_j)
 {
+    // branch-free up to ONE load per lane (four uniform loads behind four branches were four round trips in a row): every lane
+    // ends up with a valid address -- idle groups entry 0 of the fullest bin, and scene 0 / track 0 as their answer
     const int nb = cfg.t_cap;
+    int my_t = nb, my_r = 0;
     bool live = false;
-    my_s = 0; my_j = 0;
+    my_j = 0;
 #pragma unroll
     for (int gg = 0; gg < 4; gg++) {
         const int k = unit * 4 + gg;  // uniform
         const unsigned long long hit = __ballot(lane < nb && B.incl > k);
-        if (k < B.total && hit) {
-            const int b = __ffsll((long long)hit) - 1;  // first bin whose inclusive count exceeds k
-            const int base = __shfl(B.excl, b), t = nb - b;
-            const int rel = k - base, r = rel / t, j = rel - r * t;
-            const int sc = st.upd_list[((size_t)parity * (cfg.t_cap + 1) + t) * cfg.n_scenes + r];
-            if (g == gg) { my_s = sc; my_j = j; live = true; }
-        }
+        const bool valid = k < B.total && hit != 0;
+        const int b = valid ? __ffsll((long long)hit) - 1 : 0;  // first bin whose inclusive count exceeds k
+        const int base = __shfl(B.excl, b), t = nb - b;
+        const int rel = valid ? k - base : 0, r = rel / t, j = rel - r * t;
+        if (g == gg) { my_t = t; my_r = r; my_j = j; live = valid; }
     }
+    const int sc = st.upd_list[((size_t)parity * (cfg.t_cap + 1) + my_t) * cfg.n_scenes + my_r];
+    my_s = live ? sc : 0;
     return live;
 }
 
@@ -69,7 +72,7 @@ __device__ __forceinline__ bool dense_pick(const DevCfg &cfg, const DevState &st
 // An empty frame (n_pts <= 0) predicts nothing (offline_main.py:56: such frames never reach track()).
 constexpr int kSpecialUnits = 64;
 template <int DX>
-__global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts,
+__global__ __launch_bounds__(64, 4) void k_predict(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts,
                                                 const double *__restrict__ dt_all, int nq, int parity)
 {
     __shared__ double lds[4 * kPredScratch];
@@ -82,22 +85,25 @@ __global__ __launch_bounds__(64) void k_predict(DevCfg cfg, DevState st, const i
         //  -- the kSpecialUnits behind the dense range always, and the idle rest of the dense range: after a frame in which
         //  EVERY scene spawned tracks, the first frames after a reset, that is all of them; 64 waves alone took 555 us for the
         //  4096 scenes of the start-up -- serves the two lists below)
+        // (the dependent round trips of a wave -- total, bin counts, list entry, scene words, slot, record -- are what this launch
+        //  lasts, at 20 waves per CU: the bin counts are requested with the total, the scene's four words together: 6 -> 4)
         const int total = st.upd_count[(size_t)prev * (cfg.t_cap + 1)];
+        const DenseBins B = dense_bins(cfg, st, prev, lane);
         int nd = (total + 3) >> 2;
         nd = nd < n_dense ? nd : n_dense;
         if ((int)blockIdx.x < nd) {
-            const DenseBins B = dense_bins(cfg, st, prev, lane);
             for (int unit = blockIdx.x; unit * 4 < B.total; unit += n_dense) {
                 int s, j;
-                bool live = dense_pick(cfg, st, prev, B, unit, lane, g, s, j);
-                const int n = n_pts[s];
+                bool live = dense_pick(cfg, st, prev, B, unit, lane, g, s, j);   // (idle groups: s = j = 0)
+                const int n = n_pts[s], nt = st.hdr[s].n_tracks, slot = st.order[(size_t)s * cfg.t_cap + j];
+                const double dt = dt_all[s];
                 // (j < n_tracks: a scene that mmw_reset_scenes has emptied since the lists were built holds no track -- its
                 //  stale records must not be predicted, nor their error bits come back on the fresh scene)
-                live = live && frame_reaches_track(n, cfg.max_pts) && j < st.hdr[s].n_tracks;
+                live = live && frame_reaches_track(n, cfg.max_pts) && j < nt;
                 if (!__any(live)) continue;
-                TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? st.order[(size_t)s * cfg.t_cap + j] : 0);
+                TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? slot : 0);
                 int e1 = 0;
-                predict_one_track<DX>(cfg, st, rec, live, s, j, dt_all[s], Wj, lane, c, e1);
+                predict_one_track<DX>(cfg, st, rec, live, s, j, dt, Wj, lane, c, e1);
                 if (e1 && live) atomicOr(&st.hdr[s].err, e1);
             }
             return;

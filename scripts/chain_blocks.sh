@@ -1,8 +1,8 @@
 # usage: bash scripts/chain_blocks.sh -- the step with 2 / 4 / 8 DBSCAN workgroups on the side stream (make DIAG=cb2 DIAGFLAGS=-DMMW_CHAIN_BLOCKS=2, ...)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 for R in 1 2; do
-for L in libmmw_hip.so libmmw_hip_cb12.so libmmw_hip_cb16.so; do
-  for W in "--steps 100 --warmup 20" "--steps 150 --warmup 10"; do
+for L in libmmw_hip.so; do
+  for W in "--steps 100 --warmup 20"; do
   MMW_LIB_NAME=$L python3 bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --no-shards --no-full --no-ingest --no-single $W > gpurun_out/cb.json 2> gpurun_out/cb.err
   python3 - <<PY
 import json
