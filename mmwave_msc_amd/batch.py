@@ -63,6 +63,8 @@ class SceneBatch:
         self.track_cap, self.ring, self.ring_rows = dims[2].value, dims[3].value, dims[4].value
         self.UM = self.ring * self.max_pts
         self._bufs = {}
+        self._frame_out = None      # frame_host(reuse_out=True): the result arrays of the last call
+        self._posture_model = None
 
     # -- plumbing -------------------------------------------------------------
     def _chk(self, rc):
@@ -225,7 +227,7 @@ class SceneBatch:
         self._posture_model = model   # (keeps the tensors alive)
 
     def frame_host(self, n: np.ndarray, dt: np.ndarray, raw: np.ndarray = None, pts: np.ndarray = None, want_rows: bool = False,
-                   want_labels: bool = True, posture: bool = False):
+                   want_labels: bool = True, posture: bool = False, reuse_out: bool = False):
         """mmw_frame_host: one frame of every scene from host memory in ONE round trip.  `raw`[S,NP,5] radar rows (normalised
         on the device, Utils.normalize_data) or `pts`[S,NP,8] normalised rows; n[S], dt[S].  Returns a dict: assoc[S,NP],
         db_n[S], n_out[S] (rows that reached track()), n_tracks[S], labels[S,UM] (want_labels), rows[S,NP,8] (want_rows, raw form)."""
@@ -234,12 +236,21 @@ class SceneBatch:
         assert src.shape == (self.S, self.max_pts, 5 if raw is not None else 8), src.shape
         n = np.ascontiguousarray(n, dtype=np.int32)
         dt = np.ascontiguousarray(dt, dtype=np.float64)
-        out = {"assoc": np.full((self.S, self.max_pts), -1, dtype=np.int32), "db_n": np.full(self.S, -1, dtype=np.int32),
-               "n_out": np.zeros(self.S, dtype=np.int32), "n_tracks": np.zeros(self.S, dtype=np.int32)}
-        if want_labels:
-            out["labels"] = np.full((self.S, self.UM), -1, dtype=np.int32)
+        if reuse_out and self._frame_out is not None:
+            out = self._frame_out   # (the caller copies what it keeps before the next call: TrackBuffer)
+            out.pop("posture_rows", None)
+        else:
+            out = {"assoc": np.full((self.S, self.max_pts), -1, dtype=np.int32), "db_n": np.full(self.S, -1, dtype=np.int32),
+                   "n_out": np.zeros(self.S, dtype=np.int32), "n_tracks": np.zeros(self.S, dtype=np.int32),
+                   "labels": np.full((self.S, self.UM), -1, dtype=np.int32)}
+            if reuse_out:
+                self._frame_out = out
+        if not want_labels and not reuse_out:
+            out.pop("labels")
         if want_rows and raw is not None:
             out["rows"] = np.zeros((self.S, self.max_pts, 8))
+        elif "rows" in out:
+            out.pop("rows")
         args = (self.h, src.ctypes.data if raw is not None else None, src.ctypes.data if raw is None else None,
                 n.ctypes.data, dt.ctypes.data, out["rows"].ctypes.data if "rows" in out else None,
                 out["n_out"].ctypes.data, out["assoc"].ctypes.data,

@@ -105,7 +105,7 @@ struct mmw_ctx {
     // host-convenience staging (lazy): one device block in [rows | dt | n], one out [assoc | db_n | n_out | labels], their pinned
     // host mirrors, and pinned copies of the scene headers and the queue words -- mmw_frame_host moves each with ONE copy
     char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
-    double *d_raw = nullptr;          // [S][max_pts][5] raw rows of the fused normalise + track form
+    double *d_raw = nullptr;          // [S][max_pts][8]: normalize_data's rows in the raw form of mmw_frame_host (the raw rows arrive in d_in's row area)
     SceneHdr *h_hdr = nullptr;        // pinned [S]
     int32_t *h_q = nullptr;           // pinned [kQWords]
     double *d_pts = nullptr; int32_t *d_n = nullptr; double *d_dt = nullptr;      // (views into d_in / d_out)
@@ -732,10 +732,10 @@ static StageLayout stage_layout(const mmw_ctx *c)
     const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     StageLayout L;
-    L.in_rows = 0;
-    L.in_dt = al(S * NP * 8 * sizeof(double));
-    L.in_n = L.in_dt + al(S * sizeof(double));
-    L.in_bytes = L.in_n + al(S * sizeof(int32_t));
+    L.in_dt = 0;   // [dt | n | rows]: the two small arrays in front, so that a frame's upload is ONE copy that ends with its last valid row
+    L.in_n = al(S * sizeof(double));
+    L.in_rows = L.in_n + al(S * sizeof(int32_t));
+    L.in_bytes = L.in_rows + al(S * NP * 8 * sizeof(double));
     L.out_assoc = 0;
     L.out_dbn = al(S * NP * sizeof(int32_t));
     L.out_nout = L.out_dbn + al(S * sizeof(int32_t));
@@ -752,7 +752,7 @@ static int ensure_host_staging(mmw_ctx *c)
     const size_t S = c->dc.n_scenes, NP = c->dc.max_pts;
     HIPCHK(c, hipMalloc((void **)&c->d_in, L.in_bytes));
     HIPCHK(c, hipMalloc((void **)&c->d_out, L.out_bytes));
-    HIPCHK(c, hipMalloc((void **)&c->d_raw, S * NP * 5 * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_raw, S * NP * 8 * sizeof(double)));   // (the raw form: normalize_data's rows, what the step reads)
     HIPCHK(c, hipHostMalloc((void **)&c->h_in, L.in_bytes, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&c->h_out, L.out_bytes, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&c->h_hdr, S * sizeof(SceneHdr), hipHostMallocDefault));
@@ -796,16 +796,15 @@ static int frame_impl(mmw_ctx *c, const double *raw, const double *pts, const in
     }
     memcpy(c->h_in + L.in_dt, dt, S * sizeof(double));
     memcpy(c->h_in + L.in_n, n, S * sizeof(int32_t));
+    HIPCHK(c, hipMemcpyAsync(c->d_in, c->h_in, L.in_rows + rows_span, hipMemcpyHostToDevice, c->stream));   // [dt | n | rows up to the last valid one]
+    double *d_rows = c->d_pts;   // what the step reads
     if (raw) {
-        if (rows_span) HIPCHK(c, hipMemcpyAsync(c->d_raw, h_rows, rows_span, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_in + L.in_dt, c->h_in + L.in_dt, L.in_bytes - L.in_dt, hipMemcpyHostToDevice, c->stream));
-        rc = mmw_normalize(c, c->d_raw, c->d_n, c->d_pts, c->d_nout);
+        d_rows = c->d_raw;
+        rc = mmw_normalize(c, c->d_pts, c->d_n, d_rows, c->d_nout);   // (the raw rows sit in the row area of the upload block)
         if (rc) return rc;
-        rc = mmw_step(c, c->d_pts, c->d_nout, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
+        rc = mmw_step(c, d_rows, c->d_nout, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
     } else {
-        if (rows_span) HIPCHK(c, hipMemcpyAsync(c->d_in, c->h_in, rows_span, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_in + L.in_dt, c->h_in + L.in_dt, L.in_bytes - L.in_dt, hipMemcpyHostToDevice, c->stream));
-        rc = mmw_step(c, c->d_pts, c->d_n, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
+        rc = mmw_step(c, d_rows, c->d_n, c->d_dt, c->d_assoc, c->d_labels, c->d_dbn);
     }
     if (rc) return rc;
     if (posture) {
@@ -829,7 +828,7 @@ static int frame_impl(mmw_ctx *c, const double *raw, const double *pts, const in
     double *h_pts_out = nullptr;
     if (raw && pts_out) {   // normalize_data's rows (the reference's `effective_data`): into the pinned row area, now free again
         h_pts_out = reinterpret_cast<double *>(c->h_in + L.in_rows);
-        HIPCHK(c, hipMemcpyAsync(h_pts_out, c->d_pts, S * NP * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_pts_out, d_rows, S * NP * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (assoc) memcpy(assoc, c->h_out + L.out_assoc, S * NP * sizeof(int32_t));

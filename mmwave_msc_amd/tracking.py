@@ -199,7 +199,7 @@ class TrackBuffer:
         # an empty cloud still IS a track() call (predict, ageing / expiry, _update_all, an empty ring frame): the C-ABI's
         # count 0 means "frame skipped" (offline_main.py:56), MMW_EMPTY_FRAME means this.  ONE round trip (mmw_frame_host).
         r = sb.frame_host(np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]), pts=pts,
-                          posture=self._fused_model is not None)
+                          posture=self._fused_model is not None, reuse_out=True)
         self._take(r, n)
 
     def _take(self, r, n):
@@ -230,7 +230,7 @@ class TrackBuffer:
         for i, k in enumerate(("x", "y", "z", "doppler", "peakVal")):
             buf[0, :m, i] = detObj[k]
         r = sb.frame_host(np.array([m], np.int32), np.array([float(self.dt)]), raw=buf, want_rows=want_rows,
-                          posture=self._fused_model is not None)
+                          posture=self._fused_model is not None, reuse_out=True)
         n = int(r["n_out"][0])
         if n > 0:
             self._take(r, n)
