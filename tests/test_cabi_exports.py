@@ -38,6 +38,7 @@ def test_config_struct_matches_header_layout():
     assert L.mmw_version().startswith(b"mmw-hip")
     assert C.sizeof(_lib.MmwConfig) == 8 * 4 + 24 * 8 + 57 * 4 + 5 * 4 + 8 * 8 + 2 * 4  # 8 ints, 24 doubles, 57 floats, 5 ints, 8 doubles, 2 ints
     assert cfg.fused_step == 0 and cfg.chain_side_stream == 0
+    assert C.sizeof(_lib.MmwPostureModel) == 9 * 8   # struct mmw_posture_model: eight pointers and one int64
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():

@@ -282,6 +282,39 @@ def test_attached_posture_model_one_round_trip_per_frame():
     att.close(); dev.close(); ora.close()
 
 
+def test_attach_posture_refuses_what_it_cannot_run():
+    """mmw_attach_posture / mmw_frame_posture_host argument errors are loud: a context of several scenes, another ring length, a
+    frame before any model was attached, null weight pointers."""
+    import ctypes as C
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    model = MarsCNN.from_keras_weights(random_keras_weights(seed=2, frames=3)).to("cuda:0")
+    two = SceneBatch(_lib.default_config(), 2, 64)
+    with pytest.raises(_lib.MmwError) as e:
+        two.attach_posture(model)
+    assert e.value.code == _lib.E_ARG and "one-scene" in str(e.value)
+    two.close()
+    short = SceneBatch(_lib.default_config(fb_frames_batch=1), 1, 64)   # ring of 2 frames: not the 3-frame model's
+    with pytest.raises(_lib.MmwError):
+        short.attach_posture(model)
+    short.close()
+    one = SceneBatch(_lib.default_config(), 1, 64)
+    n, dt, pts = np.array([4], np.int32), np.array([0.1]), np.zeros((1, 64, 8))
+    with pytest.raises(_lib.MmwError) as e:
+        one.frame_host(n, dt, pts=pts, posture=True)
+    assert e.value.code == _lib.E_ARG and "no model attached" in str(e.value)
+    m = _lib.MmwPostureModel()   # all pointers null
+    assert one.L.mmw_attach_posture(one.h, C.byref(m)) == _lib.E_ARG
+    one.attach_posture(model)
+    r = one.frame_host(n, dt, pts=pts, posture=True)
+    assert r["posture_rows"] == 0   # (four points: no track yet)
+    one.attach_posture(None)
+    with pytest.raises(_lib.MmwError):
+        one.frame_host(n, dt, pts=pts, posture=True)
+    one.close()
+
+
 def test_device_pointer_posture_path_is_ordered_with_torch():
     """features_dev -> torch CNN -> set_keypoints_dev with NO host synchronisation in between, torch on its default
     stream: the context must run on that very stream (SceneBatch.follow_torch_stream; include/mmw.h

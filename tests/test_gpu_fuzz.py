@@ -13,7 +13,7 @@ order, every fp64 field of every track, ring lengths, the global ring, inner-clu
 import numpy as np
 import pytest
 
-from tests._fuzz import N_CASES, draw_case, scene_inputs
+from tests._fuzz import N_CASES, SEED0, draw_case, scene_inputs
 from tests._golden import assert_tracks_match
 from tests._layouts import LAYOUTS, make_checked
 
@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
-@pytest.mark.parametrize("seed", range(N_CASES))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_CASES))
 def test_random_configuration_vs_oracle(seed, layout):
     from mmwave_msc_amd import _lib
     from oracle import c_oracle as co

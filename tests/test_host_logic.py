@@ -18,6 +18,9 @@ def test_offline_manager_matches_reference_sequence(tmp_path):
     seq = []
     while not man.is_finished():
         ok, fc, det = man.get_data()
+        if ok:   # the five columns as float64 arrays (the reference: lists; same keys, same values), posix as the reference has it
+            assert all(isinstance(det[k], np.ndarray) and det[k].dtype == np.float64 and det[k].shape == det["x"].shape
+                       for k in ("x", "y", "z", "doppler", "peakVal")) and len(det["posix"]) == len(det["x"])
         seq.append((1, fc, len(det["x"]), det["posix"][0]) if ok else (0, fc, 0, 0))
     want = z["seq"]
     assert len(seq) == len(want)
