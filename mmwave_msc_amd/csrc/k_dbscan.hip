@@ -1549,7 +1549,7 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
 // The clouds of more than 256 points (a scene without tracks clusters its whole ring: the start-up frames, and every scene
 // whose tracks have all expired): 100-250 us of BallTree chain each on a 512-thread workgroup.  They sit in a queue k_track
 // fills while it runs (q[kQBig + ...], ring = list 1).  Consumers:
-//   k_chain           eight workgroups on a side stream, BESIDE k_track and k_post, for this queue and the small clouds'
+//   k_chain           twelve workgroups on a side stream, BESIDE k_track and k_post, for this queue and the small clouds'
 //                     (claims by compare-and-swap, leaves when k_post has begun and both queues are empty; not in the
 //                     start-up frames, whose pushes carry no release: cfg.big_live);
 //   k_dbscan_big      behind k_post on the context's stream: takes what is left (tickets by atomicAdd: the pushes are
@@ -1689,10 +1689,10 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
 }
 
 // k_post: what follows the association of a frame, in ONE launch of 256-thread workgroups of two kinds:
-//   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the scenes of work list 3 (clouds of
-//                    <= 256 points k_track's cell count could not rule out): the exact pair count, then for
-//                    the handful of scenes per step that survive it the BallTree, a latency chain of ~60 us
-//                    that would otherwise leave the chip idle;
+//   blocks [0, G0)   apply_DBscan + _add_tracks (Tracking.py:697-703) for the clouds of <= 256 points k_track's / k_scene's
+//                    screens could not rule out (work list 3, and what k_chain has left of queue 0): the exact pair
+//                    count once more (a few microseconds, for the handful of scenes per step that arrive), then the
+//                    BallTree, a latency chain of ~60 us that would otherwise leave the chip idle;
 //   block G0         next frame's schedule for k_track (post_schedule_sort above; not in the fused step)
 //   the others       _update_all (Tracking.py:598-603) of four (scene, quarter) units each, one wave per unit
 //                    (update_tracks_wave, mmw_kalman.hpp) -- the bulk work the BallTree scenes hide under.

@@ -693,7 +693,7 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
     if (c->dc.side_worker) {
         // No event between the two streams: the side stream paces itself -- the workers of step f leave when k_post(f) has raised
         // its stop epoch, the workers of step f + 1 start behind them and find empty queues until k_track(f + 1) pushes (idle polls
-        // with s_sleep: eight workgroups, ~70 us early in a back-to-back loop).  The event recorded at the head of every step (so
+        // with s_sleep: twelve workgroups, ~70 us early in a back-to-back loop).  The event recorded at the head of every step (so
         // that they would not start early) was a marker packet on the context's stream: 7 us of idle chip per step in the
         // kernel trace (profiles/NOTEBOOK.md, round 4).  gate_side = 1 (callers with their own work on the context's stream,
         // mmw_config.chain_side_stream = 3) keeps the event.
