@@ -956,6 +956,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         }
     }
     PROBE(9);
+    STAMP(10);  // DBSCAN screens + push
     if (tid == 0 && st.stats) {
         // algorithmic bytes of this scene-frame: points in, assoc out, per track the gate record
         // and the record fields this kernel reads and writes, unassigned rows appended to the global ring, rows

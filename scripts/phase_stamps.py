@@ -25,9 +25,9 @@ sb.synchronize()
 out = np.zeros(32, dtype=np.uint64)
 sb._chk(sb.L.mmw_stats_get_ext(sb.h, out.ctypes.data))
 names_t = ["stage points", "gate records -> LDS", "gating", "class split", "centroid/minmax/spread", "dispersion D",
-           "track-ring rows+barrier", "maintenance", "update", "global ring append"]
+           "track-ring rows+barrier", "maintenance", "update", "global ring append", "DBSCAN screens + push"]
 frames = float(out[2])
-tot = float(out[8:18].sum())
+tot = float(out[8:19].sum())
 print(f"k_track: {frames:.0f} scene-frames, mean cycles/WG {tot / frames:.0f}")
 for i, nme in enumerate(names_t):
     print(f"  {nme:28s} {float(out[8 + i]) / frames:9.0f} cyc  {100 * float(out[8 + i]) / tot:5.1f} %")
