@@ -126,6 +126,10 @@ struct mmw_ctx {
 };
 
 constexpr int kTickets = 4;
+// Contexts of at least this many scenes run the DBSCAN chain workers on a side stream unless told otherwise (mmw_config.chain_side_stream = 0).
+// 1536 while every step recorded an event for them (round 3: 1024 / 1280 scenes 91 -> 96 us with them); without that event
+// 768 / 1024 / 1280 scenes: 0.0927 / 0.1108 / 0.1259 ms per step without, 0.0919 / 0.0969 / 0.1099 with (scripts/side_threshold.sh).
+constexpr int kSideWorkerMinScenes = 1024;
 
 static int fail(mmw_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -322,7 +326,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.var_ring = 0;
     // the BallTree chain workers beside k_track on a second stream: for contexts large enough that k_track is a long launch
     // (a small context's whole step is shorter than a chain), and not with seek_inner (k_inner may cancel queued scenes)
-    d.side_worker = (!d.seek_inner && (cfg->chain_side_stream > 0 || (cfg->chain_side_stream == 0 && n_scenes >= 1536))) ? 1 : 0;
+    d.side_worker = (!d.seek_inner && (cfg->chain_side_stream > 0 || (cfg->chain_side_stream == 0 && n_scenes >= kSideWorkerMinScenes))) ? 1 : 0;
     d.fused = 0;   // (decided below, once the track capacity is known)
     if (d.seek_inner) {
         // seek_inner_clusters clusters whole ring frames, and the first frame of a track it spawns is a cluster of up to
