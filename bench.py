@@ -258,7 +258,7 @@ def main():
     ap.add_argument("--no-e2e-parity", action="store_true", help="skip the configs[3] end-to-end parity leg")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start (frames 0..3) leg")
     ap.add_argument("--chain-side-stream", type=int, default=0, choices=(-1, 0, 1, 2, 3),
-                    help="mmw_config.chain_side_stream: 0 = the library's choice (on from 1024 scenes), 1 = on, -1 = off, "
+                    help="mmw_config.chain_side_stream: 0 = the library's choice (on above 512 scenes), 1 = on, -1 = off, "
                          "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
     ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")

@@ -78,7 +78,7 @@ typedef struct mmw_config {
     double tilt_sin;                /* sin(radians(S_TILT)) */
     float default_posture[MMW_NKP]; /* MODEL_DEFAULT_POSTURE :112-172 */
     int32_t kalman_dense_min_units; /* not a reference constant: layout of the Kalman kernels.  0 = automatic (laid out over tracks
-                                       when the context holds more than 768 scenes and > 1024 four-track waves; smaller contexts run
+                                       when the context holds more than 512 scenes and > 1024 four-track waves; smaller contexts run
                                        a two-launch step per scene), < 0 = always per scene, n > 0 = over tracks from n waves on
                                        (tests run both layouts) */
     int32_t seek_inner;             /* 0 = Tracking.py:656 stays commented out (the reference as shipped); 1 = run
@@ -86,7 +86,7 @@ typedef struct mmw_config {
     int32_t db_points_thres;        /* DB_POINTS_THRES :76   (seek_inner_clusters) */
     int32_t fb_frames_batch_static; /* FB_FRAMES_BATCH_STATIC :67 */
     int32_t chain_side_stream;      /* not a reference constant: where the small-cloud DBSCAN (pair-count screen, BallTree chain) of a
-                                       frame runs.  0 = automatic (contexts of >= 1024 scenes: worker blocks on a second stream beside
+                                       frame runs.  0 = automatic (contexts of > 512 scenes: worker blocks on a second stream beside
                                        the association kernel, whatever they have not taken by its end in the post kernel), -1 = post
                                        kernel only, 1 = always with the side stream (tests run both), 2 = as 1 without the check that
                                        the side stream really runs beside the context's (profilers that serialise kernels fail it: the

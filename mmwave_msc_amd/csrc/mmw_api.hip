@@ -126,10 +126,18 @@ struct mmw_ctx {
 };
 
 constexpr int kTickets = 4;
-// Contexts of at least this many scenes run the DBSCAN chain workers on a side stream unless told otherwise (mmw_config.chain_side_stream = 0).
-// 1536 while every step recorded an event for them (round 3: 1024 / 1280 scenes 91 -> 96 us with them); without that event
-// 768 / 1024 / 1280 scenes: 0.0927 / 0.1108 / 0.1259 ms per step without, 0.0919 / 0.0969 / 0.1099 with (scripts/side_threshold.sh).
-constexpr int kSideWorkerMinScenes = 1024;
+// Contexts of more than kPerSceneMaxScenes scenes run the Kalman kernels laid out over tracks and the DBSCAN chain workers on a side
+// stream unless told otherwise (mmw_config.kalman_dense_min_units = 0, chain_side_stream = 0).  Round 3 had the workers from 1536
+// scenes (every step recorded an event for them: 1024 / 1280 scenes 91 -> 96 us with them) and the per-scene, two-launch step up
+// to 768.  Without that event (scripts/side_threshold.sh, scripts/layout_ab.py; ms per step, same box):
+//   scenes                              576     640     768     896     1024    1280
+//   round-3 choice, frames 20..120      -       0.0822  0.0899  0.0985  0.1108  0.1259
+//   track-wise + side stream            -       0.0720  0.0809  0.0878  0.0969  0.1099
+//   round-3 choice, frames 10..50       0.0646  0.0646  0.0676  0.0737  -       -
+//   track-wise + side stream            0.0581  0.0599  0.0653  0.0740  -       -
+// At 512 and below the one-workgroup step / the two-launch step stay ahead in the early window (0.0505 vs 0.0557 at 512).
+constexpr int kPerSceneMaxScenes = 512;
+constexpr int kSideWorkerMinScenes = kPerSceneMaxScenes + 1;
 
 static int fail(mmw_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -347,7 +355,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     d.t_cap = cap; d.max_pts = max_pts; d.n_scenes = n_scenes;
     // layout of the Kalman kernels (mmw_kalman.hpp: tracks_dense): laid out over tracks when the context holds more
     // four-track waves than this; 0 = the default threshold (one wave per CU x 4), < 0 = always per scene
-    d.dense_min_units = cfg->kalman_dense_min_units == 0 ? (n_scenes <= kSmallContextScenes ? 0x7fffffff : 1024)   // (small contexts: per scene, two-launch step)
+    d.dense_min_units = cfg->kalman_dense_min_units == 0 ? (n_scenes <= kPerSceneMaxScenes ? 0x7fffffff : 1024)   // (small contexts: per scene, two-launch step)
                                                          : (cfg->kalman_dense_min_units < 0 ? 0x7fffffff : cfg->kalman_dense_min_units - 1);
     if (d.seek_inner) d.dense_min_units = 0x7fffffff;  // k_inner changes a scene's track count between k_track and k_post: per-scene layout
     d.db_z_weight = cfg->db_z_weight; d.db_range_weight = cfg->db_range_weight; d.db_eps = cfg->db_eps;

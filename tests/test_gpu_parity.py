@@ -25,7 +25,7 @@ def kalman_layout(request):
     """Every test of this file runs under the four kernel layouts (tests/_layouts.py): the bulk kernels with the Kalman
     kernels per scene, the same laid out over tracks (by default only for contexts with more than 1024 four-track waves,
     mmw_config.kalman_dense_min_units), a third time with the small-cloud DBSCAN workers on the side stream (k_chain beside
-    k_track, mmw_config.chain_side_stream: by default only for contexts of >= 1024 scenes), and a fourth time with the
+    k_track, mmw_config.chain_side_stream: by default only for contexts of more than 512 scenes), and a fourth time with the
     one-workgroup step (k_scene.hip, mmw_config.fused_step: by default only for contexts of 257..512 scenes).  A context
     whose configuration forbids the layout is SKIPPED with the reason, never run as a duplicate of another layout."""
     _LAYOUT["name"] = request.param
