@@ -101,8 +101,8 @@ typedef struct mmw_config {
     double v_screen_fade_size_max;  /* V_SCREEN_FADE_SIZE_MAX :48 */
     double v_screen_fade_size_min;  /* V_SCREEN_FADE_SIZE_MIN :49 */
     double v_screen_fade_weight;    /* V_SCREEN_FADE_WEIGHT :50 */
-    int32_t fused_step;             /* not a reference constant: which kernels make a step.  0 = automatic: a context of 257..512 scenes
-                                       whose scenes are all resident at once, two workgroups per CU (<= 512 points per frame), runs
+    int32_t fused_step;             /* not a reference constant: which kernels make a step.  0 = automatic: a context of <= 512 scenes
+                                       whose scenes are all resident at once (two workgroups per CU up to 512 points per frame), runs
                                        TrackBuffer.track of a scene in ONE workgroup start to finish (k_scene: the step is one scene's
                                        latency there), others the bulk kernels; 1 = the one-workgroup step whenever the configuration
                                        allows it (not with seek_inner, resized rings, track_cap > 63 or the side-stream workers);

@@ -371,16 +371,16 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     {
         // The one-workgroup step (k_scene.hip): a scene's whole track() in one workgroup, for contexts whose scenes are all
         // resident at once, two workgroups per CU -- there a step is one scene's latency, and one launch boundary less is
-        // what pays: measured on one box, 512 scenes x 512 points x 8 tracks 0.0617 -> 0.0588 ms per step; at 256 scenes
-        // (one workgroup per CU either way) the two-launch step wins, 0.0448 against 0.0477 ms -- the update is 7 us of chain
-        // inside k_scene and 4 us over k_post's floor as a batched launch.  Hence "automatic" = more than one workgroup per CU
-        // and all of them resident.  Not with seek_inner (k_inner sits between association and update), the side-stream
-        // workers (they claim scenes while the association kernel runs) or more than 63 tracks per scene (a lane per track in
-        // its maintenance step).
+        // what pays: measured on one box, 512 scenes x 512 points x 8 tracks 0.0617 -> 0.0588 ms per step.  (Round 3 kept the
+        // two-launch step up to 256 scenes -- 0.0448 against 0.0477 ms then; round 4, scripts/fused_small.sh: 64 / 128 / 256
+        // scenes x 256 points x 4 tracks 0.0355 / 0.0364 / 0.0414 two-launch against 0.0305 / 0.0313 / 0.0366 ms, 128 / 256
+        // scenes x 512 x 8 equal.)  Hence "automatic" = all scenes resident at once, up to kPerSceneMaxScenes.  Not with
+        // seek_inner (k_inner sits between association and update), the side-stream workers (they claim scenes while the
+        // association kernel runs) or more than 63 tracks per scene (a lane per track in its maintenance step).
         const size_t sl = scene_lds_bytes(d);
         const int per_cu = sl <= 80 * 1024 ? 2 : (sl <= 160 * 1024 ? 1 : 0);
         const bool can = per_cu > 0 && !d.seek_inner && d.t_cap <= 63 && cfg->chain_side_stream <= 0;
-        const bool want = cfg->fused_step > 0 || (cfg->fused_step == 0 && cfg->kalman_dense_min_units == 0 && per_cu == 2 && n_scenes > 256 && n_scenes <= 512);
+        const bool want = cfg->fused_step > 0 || (cfg->fused_step == 0 && cfg->kalman_dense_min_units == 0 && n_scenes <= 256 * per_cu && n_scenes <= kPerSceneMaxScenes);
         c->fused_wanted = d.fused = (can && want) ? 1 : 0;
         if (d.fused) { d.dense_min_units = 0x7fffffff; d.side_worker = 0; }
     }
