@@ -198,7 +198,7 @@ class MarsCNN(nn.Module):
     # of 4 KB, which spreads a tile's rows over the L2 channels (k_mars_dense1 1.144 -> 1.093 ms at 18 k rows)
     ROW_PAD = 256
 
-    def _hip_convs_split(self, x: torch.Tensor) -> torch.Tensor:
+    def _hip_convs_split(self, x: torch.Tensor, sflags: torch.Tensor | None = None) -> torch.Tensor:
         """The conv pair on the fp16 matrix cores with split operands (mmw_mars_conv_split), the activation already split
         for Dense-1: (B, 2 * flat) fp16, halves interleaved in runs of 32 (interleave_split), flat = frames * 2048 in (d,h,w,c)
         order.  The result is a VIEW: its rows are 2 * flat + ROW_PAD apart and the storage holds whole 256-row tiles (the rows
@@ -210,8 +210,11 @@ class MarsCNN(nn.Module):
         rows = (x.shape[0] + 255) // 256 * 256
         ld = 2 * flat + self.ROW_PAD
         out = torch.empty((rows, ld), dtype=torch.float16, device=x.device)
-        sflags = None
-        if self.has_range_fixup():   # the list the fp32 fix-up behind Dense-2 works off (forward): [count, taken, 64 sample indices]
+        # the list the fp32 fix-up behind Dense-2 works off (forward): [count, taken, 64 sample indices] -- the model's own, or the
+        # caller's (posture.PosturePipeline keeps one per frame in flight and runs the fix-up on another stream)
+        if sflags is not None:
+            sflags = sflags.data_ptr()
+        elif self.has_range_fixup():
             if self._sflags is None or self._sflags.device != x.device:
                 self._sflags = torch.zeros((2 + 64,), dtype=torch.int32, device=x.device)
             sflags = self._sflags.data_ptr()
@@ -246,7 +249,18 @@ class MarsCNN(nn.Module):
         """The split arithmetic repairs itself (3-frame model): samples that left fp16's range are recomputed in fp32 on the device."""
         return self.use_hip_conv_f32
 
-    def _range_fixup(self, x: torch.Tensor, kp: torch.Tensor):
+    def new_fixup_list(self, device) -> torch.Tensor:
+        """A fix-up list of its own for a caller that keeps several frames in flight (forward(..., fixup=False, sflags=...) then
+        range_fixup(..., sflags=...) for the same frame, on any stream ordered behind that forward)."""
+        return torch.zeros((2 + 64,), dtype=torch.int32, device=device)
+
+    def range_fixup(self, x: torch.Tensor, kp: torch.Tensor, sflags: torch.Tensor):
+        """The repair forward(..., fixup=False, sflags=sflags) left out, on torch's current stream: rows of kp[n][57] whose samples
+        left fp16's range recomputed in fp32 from x[n] (the same feature tensors)."""
+        if self.has_range_fixup():
+            self._range_fixup(x, kp, sflags)
+
+    def _range_fixup(self, x: torch.Tensor, kp: torch.Tensor, sflags: torch.Tensor | None = None):
         """mmw_mars_range_fixup behind a split-arithmetic forward: the flagged samples' rows of kp recomputed in Keras' fp32 -- no host
         wait; a batch without such samples pays four empty launches."""
         from . import _lib
@@ -254,7 +268,7 @@ class MarsCNN(nn.Module):
         if self._fix_scratch is None or self._fix_scratch.device != x.device:
             self._fix_scratch = torch.empty((512 + 64 * (960 + 6144 + 1536 + 57) * 4,), dtype=torch.uint8, device=x.device)   # MMW_RANGE_FIXUP_SCRATCH
         w1 = self.dense1_dhwc.weight
-        rc = L.mmw_mars_range_fixup(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), self._sflags.data_ptr(), x.shape[0],
+        rc = L.mmw_mars_range_fixup(torch.cuda.current_stream(x.device).cuda_stream, x.data_ptr(), (sflags if sflags is not None else self._sflags).data_ptr(), x.shape[0],
                                     self.k_w1.data_ptr(), self.k_b1.data_ptr(), self.k_w2.data_ptr(), self.k_b2.data_ptr(), w1.data_ptr(), w1.stride(0),
                                     self.dense1_dhwc.bias.data_ptr(), self.dense2.weight.data_ptr(), self.dense2.bias.data_ptr(),
                                     self._fix_scratch.data_ptr(), kp.data_ptr(), self.range_flag.data_ptr())
@@ -305,9 +319,10 @@ class MarsCNN(nn.Module):
         matrix-core kernel for the 3-frame model, torch's fp32 kernels for the single-frame one (no fp32 HIP kernel exists)."""
         return "f32" if self.use_hip_conv_f32 else "torch"
 
-    def forward(self, x: torch.Tensor, arith: str | None = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, arith: str | None = None, fixup: bool = True, sflags: torch.Tensor | None = None) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it.  `arith` overrides the model's for
-        this call.  A CUDA tensor runs this package's HIP kernels or raises: torch's own convolutions take a GPU batch only
+        this call; `fixup=False, sflags=<new_fixup_list()>` leaves the fp32 repair of out-of-range samples to the caller's
+        range_fixup() (another stream, later).  A CUDA tensor runs this package's HIP kernels or raises: torch's own convolutions take a GPU batch only
         when arith = "torch" was asked for (CPU tensors always take the torch path -- training exports, CPU tests)."""
         arith = arith or self.arith
         if x.is_cuda and arith != "torch":
@@ -320,9 +335,9 @@ class MarsCNN(nn.Module):
             with torch.cuda.device(x.device):
                 if arith == "f16x3":
                     xc = x.contiguous()
-                    kp = self.dense2(self._dense1_split(self._hip_convs_split(xc))).contiguous()
-                    if self.has_range_fixup():
-                        self._range_fixup(xc, kp)   # samples outside fp16's range: their rows again, in fp32 (Keras' arithmetic)
+                    kp = self.dense2(self._dense1_split(self._hip_convs_split(xc, sflags))).contiguous()
+                    if fixup and self.has_range_fixup():
+                        self._range_fixup(xc, kp, sflags)   # samples outside fp16's range: their rows again, in fp32 (Keras' arithmetic)
                     return kp
                 h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
             return self.dense2(h)

@@ -71,6 +71,12 @@ class PosturePipeline:
             self.owner = [torch.zeros((self.cap, 2), dtype=torch.int32, device=self.dev) for _ in range(self.NBUF)]
             self.uid = [torch.zeros((self.cap,), dtype=torch.int32, device=self.dev) for _ in range(self.NBUF)]
             self.kp = [torch.zeros((self.cap, NKP), dtype=torch.float32, device=self.dev) for _ in range(self.NBUF)]
+            # the split-fp16 CNN's fp32 repair of out-of-range samples (mars.MarsCNN.range_fixup: five launches, empty on almost
+            # every frame) leaves the CNN stream, which is the critical path of this schedule: it runs on the tracker stream in
+            # front of the frame's scatter, off a fix-up list of the frame's own
+            self._defer_fixup = (self.B is not self.A and getattr(model, "arith", None) == "f16x3" and hasattr(model, "range_fixup")
+                                 and getattr(model, "has_range_fixup", lambda: False)())
+            self.sflags = [model.new_fixup_list(self.dev) for _ in range(self.NBUF)] if self._defer_fixup else None
         self.A.synchronize()
         self.ev_feat = [torch.cuda.Event() for _ in range(self.NBUF)]
         self.ev_cnn = [torch.cuda.Event() for _ in range(self.NBUF)]
@@ -106,7 +112,10 @@ class PosturePipeline:
             if self.time_cnn:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 pair[0].record(self.B)
-            self.kp[d][:n].copy_(self.model(self.feat[d][:n]))
+            if self._defer_fixup:
+                self.kp[d][:n].copy_(self.model(self.feat[d][:n], fixup=False, sflags=self.sflags[d]))
+            else:
+                self.kp[d][:n].copy_(self.model(self.feat[d][:n]))
             if self.time_cnn:
                 pair[1].record(self.B)
                 self._cnn_pairs.append(pair)
@@ -119,6 +128,9 @@ class PosturePipeline:
         if n == 0:
             return
         self.A.wait_event(self.ev_cnn[d])
+        if self._defer_fixup:
+            with torch.cuda.stream(self.A), torch.no_grad():
+                self.model.range_fixup(self.feat[d][:n], self.kp[d], self.sflags[d])
         self.sb.set_keypoints_uid_dev(self.kp[d].data_ptr(), self.owner[d].data_ptr(), self.uid[d].data_ptr(), n)
 
     def after_step(self):

@@ -98,6 +98,61 @@ def test_pipelined_posture_equals_frame_synchronous_loop():
     torch.cuda.synchronize()
 
 
+def test_pipeline_repairs_out_of_range_samples_on_the_tracker_stream():
+    """The split-fp16 CNN's fp32 repair (samples whose inputs or activations leave fp16's range: mars.MarsCNN.range_fixup) runs on
+    the TRACKER stream in the pipelined schedule, in front of the frame's scatter, off a fix-up list of the frame's own -- not on
+    the CNN stream it used to lengthen by five launches a frame.  A feature tensor of the last frame is pushed out of fp16's range
+    behind the feature kernel: the track it belongs to ends up with the keypoints of Keras' fp32 arithmetic, the others with
+    the split arithmetic's, and the run reports one repaired batch and nothing left meaningless."""
+    import torch
+    import bench
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.posture import PosturePipeline
+    S, N, T, F = 64, 256, 4, 8
+    pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=4)
+    dev = torch.device("cuda", 0)
+    model = MarsCNN.from_keras_weights(random_keras_weights(seed=4, frames=3)).to(dev)
+    sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
+    pipe = PosturePipeline(sb, model, S * sb.track_cap, overlap=True)
+    if pipe.B is pipe.A:
+        pipe.close(); sb.close()
+        pytest.skip("no second stream on an independent hardware queue: the serial schedule keeps the repair behind Dense-2")
+    assert pipe._defer_fixup
+    with torch.cuda.stream(pipe.A):
+        d_pts = torch.from_numpy(pts).to(dev).double(); d_cnt = torch.from_numpy(cnt).to(dev); d_dt = torch.from_numpy(dts).to(dev)
+    pipe.A.synchronize()
+    for f in range(F):
+        sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+        pipe.after_step()
+    torch.cuda.synchronize()                      # the last frame's feature tensors are written, its CNN is not queued yet
+    d = (F - 1) % pipe.NBUF
+    with torch.cuda.stream(pipe.A):
+        pipe.feat[d][0, 0, 0, 0, :] = 1.0e5       # sample 0: an input beyond fp16's 65 504
+        x_mod = pipe.feat[d].clone()
+        owner0 = pipe.owner[d][0].clone()
+    torch.cuda.synchronize()
+    before = model.range_recomputed
+    pipe.drain()
+    assert model.range_recomputed == before + 1 and not pipe.range_overflowed
+    n = pipe.rows[d]
+    assert n > 8
+    with torch.no_grad():
+        want32 = model(x_mod[:n], arith=model.fp32_arith()).float().cpu().numpy()
+    s0, j0 = (int(v) for v in owner0.cpu().numpy())
+    own = pipe.owner[d][:n].cpu().numpy()
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    got0 = trk[s0, j0]["keypoints"]
+    assert np.isfinite(got0).all()
+    assert np.abs(got0 - want32[0]).max() <= 1e-4 * max(1.0, float(np.abs(want32[0]).max()))
+    for i in range(1, min(n, 40)):               # the others: untouched by the repair, the split arithmetic's (within 1e-4 of fp32's)
+        s_i, j_i = int(own[i, 0]), int(own[i, 1])
+        assert np.abs(trk[s_i, j_i]["keypoints"] - want32[i]).max() <= 1e-4 * max(1.0, float(np.abs(want32[i]).max())), i
+    pipe.close(); sb.close()
+
+
 def test_features_async_tickets_and_uid_scatter():
     import torch
     from mmwave_msc_amd import _lib
