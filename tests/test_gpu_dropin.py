@@ -247,10 +247,12 @@ def test_attached_posture_model_one_round_trip_per_frame():
     p, c, d = make_scene(91, 16, 220, 3, ragged=True)
     ang = np.radians(const.S_TILT)
     raw = bench_ingest.raw_rows_from_normalised(p, float(np.cos(ang)), float(np.sin(ang)), float(const.S_HEIGHT)).astype(np.float64)
+    from mmwave_msc_amd.utils import normalize_data
     att, ab = TrackBuffer(max_pts=256), BatchedData()
+    att2, ab2 = TrackBuffer(max_pts=256), BatchedData()   # attached too, driven through normalize_data + track() (the rows form)
     dev, db = TrackBuffer(max_pts=256), BatchedData()
     ora, ob = TrackBuffer(max_pts=256), BatchedData()
-    assert att.attach_posture_model(model) is True
+    assert att.attach_posture_model(model) is True and att2.attach_posture_model(model) is True
     assert att.attach_posture_model(KerasLike()) is False and att._fused_model is model   # (not a MarsCNN: refused, nothing changes)
     estimated = 0
     for f in range(16):
@@ -269,8 +271,17 @@ def test_attached_posture_model_one_round_trip_per_frame():
                 tb.estimate_posture(m)
                 if tb is att:
                     assert not tb._posture_done
+        att2.dt = float(d[f])
+        eff = normalize_data(det)
+        if eff.shape[0]:
+            att2.track(eff, ab2)
+            assert att2._posture_done
+            att2.estimate_posture(model)
+        t2 = att2.effective_tracks
         ta, td, to = att.effective_tracks, dev.effective_tracks, ora.effective_tracks
-        assert len(ta) == len(td) == len(to), f
+        assert len(ta) == len(td) == len(to) == len(t2), f
+        for x, y in zip(ta, t2):
+            assert np.array_equal(x.state.x, y.state.x) and np.array_equal(x.keypoints, y.keypoints), f
         for x, y, z in zip(ta, td, to):
             assert np.array_equal(x.state.x, y.state.x) and np.array_equal(x.state.P, y.state.P) and x.uid == y.uid, f
             assert np.array_equal(x.keypoints, y.keypoints), f
@@ -279,7 +290,7 @@ def test_attached_posture_model_one_round_trip_per_frame():
     assert len(att.effective_tracks) >= 2 and estimated >= 10
     att.attach_posture_model(None)
     assert att._fused_model is None
-    att.close(); dev.close(); ora.close()
+    att.close(); att2.close(); dev.close(); ora.close()
 
 
 def test_attach_posture_refuses_what_it_cannot_run():
