@@ -319,10 +319,12 @@ class MarsCNN(nn.Module):
         matrix-core kernel for the 3-frame model, torch's fp32 kernels for the single-frame one (no fp32 HIP kernel exists)."""
         return "f32" if self.use_hip_conv_f32 else "torch"
 
-    def forward(self, x: torch.Tensor, arith: str | None = None, fixup: bool = True, sflags: torch.Tensor | None = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, arith: str | None = None, fixup: bool = True, sflags: torch.Tensor | None = None,
+                out: torch.Tensor | None = None) -> torch.Tensor:
         """x: (B,3,8,8,5) [or (B,8,8,5)] channels-last fp32, as mmw_features writes it.  `arith` overrides the model's for
         this call; `fixup=False, sflags=<new_fixup_list()>` leaves the fp32 repair of out-of-range samples to the caller's
-        range_fixup() (another stream, later).  A CUDA tensor runs this package's HIP kernels or raises: torch's own convolutions take a GPU batch only
+        range_fixup() (another stream, later); `out` (B, 57) fp32 contiguous receives the keypoints of the split-arithmetic path
+        directly (Dense-2 writes there: no copy behind it).  A CUDA tensor runs this package's HIP kernels or raises: torch's own convolutions take a GPU batch only
         when arith = "torch" was asked for (CPU tensors always take the torch path -- training exports, CPU tests)."""
         arith = arith or self.arith
         if x.is_cuda and arith != "torch":
@@ -335,7 +337,11 @@ class MarsCNN(nn.Module):
             with torch.cuda.device(x.device):
                 if arith == "f16x3":
                     xc = x.contiguous()
-                    kp = self.dense2(self._dense1_split(self._hip_convs_split(xc, sflags))).contiguous()
+                    h = self._dense1_split(self._hip_convs_split(xc, sflags))
+                    if out is not None and out.is_contiguous() and out.dtype == torch.float32 and out.shape == (xc.shape[0], N_KEYPOINTS):
+                        kp = torch.addmm(self.dense2.bias, h, self.dense2.weight.t(), out=out)
+                    else:
+                        kp = self.dense2(h).contiguous()
                     if fixup and self.has_range_fixup():
                         self._range_fixup(xc, kp, sflags)   # samples outside fp16's range: their rows again, in fp32 (Keras' arithmetic)
                     return kp

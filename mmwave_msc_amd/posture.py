@@ -113,7 +113,7 @@ class PosturePipeline:
                 pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 pair[0].record(self.B)
             if self._defer_fixup:
-                self.kp[d][:n].copy_(self.model(self.feat[d][:n], fixup=False, sflags=self.sflags[d]))
+                self.model(self.feat[d][:n], fixup=False, sflags=self.sflags[d], out=self.kp[d][:n])   # (Dense-2 writes the frame's keypoint buffer)
             else:
                 self.kp[d][:n].copy_(self.model(self.feat[d][:n]))
             if self.time_cnn:
