@@ -260,6 +260,156 @@ __device__ __forceinline__ void update_math(TrackRec *rec, bool live, const doub
     wave_sync();
 }
 
+// Lane K of every 16-lane row, to all lanes of that row: the one DPP control the 64-bit moves take (row_newbcast).  All 64 lanes
+// must be active (a DPP read of a disabled lane returns nothing useful), hence only in wave-uniform code; the wait states between a
+// VALU write and a DPP read of the same register are the asm's own (the compiler does not see a DPP instruction in it).
+template <int K>
+__device__ __forceinline__ double row_bcast(double v)
+{
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+
+// ... with a value the move has to wait for (never read): the chain of products then takes its broadcasts one at a time instead
+// of the scheduler lining all of them up first (36 .. 135 live doubles: 124 VGPRs spilled under k_post's budget)
+template <int K>
+__device__ __forceinline__ double row_bcast_after(double v, double dep)
+{
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K), "v"(dep));
+    return r;
+}
+
+// update_math for the batched kernels (16 lanes per track) with the operands the lanes of a track share -- S^-1, Rc, rows of K,
+// A and C1 -- BROADCAST FROM THE REGISTERS of the lane that owns them (row_bcast) instead of written to and read back from the
+// LDS: a wave's pass over four tracks moved 213 KB through the LDS, most of it 16 lanes reading the same eight bytes, and k_post
+// was bound by that pipe (profiles/NOTEBOOK.md, round 4).  Lane c owns row c of K and C1, column c of A, P and (c < 6) of S, Rc;
+// lanes 6..11 hold the columns of S^-1 when the inverse returns.  Every lane runs every instruction (lanes past DX and idle
+// groups on garbage that is never stored): no divergence between a value's definition and its broadcast.  Per element the same
+// operations in the same order as update_math.
+template <int DX>
+__device__ __forceinline__ void update_math_bcast(TrackRec *rec, bool live, const double *R, int lane, int c, int &err)
+{
+    const double *Pw = R + rP;
+    const bool valid = live && c < 6;
+    double v[6], rcol[6], det;
+    const double N = (double)reinterpret_cast<const int32_t *>(R + rInts)[0], nest = R[rNest];
+    const double den = (nest - 1) * N;
+    if (valid && den == 0.0) err |= ERR_DIVZERO;
+    const double coef = (nest - N) / den;
+    const double hh = R[rSpr + c] / 2;           // (c >= 6: words of the staged record that mean something else -- never used)
+    const double dg = (hh * hh) / N;             // Rm[c][c] / N; the off-diagonal 0 / N is +0 (N >= 1): one division, same bits
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        rcol[i] = ((i == c) ? dg : 0.0) + coef * R[rGd + i * 6 + c];   // Rc[i][c]
+        const double sv = Pw[i * 9 + c] + rcol[i];                      // S = H P H^T + R
+        v[i] = valid ? sv : ((c == i) ? 1.0 : 0.0);
+    }
+    const double y_own = R[rCen + c] - R[rX + c];   // y = z - H x (c < 6)
+    const bool ok = lu6_inverse_cols(v, lane, det);
+    if (live && !ok && den != 0.0) err |= ERR_SINGULAR;   // (den == 0: S is inf / NaN because of the division, not singular)
+    // K = P H^T S^-1, row c: S^-1[m][cc] = v[m] of lane 6 + cc
+    double krow[6];
+    {
+        double prow[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) prow[m] = Pw[c * 9 + m];
+#define MMW_K_COL(cc)                                                                      \
+        {                                                                                  \
+            double a = prow[0] * row_bcast<6 + cc>(v[0]);                                  \
+            a += prow[1] * row_bcast_after<6 + cc>(v[1], a);                                        \
+            a += prow[2] * row_bcast_after<6 + cc>(v[2], a);                                        \
+            a += prow[3] * row_bcast_after<6 + cc>(v[3], a);                                        \
+            a += prow[4] * row_bcast_after<6 + cc>(v[4], a);                                        \
+            a += prow[5] * row_bcast_after<6 + cc>(v[5], a);                                        \
+            krow[cc] = a;                                                                  \
+        }
+        MMW_K_COL(0) MMW_K_COL(1) MMW_K_COL(2) MMW_K_COL(3) MMW_K_COL(4) MMW_K_COL(5)
+#undef MMW_K_COL
+    }
+    {  // x = x + K y: y[m] = y_own of lane m
+        double a = krow[0] * row_bcast<0>(y_own);
+        a += krow[1] * row_bcast_after<1>(y_own, a);
+        a += krow[2] * row_bcast_after<2>(y_own, a);
+        a += krow[3] * row_bcast_after<3>(y_own, a);
+        a += krow[4] * row_bcast_after<4>(y_own, a);
+        a += krow[5] * row_bcast_after<5>(y_own, a);
+        double xnew = R[rX + c] + a;
+        if (c == 0) {  // Tracking.py:396-398: abs(variance.any()) > 0.6 <=> z[0] != x[0]
+            const double var = R[rCen] - xnew;
+            if (!(var == 0.0) && R[rLife] == 0.0) xnew += var * 0.4;
+        }
+        if (live && c < DX) rec->x[c] = xnew;
+    }
+    // C1 = K R, row c: Rc[m][cc] = rcol[m] of lane cc
+    double c1row[6];
+#define MMW_C1_COL(cc)                                                                     \
+    {                                                                                      \
+        double a = krow[0] * row_bcast<cc>(rcol[0]);                                       \
+        a += krow[1] * row_bcast_after<cc>(rcol[1], a);                                             \
+        a += krow[2] * row_bcast_after<cc>(rcol[2], a);                                             \
+        a += krow[3] * row_bcast_after<cc>(rcol[3], a);                                             \
+        a += krow[4] * row_bcast_after<cc>(rcol[4], a);                                             \
+        a += krow[5] * row_bcast_after<cc>(rcol[5], a);                                             \
+        c1row[cc] = a;                                                                     \
+    }
+    MMW_C1_COL(0) MMW_C1_COL(1) MMW_C1_COL(2) MMW_C1_COL(3) MMW_C1_COL(4) MMW_C1_COL(5)
+#undef MMW_C1_COL
+    // A = (I - K H) P, column c: K[i][m] = krow[m] of lane i
+    double pcol[DX], acol[DX];
+#pragma unroll
+    for (int m = 0; m < DX; m++) pcol[m] = Pw[m * 9 + c];
+#define MMW_A_ROW(i)                                                                       \
+    if (i < DX) {                                                                          \
+        double a = 0.0;                                                                    \
+        _Pragma("unroll") for (int m = 0; m < DX; m++) {                                   \
+            const double d = (i == m) ? 1.0 : 0.0;                                         \
+            double ikh = d;                                                                \
+            if (m < 6) ikh = d - row_bcast_after<i>(krow[m < 6 ? m : 0], a);                        \
+            a = (m == 0) ? ikh * pcol[0] : a + ikh * pcol[m];                              \
+        }                                                                                  \
+        acol[i < DX ? i : 0] = a;                                                          \
+    }
+    MMW_A_ROW(0) MMW_A_ROW(1) MMW_A_ROW(2) MMW_A_ROW(3) MMW_A_ROW(4) MMW_A_ROW(5) MMW_A_ROW(6) MMW_A_ROW(7) MMW_A_ROW(8)
+#undef MMW_A_ROW
+    // P = A (I-KH)^T + C1 K^T, column c: A[i][m] = acol[i] of lane m, C1[i][m] = c1row[m] of lane i
+    double ikhc[DX];
+#pragma unroll
+    for (int m = 0; m < DX; m++) {
+        const double d = (c == m) ? 1.0 : 0.0;
+        ikhc[m] = m < 6 ? d - krow[m < 6 ? m : 0] : d;
+    }
+#define MMW_P_TERM(i, m) row_bcast_after<m>(acol[i], b)
+#define MMW_P_TERM0(i) row_bcast<0>(acol[i])
+#define MMW_P_ROW(i)                                                                       \
+    if (i < DX) {                                                                          \
+        double b = MMW_P_TERM0(i) * ikhc[0];                                             \
+        b += MMW_P_TERM(i, 1) * ikhc[1];                                                   \
+        b += MMW_P_TERM(i, 2) * ikhc[2];                                                   \
+        b += MMW_P_TERM(i, 3) * ikhc[3];                                                   \
+        b += MMW_P_TERM(i, 4) * ikhc[4];                                                   \
+        b += MMW_P_TERM(i, 5) * ikhc[5];                                                   \
+        if (DX > 6) {                                                                      \
+            b += MMW_P_TERM(i, 6) * ikhc[DX > 6 ? 6 : 0];                                  \
+            b += MMW_P_TERM(i, 7) * ikhc[DX > 7 ? 7 : 0];                                  \
+            b += MMW_P_TERM(i, 8) * ikhc[DX > 8 ? 8 : 0];                                  \
+        }                                                                                  \
+        double c2 = row_bcast<i>(c1row[0]) * krow[0];                                      \
+        c2 += row_bcast_after<i>(c1row[1], c2) * krow[1];                                            \
+        c2 += row_bcast_after<i>(c1row[2], c2) * krow[2];                                            \
+        c2 += row_bcast_after<i>(c1row[3], c2) * krow[3];                                            \
+        c2 += row_bcast_after<i>(c1row[4], c2) * krow[4];                                            \
+        c2 += row_bcast_after<i>(c1row[5], c2) * krow[5];                                            \
+        if (live && c < DX) rec->P[i * 9 + c] = b + c2;                                    \
+    }
+    MMW_P_ROW(0) MMW_P_ROW(1) MMW_P_ROW(2) MMW_P_ROW(3) MMW_P_ROW(4) MMW_P_ROW(5) MMW_P_ROW(6) MMW_P_ROW(7) MMW_P_ROW(8)
+#undef MMW_P_ROW
+#undef MMW_P_TERM
+#undef MMW_P_TERM0
+    wave_sync();
+}
+
 // ... for a record that is still in global memory (the batched kernels): `rec` = the group's track record (idle groups:
 // any valid record), `Wj` = the group's kUpdScratch doubles = [staged record | scratch].
 template <int DX>
@@ -267,7 +417,11 @@ __device__ __forceinline__ void update_one_track(TrackRec *rec, bool live, doubl
 {
     stage_record<16>(rec, Wj, c);
     wave_sync();
+#ifdef MMW_UPD_LDS   // (diagnostic builds: the shared operands through the LDS, as before round 4's broadcast form)
     update_math<DX, 16>(rec, live, Wj, Wj + kRecStage, lane, c, err);
+#else
+    update_math_bcast<DX>(rec, live, Wj, lane, c, err);
+#endif
 }
 
 // _predict_all for ONE track per LP-lane group (predict_state, Tracking.py:372-385: filterpy predict with the motion
