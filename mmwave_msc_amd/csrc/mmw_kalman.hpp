@@ -504,6 +504,87 @@ __device__ __forceinline__ void predict_math(const DevCfg &cfg, TrackRec *rec, d
     wave_sync();
 }
 
+// lane i + N of the 16-lane row, for lane i (lanes past the row's end: 0): two 32-bit DPP moves (row_shl)
+template <int N>
+__device__ __forceinline__ double row_from_right(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// predict_math for the batched kernel (k_predict: 16 lanes per track, the record written back to global memory, nothing read from
+// the LDS copy afterwards) with lane c owning COLUMN c of P: A = F P needs nothing but the lane's own column (F shifts ROWS), B = A F^T
+// takes columns c + 3 and c + 6 from the lanes three and six to the right (row_from_right), and the gate matrix wants exactly the
+// first six entries of the lane's column -- no scratch in the LDS, no k / 9, k % 9.  Per element the same operations in the same
+// order as predict_math.  Every lane runs every instruction; stores are guarded.
+template <int DX>
+__device__ __forceinline__ void predict_math_cols(const DevCfg &cfg, TrackRec *rec, double *G, bool live, double dt, const double *R, int lane, int c,
+                                                  int &err)
+{
+    const double dtm = R[rLife] + dt;
+    const double h = 0.5 * (dtm * dtm);
+    const double dt2 = dtm * dtm, dt3 = dt2 * dtm, dt4 = dt2 * dt2;
+    const bool own = c < DX;
+    double acol[DX], pn[DX];
+    {   // A = F P, column c (F has ones on the diagonal, dt at (i,i+3), h at (i,i+6): the k-ordered dense dot product reduces to these terms)
+        double pcol[DX];
+#pragma unroll
+        for (int i = 0; i < DX; i++) pcol[i] = R[rP + i * 9 + (own ? c : 0)];
+#pragma unroll
+        for (int i = 0; i < DX; i++) {
+            double a = pcol[i];
+            if (i + 3 < DX) a += dtm * pcol[i + 3 < DX ? i + 3 : 0];
+            if (i + 6 < DX) a += h * pcol[i + 6 < DX ? i + 6 : 0];
+            acol[i] = a;
+        }
+    }
+    double xn = R[rX + (own ? c : 0)];
+    {
+        const double x3 = R[rX + (c + 3 < DX ? c + 3 : 0)], x6 = R[rX + (c + 6 < DX ? c + 6 : 0)];
+        if (c + 3 < DX) xn += dtm * x3;
+        if (c + 6 < DX) xn += h * x6;
+    }
+    const int qc = c % 3, cb = c / 3;
+#pragma unroll
+    for (int i = 0; i < DX; i++) {  // B = A F^T + Q, column c
+        const double a3 = row_from_right<3>(acol[i]), a6 = row_from_right<6>(acol[i]);
+        double b = acol[i];
+        if (c + 3 < DX) b += a3 * dtm;
+        if (c + 6 < DX) b += a6 * h;
+        double qn = 0.0;
+        if (i / 3 == cb) {  // block_diag of Q_discrete_white_noise(dim=3) (constants.py:210-215)
+            const int qi = i % 3, sdeg = qi + qc;
+            const double base = sdeg == 0 ? 0.25 * dt4 : sdeg == 1 ? 0.5 * dt3 : sdeg == 2 ? ((qi == 1) ? dt2 : 0.5 * dt2)
+                              : sdeg == 3 ? dtm : 1.0;
+            qn = base * cfg.kf_q_std;
+        }
+        pn[i] = b + qn;
+        if (live && own) rec->P[i * 9 + c] = pn[i];
+    }
+    if (live && own) rec->x[c] = xn;
+    // gate matrix: lane c < 6 of the group holds column c of C = P[:6,:6] + diag((spread/2)^2) + group_disp_est
+    const bool valid = live && c < 6;
+    double v[6], det;
+    const double hh = R[rSpr + c] / 2;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double cv = (pn[i] + ((i == c) ? hh * hh : 0.0)) + R[rGd + i * 6 + c];
+        v[i] = valid ? cv : ((c == i) ? 1.0 : 0.0);  // idle groups: identity
+    }
+    const bool ok = lu6_inverse_cols(v, lane, det);
+    if (live) {
+        if (!ok) err |= ERR_SINGULAR;
+        if (c >= 6 && c < 12) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) G[r * 6 + c - 6] = v[r];
+        }
+        if (c == 0) G[36] = dlog(fabs(det));
+        if (c < 6) G[37 + c] = xn;
+    }
+    wave_sync();
+}
+
 // ... for a record that is still in global memory: `Wj` = the group's kPredScratch doubles = [staged record | scratch];
 // the gate record goes to gate_buf[s][j] (by effective_tracks position).
 template <int DX>
@@ -512,7 +593,11 @@ __device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevSt
 {
     stage_record<16>(rec, Wj, c);
     wave_sync();
+#ifdef MMW_PRED_LDS   // (diagnostic builds: the element-wise form with its LDS scratch, as before round 4's column form)
     predict_math<DX, 16, true>(cfg, rec, st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec, live, dt, Wj, Wj + kRecStage, lane, c, err);
+#else
+    predict_math_cols<DX>(cfg, rec, st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec, live, dt, Wj, lane, c, err);
+#endif
 }
 
 // When the track-wise layout is used: it needs one lane per bin (t_cap <= 63), and it only pays when there are more

@@ -129,5 +129,5 @@ def test_gate_records_are_not_read_before_the_scalar_cache_invalidate():
             kern = re.search(r"s_load_dword\S* \S+ (s\[\d+:\d+\]), 0x", body).group(1)   # first scalar load: the kernel arguments
             wide = [(m.start(), m.group(1)) for m in re.finditer(r"s_load_dwordx16 \S+ (s\[\d+:\d+\]),", body)]
             before = [w for w in wide if w[0] < inv and w[1] != kern]
-            after = [w for w in wide if w[0] > mark and w[1] != kern]
+            after = [w for w in wide if w[0] > mark]   # (whatever pair the base sits in by then: the allocator may reuse the arguments' one)
             assert len(before) <= allowed_before and len(after) >= 5, (n, len(before), len(after))
