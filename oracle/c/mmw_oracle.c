@@ -465,7 +465,7 @@ int orc_dbscan(const orc_config *cfg, const double *pts, int n, double eps, int 
  * threshold; the cluster's cloud is added to the ring a second time; change_buffer_size is permanent;
  * apply_DBscan is called with eps = DB_INNER_EPS and the DEFAULT min_samples (DB_INNER_MIN_SAMPLES is unused);
  * only the cluster with label 1 is returned. */
-static void seek_inner(orc_scene *s, trk_t *t, int j, const double *rows, int n)
+static int seek_inner(orc_scene *s, trk_t *t, int j, const double *rows, int n)
 {
     const orc_config *c = &s->cfg;
     const size_t um = (size_t)s->ring_size * s->cfg.ring_rows;
@@ -474,7 +474,7 @@ static void seek_inner(orc_scene *s, trk_t *t, int j, const double *rows, int n)
     int k = s->inner_calls, U = 0, ncl;
     double *cat;
     int32_t *lab;
-    if (!(t->point_num > c->db_points_thres && any > c->db_spread_thres)) return;
+    if (!(t->point_num > c->db_points_thres && any > c->db_spread_thres)) return 0;
     t->ring_size = t->is_static ? c->fb_frames_batch_static : c->fb_frames_batch;
     track_ring_push(s, t, rows, n);
     cat = s->inner_rows + (size_t)k * um * 8;   /* effective_data, then overwritten by the returned cluster */
@@ -484,6 +484,8 @@ static void seek_inner(orc_scene *s, trk_t *t, int j, const double *rows, int n)
         U += t->ring_n[f];
     }
     ncl = orc_dbscan(c, cat, U, c->db_inner_eps, c->db_min_samples, lab);
+    if (ncl < 0) return ncl;   /* sklearn's ValueError on a non-finite row (an assigned point's doppler / peakVal: the gate only sees
+                                  columns 0..5) leaves track() here, in the middle of _associate_points_to_tracks */
     s->inner_track[k] = j;
     s->inner_n[k] = U;
     s->inner_m[k] = 0;
@@ -494,6 +496,7 @@ static void seek_inner(orc_scene *s, trk_t *t, int j, const double *rows, int n)
         s->inner_m[k] = m;
     }
     s->inner_calls = k + 1;
+    return 0;
 }
 
 /* ClusterTrack.update_state Tracking.py:387-398 + filterpy update + _get_Rc 299-312 */
@@ -678,7 +681,27 @@ int orc_dbscan_neighbors(const orc_config *cfg, const double *pts, int n, double
     return ok;
 }
 
-/* DBSCAN.fit (sklearn/cluster/_dbscan.py:410-432) + dbscan_inner (_dbscan_inner.pyx) */
+/* sklearn's input validation in front of DBSCAN.fit (the reference's call site: Utils.py:272-278 -> DBSCAN.fit_predict ->
+ * validate_data -> check_array(ensure_all_finite=True) -> _assert_all_finite, sklearn/utils/validation.py): ALL 8 columns of
+ * the cloud.  ValueError("Input X contains NaN. ...") when any value is NaN, else ValueError("Input X contains infinity or a
+ * value too large for dtype('float64').") when any is +-inf -- the precedence of sklearn 1.7.2 as it runs here (get_namespace
+ * hands _assert_all_finite_element_wise array_api_compat.numpy, so `xp is np` is false and it takes the any(isinf) /
+ * any(isnan) branch: NaN wins wherever it sits; the Cython scan of sklearn/utils/_isfinite.pyx, which would report the FIRST
+ * non-finite value in row-major order, is not reached.  Only the message text depends on it).  Returns 0,
+ * ORC_E_NONFINITE_NAN or ORC_E_NONFINITE_INF.  (The fast path -- isfinite(sum(X)) -- only skips the scan for all-finite
+ * input: a sum that overflows sends sklearn to the element-wise test, which then finds nothing.) */
+int orc_check_finite(const double *pts, int n)
+{
+    int has_inf = 0;
+    for (size_t i = 0; i < (size_t)(n > 0 ? n : 0) * 8; i++) {
+        if (isnan(pts[i])) return ORC_E_NONFINITE_NAN;
+        if (isinf(pts[i])) has_inf = 1;
+    }
+    return has_inf ? ORC_E_NONFINITE_INF : 0;
+}
+
+/* DBSCAN.fit (sklearn/cluster/_dbscan.py:410-432) + dbscan_inner (_dbscan_inner.pyx).  Returns the number of clusters, or
+ * ORC_E_NONFINITE_* (< 0) where sklearn raises on a NaN / infinite coordinate (labels untouched). */
 int orc_dbscan(const orc_config *cfg, const double *pts, int n, double eps, int min_samples, int32_t *labels)
 {
     uint8_t *adj, *core;
@@ -686,6 +709,10 @@ int orc_dbscan(const orc_config *cfg, const double *pts, int n, double eps, int 
     int sp = 0, label_num = 0;
     size_t cap;
     if (n <= 0) return 0;
+    {
+        const int nf = orc_check_finite(pts, n);
+        if (nf) return nf;
+    }
     adj = (uint8_t *)malloc((size_t)n * (size_t)n);
     core = (uint8_t *)malloc((size_t)n);
     orc_dbscan_neighbors(cfg, pts, n, eps, adj);
@@ -827,7 +854,10 @@ int orc_track_frame(orc_scene *s, const double *pts, int n, double dt, int32_t *
             t->lifetime = 0.0;
             rc = track_associate(s, t, s->cloud, m);
             if (rc) return rc;
-            if (c->seek_inner) seek_inner(s, t, j, s->cloud, m);   /* Tracking.py:656 */
+            if (c->seek_inner) {   /* Tracking.py:656 */
+                rc = seek_inner(s, t, j, s->cloud, m);
+                if (rc) return rc;
+            }
         }
     }
     /* Tracking.py:658-660: a track for every inner cluster found, appended BEFORE _maintain_tracks / _update_all */
@@ -870,6 +900,11 @@ int orc_track_frame(orc_scene *s, const double *pts, int n, double dt, int32_t *
         }
         if (U > 0 && T < c->tr_max_tracks) {
             int ncl = orc_dbscan(c, s->concat, U, c->db_eps, c->db_min_samples, db_labels);
+            if (ncl < 0) {   /* sklearn raised (a NaN / inf in the ring): track() ends here with the frame in the ring, nothing clustered,
+                                nothing cleared -- and again on every frame the row stays in the ring and the trigger holds */
+                *db_n = ORC_DB_RAISED;
+                return ncl;
+            }
             *db_n = U;
             if (ncl > 0) {
                 s->g_len = 0; /* batch.clear() Tracking.py:53-58 */

@@ -184,6 +184,24 @@ def config_from_constants(const, **overrides) -> OrcConfig:
     return default_config(**kw)
 
 
+E_NONFINITE_NAN, E_NONFINITE_INF, DB_RAISED = -7, -8, -2   # mmw_oracle.h
+
+
+class OracleNonFinite(RuntimeError, ValueError):
+    """apply_DBscan was reached with a NaN / an infinite value in its cloud: sklearn's input validation raises ValueError
+    there (Utils.py:272-278).  `kind` = "NaN" | "infinity" (sklearn's message: NaN when any value is NaN, else infinity); `.rc` = the oracle's return code."""
+
+    def __init__(self, rc, where="orc_track_frame"):
+        self.rc = int(rc)
+        self.kind = "NaN" if rc == E_NONFINITE_NAN else "infinity"
+        super().__init__(f"{where} failed rc={rc}: " + sklearn_message(self.kind))
+
+
+def sklearn_message(kind: str) -> str:
+    """First line of the ValueError sklearn raises (sklearn/utils/validation.py:_assert_all_finite_element_wise)."""
+    return "Input X contains NaN." if kind == "NaN" else "Input X contains infinity or a value too large for dtype('float64')."
+
+
 class OracleScene:
     """One scene = one reference `TrackBuffer` + its global `BatchedData`."""
 
@@ -213,6 +231,10 @@ class OracleScene:
         dbn = C.c_int32(-1)
         rc = self.L.orc_track_frame(self.h, _p(pts, C.c_double), n, float(dt), _p(assoc, C.c_int32),
                                     _p(labels, C.c_int32), C.byref(dbn))
+        self.last_assoc = assoc[:n].copy()   # (valid also when the frame's apply_DBscan raised: the association came first)
+        self.last_db_n = int(dbn.value)
+        if rc in (E_NONFINITE_NAN, E_NONFINITE_INF):
+            raise OracleNonFinite(rc)
         if rc != 0:
             raise RuntimeError(f"orc_track_frame failed rc={rc}")
         return assoc[:n].copy(), (labels[: dbn.value].copy() if dbn.value >= 0 else None)
@@ -295,9 +317,11 @@ def normalize(cfg: OrcConfig, raw: np.ndarray) -> np.ndarray:
 def dbscan(cfg: OrcConfig, pts: np.ndarray, eps=None, min_samples=None) -> np.ndarray:
     pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 8)
     labels = np.full(max(pts.shape[0], 1), -1, dtype=np.int32)
-    lib().orc_dbscan(C.byref(cfg), _p(pts, C.c_double), pts.shape[0],
-                     cfg.db_eps if eps is None else float(eps),
-                     cfg.db_min_samples if min_samples is None else int(min_samples), _p(labels, C.c_int32))
+    rc = lib().orc_dbscan(C.byref(cfg), _p(pts, C.c_double), pts.shape[0],
+                          cfg.db_eps if eps is None else float(eps),
+                          cfg.db_min_samples if min_samples is None else int(min_samples), _p(labels, C.c_int32))
+    if rc < 0:
+        raise OracleNonFinite(rc, "orc_dbscan")
     return labels[: pts.shape[0]]
 
 

@@ -64,6 +64,16 @@ SCENARIOS = {
     "inner_static": dict(seed=117, N=256, K=1, F=12, over={"SEEK_INNER": True, "FB_FRAMES_BATCH_STATIC": 3}, pairs=dict(sep=0.9, static=True)),
     "inner_two_pairs": dict(seed=118, N=512, K=2, F=10, over={"SEEK_INNER": True, "TR_MAX_TRACKS": 4}, pairs=dict(sep=0.8)),
     "inner_close": dict(seed=119, N=200, K=1, F=10, over={"SEEK_INNER": True, "DB_POINTS_THRES": 60}, pairs=dict(sep=0.45)),
+    # NaN / +-inf rows: the gate never takes a point whose columns 0..5 are not finite (Tracking.py:559-563), such rows enter the
+    # global ring, and sklearn's input validation raises ValueError out of apply_DBscan (Utils.py:272-278) on every frame the
+    # trigger holds (Tracking.py:693-697) while one is in the ring -- `raised` records it per frame (1 = "contains NaN",
+    # 2 = "contains infinity"), with the state the exception leaves behind.  TR_MAX_TRACKS = 2 with two targets: while both tracks
+    # live (from frame 12 on, when the second target appears) apply_DBscan is not called and a non-finite row sits in the ring
+    # without raising; before, it raises on every frame it is in the ring.
+    # ["all", 6]: every row of the frame gets a NaN doppler -- the assigned ones carry it into their track's ring and feature map.
+    "nonfinite": dict(seed=122, N=160, K=2, F=26, over={"TR_MAX_TRACKS": 2}, presence="late",
+                      nonfinite=[[1, 3, 0, "nan"], [6, 7, 2, "inf"], [7, 2, 3, "nan"], [13, 5, 1, "-inf"], [14, "all", 6, "nan"],
+                                 [20, 1, 7, "inf"]]),
 }
 
 
@@ -85,6 +95,8 @@ def _presence(kind, f, k):
     elif kind == "flicker":
         p[8:12, 0] = False
         p[20:30, 1] = False
+    elif kind == "late":
+        p[:12, 1] = False
     return p
 
 
@@ -102,7 +114,16 @@ def gen_scenario(name, sc):
     for zf in sc.get("zero_frames", ()):
         cnt[zf] = 0
         pts[zf] = 0
+    for fr, row, col, val in sc.get("nonfinite", ()):
+        v = {"nan": np.nan, "inf": np.inf, "-inf": -np.inf}[val]
+        if row == "all":
+            pts[fr, : cnt[fr], col] = v
+        else:
+            assert row < cnt[fr]
+            pts[fr, row, col] = v
     over = dict(sc["over"])
+    if "nonfinite" in sc:
+        over["NONFINITE"] = sc["nonfinite"]
     const, _, _ = load_reference()
     if "MOTION_MODEL" in over:
         over["MOTION_MODEL"] = getattr(const, over["MOTION_MODEL"])
@@ -110,12 +131,14 @@ def gen_scenario(name, sc):
     if "BATCH_INIT" in over:   # the rows BatchedData(init_data) starts with: clutter of another seed
         init_rows = make_scene(sc["seed"] + 500, 1, int(over["BATCH_INIT"]), 0)[0][0].astype(np.float64)
     resize = {int(a): int(b) for a, b in over.get("BATCH_RESIZE", [])}
-    ref = RefScene({k2: v for k2, v in over.items() if k2 not in ("TRACK_EMPTY", "BATCH_INIT", "BATCH_RESIZE")}, init_data=init_rows)
+    ref = RefScene({k2: v for k2, v in over.items() if k2 not in ("TRACK_EMPTY", "BATCH_INIT", "BATCH_RESIZE", "NONFINITE")}, init_data=init_rows)
     ring = ref.const.FB_FRAMES_BATCH + 1
     tmax = 0
     rec = dict(assoc=np.full((f, n), -2, np.int16), db_n=np.full(f, -1, np.int32),
                labels=np.full((f, ring * n), -2, np.int16), n_tracks=np.zeros(f, np.int32),
                ring_len=np.zeros(f, np.int32), ring_n=np.zeros((f, 4), np.int32))
+    if "NONFINITE" in over:
+        rec["raised"] = np.zeros(f, np.int8)
     inner = over.get("SEEK_INNER", False)
     if inner:   # per frame: the seek_inner_clusters calls (pre-maintenance track position, labels) and every track's batch.size
         rec.update(inner_calls=np.zeros(f, np.int32), inner_track=np.full((f, 8), -1, np.int32), inner_n=np.zeros((f, 8), np.int32),
@@ -133,7 +156,15 @@ def gen_scenario(name, sc):
             continue
         if i in resize:
             ref.batch.change_buffer_size(resize[i])
-        a, lab = ref.track(pts[i, : cnt[i]].astype(np.float64), float(dt[i]))
+        try:
+            with np.errstate(invalid="ignore"):
+                a, lab = ref.track(pts[i, : cnt[i]].astype(np.float64), float(dt[i]))
+        except ValueError as e:
+            if "NONFINITE" not in over or not str(e).startswith("Input X contains"):
+                raise
+            from oracle.ref_runner import _Recorder
+            rec["raised"][i] = 1 if str(e).startswith("Input X contains NaN") else 2
+            a, lab = _Recorder.assoc.copy(), None     # (_calc_dist_fun had returned before apply_DBscan raised)
         rec["assoc"][i, : cnt[i]] = a
         if lab is not None:
             rec["db_n"][i] = len(lab)
@@ -177,7 +208,8 @@ def gen_scenario(name, sc):
     np.savez_compressed(
         os.path.join(GOLDEN_DIR, f"track_{name}.npz"), pts=pts, cnt=cnt, dt=dt, tracks=trk,
         feat=feat, n_feat=n_feat, owner=owner, overrides=json.dumps(over_json), meta=_meta(), **rec)
-    print(f"  {name}: F={f} N={n} K={k} tracks(max)={tmax} dbscan_frames={(rec['db_n'] >= 0).sum()}")
+    print(f"  {name}: F={f} N={n} K={k} tracks(max)={tmax} dbscan_frames={(rec['db_n'] >= 0).sum()}"
+          + (f" raised={rec['raised'].tolist()}" if "raised" in rec else ""))
 
 
 def gen_normalize():

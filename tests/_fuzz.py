@@ -110,3 +110,25 @@ def scene_inputs(case: dict):
                 c[f] = -1
         pts[:, s], cnt[:, s], dts[:, s] = p, c, d
     return pts, cnt, dts
+
+
+def plant_nonfinite(case: dict, pts: np.ndarray, cnt: np.ndarray, rate: float = 0.25):
+    """The non-finite arm: NaN / +inf / -inf written into random columns (all 8: x, y, z, vx, vy, vz, doppler, peakVal) of random
+    rows of about `rate` of the (frame, scene) pairs -- rows that will be unassigned (start-up frames, clutter) and rows a track
+    would have taken.  The reference gates on columns 0..5 (a non-finite innovation never passes `d2 < TR_GATE`, Tracking.py:559-563),
+    pushes such rows into the global ring, and sklearn's input validation raises ValueError out of apply_DBscan (Utils.py:272-278)
+    on every frame the row is in the ring and the trigger holds (Tracking.py:693-697).  Returns the planted (frame, scene, row,
+    column) list; `pts` is modified in place."""
+    rng = np.random.default_rng(990000 + case["seed"])
+    F, S = cnt.shape
+    planted = []
+    for f in range(F):
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c <= 0 or rng.random() >= rate:
+                continue
+            for _ in range(int(rng.integers(1, 4))):
+                r, col = int(rng.integers(0, c)), int(rng.integers(0, 8))
+                pts[f, s, r, col] = (np.nan, np.inf, -np.inf)[int(rng.integers(0, 3))]
+                planted.append((f, s, r, col))
+    return planted

@@ -27,7 +27,15 @@ def test_tracker_matches_reference_golden(name):
             sc.set_batch_size(resize[f])
         if c == 0 and not g["overrides"].get("TRACK_EMPTY"):  # offline_main.py:56: empty frames never reach track()
             continue
-        assoc, labels = sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
+        raised = int(g["raised"][f]) if "raised" in g else 0
+        if raised:   # the reference raised ValueError out of apply_DBscan (a NaN / inf row in the ring, Utils.py:272-278)
+            with pytest.raises(co.OracleNonFinite) as ei:
+                sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
+            assert ei.value.kind == ("NaN", "infinity")[raised - 1], f"{name} f{f}: which ValueError"
+            assert sc.last_db_n == co.DB_RAISED
+            assoc, labels = sc.last_assoc, None
+        else:
+            assoc, labels = sc.track(g["pts"][f, :c].astype(np.float64), float(g["dt"][f]))
         assert np.array_equal(assoc, g["assoc"][f, :c]), f"{name} f{f}: association differs"
         dbn = int(g["db_n"][f])
         if dbn < 0:

@@ -83,3 +83,80 @@ def test_live_reference_vs_c_oracle_on_fresh_seeds(seed):
         utils.apply_DBscan.__defaults__ = saved_defaults
         for r in refs:
             r.close()
+
+
+N_NONFINITE_CASES = 16
+
+
+@pytest.mark.parametrize("seed", range(N_NONFINITE_CASES))
+def test_live_reference_vs_c_oracle_with_nonfinite_rows(seed):
+    """NaN / +-inf planted in random columns of random rows (tests/_fuzz.py: plant_nonfinite).  Where the reference raises
+    ValueError out of apply_DBscan (sklearn's input validation, Utils.py:272-278) the oracle returns ORC_E_NONFINITE_* with the
+    same message kind (NaN when any value of the cloud is NaN, else infinity), and BOTH are stepped on: the state the
+    exception leaves behind (frame in the ring, nothing clustered, nothing cleared) and every later frame must still agree --
+    the row raises again on each frame it stays in the ring while the trigger holds."""
+    from oracle import c_oracle as co
+    from oracle.ref_import import load_reference
+    from oracle.ref_runner import RefScene
+    from tests._fuzz import plant_nonfinite
+
+    case = draw_case(3000 + seed, max_pts=260, max_scenes=2, frames=12)
+    kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
+    pts, cnt, dts = scene_inputs(case)
+    planted = plant_nonfinite(case, pts, cnt, rate=0.3)
+    const, utils, _ = load_reference()
+    over = reference_overrides(kw)
+    if "MOTION_MODEL" in over:
+        over["MOTION_MODEL"] = getattr(const, over["MOTION_MODEL"])
+    saved_defaults = utils.apply_DBscan.__defaults__
+    utils.apply_DBscan.__defaults__ = (kw["db_eps"], kw["db_min_samples"])
+    refs = []
+    n_raised = 0
+    try:
+        cfg = co.default_config(**kw)
+        for s in range(S):
+            ref = RefScene(dict(over))
+            refs.append(ref)
+            orc = co.OracleScene(cfg, N)
+            for f in range(F):
+                c = int(cnt[f, s])
+                if c == 0:
+                    continue
+                rows = pts[f, s, : max(c, 0)].astype(np.float64)
+                ctx = (seed, s, f)
+                try:
+                    with np.errstate(all="ignore"):
+                        ra, rl = ref.track(rows, float(dts[f, s]))
+                    raised = None
+                except ValueError as e:
+                    raised = str(e)
+                except (ZeroDivisionError, np.linalg.LinAlgError) as e:
+                    with pytest.raises(RuntimeError) as ei:
+                        orc.track(rows, float(dts[f, s]))
+                    assert ("rc=-3" if isinstance(e, ZeroDivisionError) else "rc=-2") in str(ei.value), (ctx, e)
+                    break
+                if raised is not None:
+                    n_raised += 1
+                    assert raised.startswith("Input X contains"), (ctx, raised)
+                    with pytest.raises(co.OracleNonFinite) as ei:
+                        orc.track(rows, float(dts[f, s]))
+                    assert raised.startswith(co.sklearn_message(ei.value.kind)), (ctx, raised, ei.value.kind)
+                    from oracle.ref_runner import _Recorder
+                    if not kw.get("seek_inner"):   # (the frame's own call raised: the association came first and is comparable)
+                        assert orc.last_db_n == co.DB_RAISED, ctx
+                        assert np.array_equal(orc.last_assoc, _Recorder.assoc), (ctx, "association of a raising frame")
+                else:
+                    oa, ol = orc.track(rows, float(dts[f, s]))
+                    assert np.array_equal(oa, ra), (ctx, "association")
+                    assert (ol is None) == (rl is None), (ctx, "apply_DBscan call pattern")
+                    if ol is not None:
+                        assert np.array_equal(ol, rl), (ctx, "DBSCAN labels")
+                assert orc.n_tracks == ref.n_tracks, ctx
+                assert_tracks_match(orc.tracks(), ref.tracks(), ctx=f"seed {seed} s{s} f{f}", tol=1e-7)
+                assert np.array_equal(orc.batch_ring(), ref.batch_ring()), ctx
+            ref.close()
+    finally:
+        utils.apply_DBscan.__defaults__ = saved_defaults
+        for r in refs:
+            r.close()
+    assert planted
