@@ -46,6 +46,13 @@ extern "C" {
 #define MMW_E_CAPACITY (-4)   /* more tracks than track_cap */
 #define MMW_E_HIP (-5)        /* HIP runtime error */
 #define MMW_E_NODEVICE (-6)   /* no usable gfx950 device: the library has no CPU path */
+#define MMW_E_NONFINITE (-7)  /* apply_DBscan was reached with a NaN or an infinite value in its cloud: sklearn's input validation raises
+                                 ValueError there (Utils.py:272-278 -> DBSCAN.fit_predict -> check_array).  Any of the 8 columns of any row
+                                 of the global ring counts; the gate never takes a point whose columns 0..5 are not finite
+                                 (Tracking.py:559-563), so such rows always end up there.  The frame is in the ring, nothing was
+                                 clustered or cleared -- exactly the state the exception leaves -- and the scene raises again on every
+                                 frame the row is still in the ring while the trigger holds (Tracking.py:693-697) */
+#define MMW_DB_RAISED (-2)    /* db_n of a scene whose apply_DBscan call of this frame raised (MMW_E_NONFINITE); -1 = not called */
 
 /* Mirrors constants.py 1:1 (line numbers = /root/reference/src/constants.py). */
 typedef struct mmw_config {
@@ -170,8 +177,21 @@ int mmw_reset(mmw_ctx *ctx);
 int mmw_reset_scenes(mmw_ctx *ctx, const int32_t *scene_flags);
 /* The sticky error bits of every scene (host array of n_scenes words; 0 = none): 1 singular 6x6 matrix, 2 division by zero
  * in _get_Rc, 4 more tracks than track_cap (the tracks that did not fit were dropped: this scene differs from the reference
- * from then on), 8 a point count the context was not sized for.  mmw_check reports the first one as its return code. */
+ * from then on), 8 a point count the context was not sized for, 16 / 32 apply_DBscan reached with a NaN / an infinite value
+ * in its cloud (MMW_E_NONFINITE; 16 = sklearn's "contains NaN" message, which it prefers when both are present, 32 = "contains
+ * infinity").  mmw_check reports the first one as its return code. */
 int mmw_get_errors(mmw_ctx *ctx, int32_t *err_bits);
+/* Clears the given error bits of the scenes whose flag is non-zero (host array of n_scenes words; NULL = every scene) and
+ * nothing else: for errors that leave the scene's state valid -- a caller that catches the reference's ValueError
+ * (MMW_E_NONFINITE) and carries on sees the same state the reference is in, and the error comes back on the next frame if
+ * it still applies. */
+#define MMW_ERRBIT_SINGULAR 1
+#define MMW_ERRBIT_DIVZERO 2
+#define MMW_ERRBIT_CAPACITY 4
+#define MMW_ERRBIT_BADCOUNT 8
+#define MMW_ERRBIT_NONFINITE_NAN 16
+#define MMW_ERRBIT_NONFINITE_INF 32
+int mmw_clear_errors(mmw_ctx *ctx, const int32_t *scene_flags, int32_t bits);
 /* BatchedData.pop_frame() (Tracking.py:66-71; its caller is preprocessing.py:264): drop the oldest frame of the global
  * ring of every scene whose flag is non-zero (host array of n_scenes words; NULL = every scene). */
 int mmw_pop_frame(mmw_ctx *ctx, const int32_t *scene_flags);
@@ -221,7 +241,8 @@ int mmw_normalize_f32(mmw_ctx *ctx, const float *raw, const int32_t *n_raw, doub
  *   assoc[S][max_pts]      _calc_dist_fun result: -1 = None, else index into the
  *                          track list as it was BEFORE _maintain_tracks (Tracking.py:530-574)
  *   db_labels[S][ring*max_pts], db_n[S]   sklearn labels of apply_DBscan on the global
- *                          ring (Utils.py:272-278); db_n = -1 when it was not called. */
+ *                          ring (Utils.py:272-278); db_n = -1 when it was not called, MMW_DB_RAISED when
+ *                          sklearn's input validation refused the cloud (MMW_E_NONFINITE). */
 int mmw_step(mmw_ctx *ctx, const double *pts, const int32_t *n_pts, const double *dt,
              int32_t *assoc, int32_t *db_labels, int32_t *db_n);
 /* mmw_step on fp32 rows: pts[S][max_pts][8] float (32 bytes per point, 16-byte aligned), promoted to fp64 in registers as
@@ -268,7 +289,9 @@ int mmw_frame_posture_host(mmw_ctx *ctx, const double *raw, const double *pts, c
                            int32_t *n_out, int32_t *assoc, int32_t *db_labels, int32_t *db_n, int32_t *n_tracks, int32_t *posture_rows);
 
 /* Utils.apply_DBscan (Utils.py:250-291) on arbitrary clouds: pts[S][max_n][8], n[S]
- * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts; max_n > 1920: the global-memory path). */
+ * -> labels[S][max_n], n_clusters[S] (dev pointers; max_n <= ring*max_pts; max_n > 1920: the global-memory path).
+ * A cloud that holds a NaN or an infinite value in any of its 8 columns is refused as sklearn's input validation refuses it
+ * (ValueError): its labels are not written and n_clusters[s] = -MMW_ERRBIT_NONFINITE_NAN (-16) or -MMW_ERRBIT_NONFINITE_INF (-32). */
 int mmw_dbscan(mmw_ctx *ctx, const double *pts, const int32_t *n, int32_t max_n, double eps,
                int32_t min_samples, int32_t *labels, int32_t *n_clusters);
 

@@ -19,7 +19,9 @@ RING_MAX = 4
 NKP = 57
 
 MMW_OK = 0
-E_ARG, E_SINGULAR, E_DIVZERO, E_CAPACITY, E_HIP, E_NODEVICE = -1, -2, -3, -4, -5, -6
+E_ARG, E_SINGULAR, E_DIVZERO, E_CAPACITY, E_HIP, E_NODEVICE, E_NONFINITE = -1, -2, -3, -4, -5, -6, -7
+DB_RAISED = -2     # MMW_DB_RAISED: db_n of a scene whose apply_DBscan call of the frame raised (E_NONFINITE)
+ERRBIT_SINGULAR, ERRBIT_DIVZERO, ERRBIT_CAPACITY, ERRBIT_BADCOUNT, ERRBIT_NONFINITE_NAN, ERRBIT_NONFINITE_INF = 1, 2, 4, 8, 16, 32
 K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE, K_PREDICT, K_POST = range(7)
 
 EMPTY_FRAME = -1   # MMW_EMPTY_FRAME (include/mmw.h)
@@ -34,7 +36,7 @@ EXPORTS = [
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
     "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small", "mmw_mars_range_fixup",
-    "mmw_attach_posture", "mmw_frame_posture_host",
+    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors",
 ]
 
 
@@ -90,6 +92,28 @@ class MmwError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libmmw_hip error {code}: {msg}")
         self.code = code
+
+
+# The exceptions the reference's track() can raise on this path, as subclasses of BOTH MmwError and the reference's type, so
+# that `except ValueError:` / `except np.linalg.LinAlgError:` around a drop-in TrackBuffer.track() keeps working:
+#   sklearn's input validation in apply_DBscan (Utils.py:272-278)      -> ValueError
+#   np.linalg.inv / det on a singular 6x6 (Tracking.py:556-560, filterpy) -> numpy.linalg.LinAlgError
+#   (N_est - 1) * N == 0 in _get_Rc (Tracking.py:310-312)              -> ZeroDivisionError
+class MmwNonFinite(MmwError, ValueError):
+    pass
+
+
+class MmwSingular(MmwError, np.linalg.LinAlgError):
+    pass
+
+
+class MmwDivZero(MmwError, ZeroDivisionError):
+    pass
+
+
+def error_for(code, msg) -> MmwError:
+    cls = {E_NONFINITE: MmwNonFinite, E_SINGULAR: MmwSingular, E_DIVZERO: MmwDivZero}.get(code, MmwError)
+    return cls(code, msg)
 
 
 def source_hash() -> str:
@@ -221,6 +245,7 @@ def load():
         "mmw_streams_concurrent": (C.c_int, [vp, vp, vp]),
         "mmw_reset_scenes": (C.c_int, [vp, vp]),
         "mmw_get_errors": (C.c_int, [vp, vp]),
+        "mmw_clear_errors": (C.c_int, [vp, vp, i32]),
         "mmw_set_chain_side_stream": (C.c_int, [vp, i32]),
         "mmw_stats_get_ext": (C.c_int, [vp, vp]),
         "mmw_mars_conv3d": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32]),

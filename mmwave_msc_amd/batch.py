@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MmwError, RING_MAX, NKP, SUMMARY_DTYPE, TRACK_DTYPE
+from ._lib import MmwError, RING_MAX, NKP, SUMMARY_DTYPE, TRACK_DTYPE, error_for
 
 
 class DevBuf:
@@ -69,7 +69,7 @@ class SceneBatch:
     # -- plumbing -------------------------------------------------------------
     def _chk(self, rc):
         if rc != 0:
-            raise MmwError(rc, (self.L.mmw_last_error(self.h) or b"").decode())
+            raise error_for(rc, (self.L.mmw_last_error(self.h) or b"").decode())
 
     def close(self):
         if self.h:
@@ -176,10 +176,21 @@ class SceneBatch:
         self._chk(self.L.mmw_reset_scenes(self.h, m.ctypes.data))
 
     def errors(self) -> np.ndarray:
-        """Sticky error bits per scene (mmw_get_errors): 1 singular, 2 division by zero, 4 capacity, 8 bad point count."""
+        """Sticky error bits per scene (mmw_get_errors): 1 singular, 2 division by zero, 4 capacity, 8 bad point count,
+        16 / 32 apply_DBscan reached with a NaN / an infinite value in the ring (sklearn's ValueError, Utils.py:272-278)."""
         out = np.zeros(self.S, dtype=np.int32)
         self._chk(self.L.mmw_get_errors(self.h, out.ctypes.data))
         return out
+
+    def clear_errors(self, bits: int, scenes=None):
+        """mmw_clear_errors: clears the given sticky bits (of the given scenes; default all) and nothing else -- for a caller that
+        catches the reference's ValueError (non-finite rows: the scene's state is what the reference's is) and carries on."""
+        if scenes is None:
+            self._chk(self.L.mmw_clear_errors(self.h, None, int(bits)))
+            return
+        flags = np.zeros(self.S, dtype=np.int32)
+        flags[np.asarray(scenes, dtype=np.int64)] = 1
+        self._chk(self.L.mmw_clear_errors(self.h, flags.ctypes.data, int(bits)))
 
     def check(self):
         self._chk(self.L.mmw_check(self.h))
@@ -198,8 +209,10 @@ class SceneBatch:
         fn = self.L.mmw_normalize_f32 if f32 else self.L.mmw_normalize
         self._chk(fn(self.h, raw_ptr, n_raw_ptr, pts_ptr, n_out_ptr))
 
-    def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray):
-        """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S])."""
+    def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray, raise_nonfinite: bool = True):
+        """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S]).  raise_nonfinite=False: a scene
+        whose apply_DBscan call raised sklearn's ValueError (a NaN / infinite row in its ring) does not raise here -- its db_n is
+        DB_RAISED (-2), its sticky bit stays set (`errors()`, `clear_errors()`), every other scene's results are as always."""
         pts = np.ascontiguousarray(pts, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         dt = np.ascontiguousarray(dt, dtype=np.float64)
@@ -207,8 +220,10 @@ class SceneBatch:
         assoc = np.full((self.S, self.max_pts), -1, dtype=np.int32)
         labels = np.full((self.S, self.UM), -1, dtype=np.int32)
         dbn = np.full(self.S, -1, dtype=np.int32)
-        self._chk(self.L.mmw_step_host(self.h, pts.ctypes.data, n.ctypes.data, dt.ctypes.data,
-                                       assoc.ctypes.data, labels.ctypes.data, dbn.ctypes.data))
+        rc = self.L.mmw_step_host(self.h, pts.ctypes.data, n.ctypes.data, dt.ctypes.data,
+                                  assoc.ctypes.data, labels.ctypes.data, dbn.ctypes.data)
+        if not (rc == _lib.E_NONFINITE and not raise_nonfinite):   # (the results are complete either way: the check is the last thing)
+            self._chk(rc)
         return assoc, labels, dbn
 
     def attach_posture(self, model=None):
@@ -279,8 +294,10 @@ class SceneBatch:
             pts[s, n_out[s]:] = 0.0
         return pts, n_out
 
-    def dbscan_host(self, pts: np.ndarray, n: np.ndarray, eps=None, min_samples=None):
-        """Utils.apply_DBscan labels for S clouds: pts[S,max_n,8] -> (labels[S,max_n], n_clusters[S])."""
+    def dbscan_host(self, pts: np.ndarray, n: np.ndarray, eps=None, min_samples=None, raise_nonfinite: bool = True):
+        """Utils.apply_DBscan labels for S clouds: pts[S,max_n,8] -> (labels[S,max_n], n_clusters[S]).  A cloud with a NaN / an
+        infinite value raises ValueError as sklearn's input validation does (Utils.py:272-278); with raise_nonfinite=False such
+        clouds come back with n_clusters = -16 (NaN) / -32 (infinity) and labels -1."""
         pts = np.ascontiguousarray(pts, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         max_n = pts.shape[1]
@@ -297,6 +314,12 @@ class SceneBatch:
         ncl = b_c.download((self.S,), np.int32)
         for s in range(self.S):
             labels[s, n[s]:] = -1
+            if ncl[s] < 0:   # sklearn's input validation refused the cloud (a NaN / an infinite value): no labels
+                labels[s] = -1
+        if raise_nonfinite and (ncl < 0).any():
+            s = int(np.flatnonzero(ncl < 0)[0])
+            raise _lib.MmwNonFinite(_lib.E_NONFINITE, f"cloud {s}: " + ("Input X contains NaN." if ncl[s] == -_lib.ERRBIT_NONFINITE_NAN
+                                                                       else "Input X contains infinity or a value too large for dtype('float64')."))
         return labels, ncl
 
     def features_dev(self, feat_ptr, owner_ptr, cap_rows: int) -> int:

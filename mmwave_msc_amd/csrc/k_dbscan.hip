@@ -1427,6 +1427,13 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
         for (int k = 0; k < MMW_RING_MAX; k++) if (k < len && rn[k] > cfg.ring_rows) whole = false;
         if (U > UMc || !whole) { err |= ERR_CAPACITY; continue; }  // a frame that was not stored whole, or more points than the BallTree holds
         __syncthreads();  // the copied rows are visible to the whole workgroup (this barrier is also a global-memory fence)
+        {   // sklearn's input validation in front of the inner apply_DBscan (Utils.py:272-278): all 8 columns of the track's
+            // ring rows -- an assigned point can carry a NaN / infinite doppler or peakVal (the gate only sees columns 0..5).
+            // The reference's ValueError leaves track() in the middle of _associate_points_to_tracks: the scene is flagged,
+            // this track's inner clustering does not run.
+            const int nfb = cloud_nonfinite_bits(src, U);
+            if (nfb) { err |= nf_error_of(nfb); continue; }
+        }
         const bool tpp = U <= kInnerThreads;  // uniform
         db_lds_layout<true>(UMc, 2, tpp, lds_raw, &L);
         const int ncl = tpp ? dbscan_core<kInnerThreads, true>(cfg, L, src, U, UMc, cfg.db_inner_eps, cfg.db_min_samples, nullptr)
@@ -1453,7 +1460,7 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
     if (tid == 0) {
         ib[0] = calls;
         ib[1] = stored;
-        if (err) atomicOr(&hdr->err, err);
+        const int nd = hdr->need_db;
         if (T != Tin) {
             hdr->n_tracks = T;
             hdr->n_upd = T;   // _update_all covers the inner tracks as well
@@ -1462,6 +1469,14 @@ __global__ __launch_bounds__(kInnerThreads) void k_inner(DevCfg cfg, DevState st
                 if (db_n_out) db_n_out[s] = -1;
             }
         }
+        if (nd & 2) {   // k_track left the verdict on a ring that holds a non-finite row to this re-evaluated trigger
+            if (T < cfg.tr_max_tracks) {
+                err |= nd >> 2;
+                if (db_n_out) db_n_out[s] = kDbRaised;
+            }
+            hdr->need_db = 0;
+        }
+        if (err) atomicOr(&hdr->err, err);
     }
 }
 
@@ -1911,6 +1926,10 @@ __global__ __launch_bounds__(256) void k_dbscan_only(DevCfg cfg, int UM, const d
     src.stride = 0;
     src.slots = 0;
     src.c1 = src.c2 = src.c3 = 0x7fffffff;
+    if (const int nfb = cloud_nonfinite_bits(src, U)) {   // sklearn raises ValueError: no labels, n_clusters = -(error bit)
+        if (tid == 0 && ncl_out) ncl_out[s] = -nf_error_of(nfb);
+        return;
+    }
     const int ncl = dbscan_core<256, false>(cfg, L, src, U, UM, eps, min_samples, nullptr);
     for (int i = tid; i < U; i += 256) labels_out[(size_t)s * max_n + i] = L.idx2[i];
     if (tid == 0 && ncl_out) ncl_out[s] = ncl;
@@ -1961,6 +1980,10 @@ __global__ __launch_bounds__(kHugeThreads) void k_dbscan_only_huge(DevCfg cfg, D
         src.stride = 0;
         src.slots = 0;
         src.c1 = src.c2 = src.c3 = 0x7fffffff;
+        if (const int nfb = cloud_nonfinite_bits(src, U)) {   // sklearn raises ValueError: no labels, n_clusters = -(error bit)
+            if (tid == 0 && ncl_out) ncl_out[s] = -nf_error_of(nfb);
+            continue;
+        }
         const int ncl = dbscan_core<kHugeThreads, false, kHugeMW>(cfg, L, src, U, UM, eps, min_samples, nullptr);
         for (int i = tid; i < U; i += kHugeThreads) labels_out[(size_t)s * max_n + i] = L.idx2[i];
         if (tid == 0 && ncl_out) ncl_out[s] = ncl;

@@ -55,6 +55,15 @@ __global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const RT *__restr
         o[q][5] = cfg.tilt_sin * vy + cfg.tilt_cos * vz;
         o[q][6] = dop;
         o[q][7] = pk;
+        {   // Non-finite rows.  The reference multiplies full homogeneous 4-vectors by full 4 x 4 matrices, zeros included
+            // (Utils.py:311-326): one NaN / infinite coordinate meets a zero (0 * inf = NaN) and makes all three transformed
+            // coordinates NaN -- the filter below then drops the row (NaN compares false) --, one non-finite velocity component
+            // (a NaN / infinite doppler) makes all three velocities NaN on a row that is kept.  Finite rows: nothing changes.
+            constexpr int kNanInf = 0x3 | 0x4 | 0x200;
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            if (__builtin_amdgcn_class(x, kNanInf) || __builtin_amdgcn_class(y, kNanInf) || __builtin_amdgcn_class(z, kNanInf)) o[q][0] = o[q][1] = o[q][2] = qnan;
+            if (__builtin_amdgcn_class(vx, kNanInf) || __builtin_amdgcn_class(vy, kNanInf) || __builtin_amdgcn_class(vz, kNanInf)) o[q][3] = o[q][4] = o[q][5] = qnan;
+        }
         const bool keep = i < n && o[q][2] <= 2.5 && o[q][2] > 0 && o[q][1] > 0;   // Utils.py:423-427
         bal[q] = __ballot(keep);
         if (lane == 0) wcnt[q * 4 + wave] = __popcll(bal[q]);
@@ -444,11 +453,22 @@ __global__ void k_set_batch_size(DevCfg cfg, DevState st, const int32_t *__restr
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= cfg.n_scenes || (flags && !flags[s])) return;
     SceneHdr *hdr = st.hdr + s;
-    hdr->skipped = (hdr->skipped & 255) | (new_size << 8);
+    hdr->skipped = (hdr->skipped & ~(kSkipRingMask << kSkipRingShift)) | (new_size << kSkipRingShift);
 }
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st)
 {
     hipLaunchKernelGGL(k_set_batch_size, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, flags, new_size);
+}
+// mmw_clear_errors: the sticky bits `bits` of the flagged scenes (nullptr: every scene) are cleared; nothing else changes
+__global__ void k_clear_errors(DevCfg cfg, DevState st, const int32_t *__restrict__ flags, int bits)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cfg.n_scenes || (flags && !flags[s])) return;
+    st.hdr[s].err &= ~bits;
+}
+void launch_clear_errors(const DevCfg &cfg, const DevState &s, const int32_t *flags, int bits, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_clear_errors, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, flags, bits);
 }
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st)
 {

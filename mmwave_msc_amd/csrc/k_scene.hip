@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
-            hdr->skipped = 1;
+            hdr->skipped = (hv.skipped & ~255) | 1;   // (the ring's non-finite flags stay)
             if (n_raw != 0) atomicOr(&hdr->err, ERR_BADCOUNT);
         }
         return;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
     const int grp_slot = lp == 64 ? slot64 : (lp == 32 ? slot32 : slot16);
     int err = 0;
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
-    if (tid == 0) { L.ml[0] = 0; L.ml[1] = 0; }
+    if (tid == 0) { L.ml[0] = 0; L.ml[1] = 0; L.misc[15] = 0; }
     PROBE(1);
 
     // ---- _predict_all (Tracking.py:591-596) + the gate matrices, on the LDS copies ----
@@ -498,6 +498,11 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
                     double *dst = (cc == 0 ? st.g_ring + L.seg_dst[T] : st.trk_ring + L.seg_dst[cc - 1]) + (size_t)local_q * 8;
                     double2 *d2 = reinterpret_cast<double2 *>(dst);
                     d2[0] = pr[q][0]; d2[1] = pr[q][1]; d2[2] = pr[q][2]; d2[3] = pr[q][3];
+                }
+                // a NaN / an infinite value in a row that enters the global ring (all 8 columns): see the trigger (k_track.hip)
+                if (cc == 0) {
+                    const int nfb = row_nonfinite_bits(pr[q]);
+                    if (nfb) atomicOr(&L.misc[15], nfb);
                 }
             }
         }
@@ -833,12 +838,30 @@ __global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st,
     }
     PROBE(19);
     // ---- DBSCAN trigger (Tracking.py:693-697) ----
-    const bool need = U > 0 && T < cfg.tr_max_tracks;
-    if (tid == 0) {
-        hdr->n_tracks = T;
-        hdr->n_upd = T;
-        hdr->skipped = 0;
-        hdr->need_db = need ? 1 : 0;
+    bool need = U > 0 && T < cfg.tr_max_tracks;
+    {
+        // the ring's non-finite flags (two bits per physical slot, SceneHdr.skipped): this frame's replace those of the slot it
+        // was written to.  apply_DBscan reached with a NaN / an infinite value in the ring: sklearn's input validation raises
+        // ValueError (Utils.py:272-278) and track() ends here -- frame in the ring, nothing clustered, nothing cleared (k_track.hip)
+        int phys = gs[0], live = 0;
+#pragma unroll
+        for (int k = 1; k < MMW_RING_MAX; k++) if (k == g_len - 1) phys = gs[k];
+        const int nff = nf_flags_with((hv.skipped >> kSkipNfShift) & kSkipNfMask, phys, L.misc[15]);
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) if (k < g_len) live |= (nff >> (2 * gs[k])) & 3;
+        const int nfe = nf_error_of(live);
+        const bool raised = need && nfe != 0;
+        if (raised) need = false;
+        if (tid == 0) {
+            hdr->n_tracks = T;
+            hdr->n_upd = T;
+            hdr->skipped = nff << kSkipNfShift;
+            hdr->need_db = need ? 1 : 0;
+            if (raised) {
+                err |= nfe;
+                if (db_n_out) db_n_out[s] = kDbRaised;
+            }
+        }
     }
     if (err) atomicOr(&hdr->err, err);
     lds_barrier();  // the Kalman scratch is dead: the screen's grid takes its place

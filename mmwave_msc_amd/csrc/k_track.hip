@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
             hdr->need_db = 0;
-            hdr->skipped = INNER ? ((hdr->skipped & ~255) | 1) : 1;  // not in this frame's update lists: the next k_predict finds its tracks by this flag
+            hdr->skipped = (hdr->skipped & ~255) | 1;  // not in this frame's update lists: the next k_predict finds its tracks by this flag (the ring's size and non-finite flags stay)
             if (n_raw != 0) atomicOr(&hdr->err, ERR_BADCOUNT);  // a count the context was not sized for
         }
         return;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
 
     if (tid < cfg.t_cap) L.slot[tid] = my_slot;
     for (int j = tid + kThreads; j < cfg.t_cap; j += kThreads) L.slot[j] = order[j];
-    if (tid == 0) { L.ml[0] = 0; L.ml[1] = 0; }
+    if (tid == 0) { L.ml[0] = 0; L.ml[1] = 0; L.misc[15] = 0; }
     lds_barrier();
     STAMP(0);  // issue point loads
     PROBE(0);
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = rec->ring_slot[k];
         } else if (tid == T) {
             sd_len = hdr->g_len;
-            if (INNER && (hdr->skipped >> 8)) sd_size = hdr->skipped >> 8;  // BatchedData.change_buffer_size on the global ring
+            if (INNER && hdr_ring_size(hdr->skipped)) sd_size = hdr_ring_size(hdr->skipped);  // BatchedData.change_buffer_size on the global ring
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = hdr->g_slot[k];
         }
@@ -482,6 +482,12 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
                     double2 *d2 = reinterpret_cast<double2 *>(dst);
                     d2[0] = pr[q][0]; d2[1] = pr[q][1]; d2[2] = pr[q][2]; d2[3] = pr[q][3];
                 }
+                // a NaN / an infinite value in a row that enters the global ring (all 8 columns: the gate only looked at six,
+                // and never takes a point whose innovation is not finite): sklearn will refuse the cloud (see the trigger)
+                if (cls == 0) {
+                    const int nfb = row_nonfinite_bits(pr[q]);
+                    if (nfb) atomicOr(&L.misc[15], nfb);
+                }
             }
         }
         PROBE(31);
@@ -495,7 +501,8 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         int len = hdr->g_len;
         int *gs = L.misc + 4, *gn = L.misc + 8;  // small indexed arrays live in LDS, not in scratch
         for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
-        const int gsz = (INNER && (hdr->skipped >> 8)) ? (hdr->skipped >> 8) : cfg.ring;
+        const int skw = hdr->skipped;
+        const int gsz = (INNER && hdr_ring_size(skw)) ? hdr_ring_size(skw) : cfg.ring;
         while (len >= gsz && len > 0) {
             const int first = gs[0];
             for (int k = 1; k < len; k++) { gs[k - 1] = gs[k]; gn[k - 1] = gn[k]; }
@@ -512,6 +519,12 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         hdr->db_u = U;
         L.misc[3] = len;
         L.misc[13] = U;
+        // the ring's non-finite flags (two bits per physical slot, SceneHdr.skipped): this frame's replace those of the slot it
+        // was written to; [15] = the new flags | what the live frames hold together << 8, for the trigger below
+        const int nff = nf_flags_with((skw >> kSkipNfShift) & kSkipNfMask, L.misc[1], L.misc[15]);
+        int live = 0;
+        for (int k = 0; k < len; k++) live |= (nff >> (2 * gs[k])) & 3;
+        L.misc[15] = nff | (live << 8);
     }
     PROBE(3);
 
@@ -880,13 +893,28 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         const int U = L.misc[13];
         hdr->n_tracks = T;
         hdr->n_upd = T;
-        hdr->skipped = INNER ? (hdr->skipped & ~255) : 0;
+        const int nfw = L.misc[15];
+        hdr->skipped = (INNER ? (hdr->skipped & (kSkipRingMask << kSkipRingShift)) : 0) | ((nfw & kSkipNfMask) << kSkipNfShift);
         // this scene's tracks join the update list of their count (k_post lays _update_all out over tracks): the
         // slot is requested here and written at the very end of the kernel -- the atomic's round trip (a microsecond
         // under 4096 workgroups) must not sit in front of the screen below
         if (T > 0) upd_pos = atomicAdd(&st.upd_count[parity * (cfg.t_cap + 1) + T], 1);
-        const bool need = U > 0 && T < cfg.tr_max_tracks;
-        hdr->need_db = need ? 1 : 0;
+        bool need = U > 0 && T < cfg.tr_max_tracks;
+        const int nfe = nf_error_of(nfw >> 8);
+        if (need && nfe) {
+            // apply_DBscan is reached with a NaN / an infinite value in the ring: sklearn's input validation raises ValueError
+            // (Utils.py:272-278) and track() ends here -- frame in the ring, nothing clustered, nothing cleared -- on every frame
+            // the row is in the ring while the trigger holds.  With seek_inner the trigger is re-evaluated behind the inner
+            // clusters (k_inner: they may fill the track list): the verdict is left to it (need_db = 2 | error bits << 2).
+            if (INNER && cfg.seek_inner) hdr->need_db = 2 | (nfe << 2);
+            else {
+                err |= nfe;
+                hdr->need_db = 0;
+                if (db_n_out) db_n_out[s] = kDbRaised;
+            }
+            need = false;
+        } else
+            hdr->need_db = need ? 1 : 0;
         L.misc[2] = need ? U : 0;
     }
     if (err) atomicOr(&hdr->err, err);

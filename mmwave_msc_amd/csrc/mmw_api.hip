@@ -2,6 +2,7 @@
 // if HIP cannot give us a gfx950-class device, creation fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,7 @@ void launch_reset(const DevCfg &cfg, const DevState &s, const int32_t *flags, hi
 void launch_probe_wait(int32_t *w, int slot, int polls, hipStream_t st);
 void launch_probe_set(int32_t *w, hipStream_t st);
 void launch_pop_frame(const DevCfg &cfg, const DevState &s, const int32_t *flags, hipStream_t st);
+void launch_clear_errors(const DevCfg &cfg, const DevState &s, const int32_t *flags, int bits, hipStream_t st);
 void launch_set_batch_size(const DevCfg &cfg, const DevState &s, const int32_t *flags, int new_size, hipStream_t st);
 void launch_mars_conv(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, float *out, int B,
                       hipStream_t stream, const int32_t *dev_rows = nullptr);
@@ -525,6 +527,21 @@ int mmw_get_errors(mmw_ctx *c, int32_t *err_bits)
     return MMW_OK;
 }
 
+int mmw_clear_errors(mmw_ctx *c, const int32_t *scene_flags, int32_t bits)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int32_t *d_flags = nullptr;
+    if (scene_flags) {  // (staged in the feature-offset scratch: S + 1 words, not live between calls)
+        HIPCHK(c, hipMemcpyAsync(c->d_row_off, scene_flags, sizeof(int32_t) * c->dc.n_scenes, hipMemcpyHostToDevice, c->stream));
+        d_flags = c->d_row_off;
+    }
+    launch_clear_errors(c->dc, c->st, d_flags, bits, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (scene_flags) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's array may go away
+    return MMW_OK;
+}
+
 int mmw_pop_frame(mmw_ctx *c, const int32_t *scene_flags)
 {
     if (!c) return MMW_E_ARG;
@@ -572,6 +589,12 @@ int mmw_set_batch_frame(mmw_ctx *c, int32_t scene, const double *rows, int32_t n
     if (c->ring_frames_bound < 1) c->ring_frames_bound = 1;
     for (int k = 0; k < MMW_RING_MAX; k++) h.g_n[k] = 0;
     h.g_n[0] = n;
+    {   // the ring's non-finite flags (SceneHdr.skipped bits 16..23): this frame's, for the slot it is written to
+        int bits = 0;
+        for (size_t i = 0; i < (size_t)n * 8; i++) bits |= std::isnan(rows[i]) ? 1 : (std::isinf(rows[i]) ? 2 : 0);
+        const int nff = nf_flags_with((h.skipped >> kSkipNfShift) & kSkipNfMask, h.g_slot[0], bits);
+        h.skipped = (h.skipped & ~(kSkipNfMask << kSkipNfShift)) | (nff << kSkipNfShift);
+    }
     double *dst = c->st.g_ring + ((size_t)scene * c->dc.ring + h.g_slot[0]) * (size_t)c->dc.max_pts * 8;
     if (n > 0) HIPCHK(c, hipMemcpyAsync(dst, rows, (size_t)n * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->st.hdr + scene, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
@@ -988,6 +1011,10 @@ static int first_scene_error(mmw_ctx *c, const SceneHdr *h, size_t n, const int3
         //  singular: when both bits are set the division came first -- as the reference's ZeroDivisionError would have)
         if (e & ERR_DIVZERO) return fail(c, MMW_E_DIVZERO, "scene %zu: (N_est-1)*N == 0 in _get_Rc / N_est == 0", s);
         if (e & ERR_SINGULAR) return fail(c, MMW_E_SINGULAR, "scene %zu: singular 6x6 gate/innovation matrix", s);
+        // (the last thing track() can raise in a frame: sklearn's input validation in apply_DBscan, Utils.py:272-278.  The text is
+        //  sklearn's own first line: NaN wins over infinity wherever the two sit in the cloud)
+        if (e & ERR_NONFINITE_NAN) return fail(c, MMW_E_NONFINITE, "scene %zu: Input X contains NaN.", s);
+        if (e & ERR_NONFINITE_INF) return fail(c, MMW_E_NONFINITE, "scene %zu: Input X contains infinity or a value too large for dtype('float64').", s);
     }
     if (q[kQTimeout] != 0) return fail(c, MMW_E_HIP, "a DBSCAN chain worker gave up waiting (%d time(s)): device hung or oversubscribed", q[kQTimeout]);
     return MMW_OK;

@@ -97,6 +97,21 @@ __device__ __forceinline__ RowSrc ring_rows_of(const DevCfg &cfg, const DevState
     return src;
 }
 
+// sklearn's input validation in front of DBSCAN.fit (apply_DBscan, Utils.py:272-278 -> check_array): every value of the
+// cloud's 8 columns must be finite.  Bit 0: some value is NaN, bit 1: some value is infinite; uniform over the workgroup
+// (all its threads call: two barriers).  The global ring keeps these bits per frame (SceneHdr.skipped) and never scans; this
+// is for clouds that come from elsewhere (a track's ring in k_inner, a caller's block in mmw_dbscan).
+__device__ __forceinline__ int cloud_nonfinite_bits(const RowSrc &src, int U)
+{
+    int nfb = 0;
+    for (int i = threadIdx.x; i < U; i += blockDim.x) {
+        const double2 *r2 = reinterpret_cast<const double2 *>(src.row(i));
+        const double2 rr[4] = {r2[0], r2[1], r2[2], r2[3]};
+        nfb |= row_nonfinite_bits(rr);
+    }
+    const int any_nan = __syncthreads_or(nfb & 1), any_inf = __syncthreads_or(nfb & 2);
+    return (any_nan ? 1 : 0) | (any_inf ? 2 : 0);
+}
 
 // apply_DBscan found (or can find) nothing: labels -1, bookkeeping as after a full run with 0 clusters
 // (all threads of the workgroup call)

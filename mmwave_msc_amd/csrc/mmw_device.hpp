@@ -19,7 +19,10 @@ constexpr int kBigCloudMax = 30 * 64;  // = 1920: the largest cloud whose BallTr
 constexpr int kMaxNodes = 63;
 
 // per-scene error bits (sticky until mmw_reset)
-enum : int { ERR_SINGULAR = 1, ERR_DIVZERO = 2, ERR_CAPACITY = 4, ERR_BADCOUNT = 8 };
+// ERR_NONFINITE_*: apply_DBscan was reached with a NaN / an infinite value in its cloud -- sklearn's input validation raises
+// ValueError there (Utils.py:272-278): "contains NaN" when any value is NaN, else "contains infinity" (oracle/c: orc_check_finite)
+enum : int { ERR_SINGULAR = 1, ERR_DIVZERO = 2, ERR_CAPACITY = 4, ERR_BADCOUNT = 8, ERR_NONFINITE_NAN = 16, ERR_NONFINITE_INF = 32 };
+constexpr int kDbRaised = -2;   // db_n of a frame whose apply_DBscan call "raised" (MMW_DB_RAISED; -1 = not called)
 
 struct DevCfg {
     int32_t ring;            // FB_FRAMES_BATCH + 1
@@ -61,9 +64,35 @@ struct SceneHdr {
     int32_t next_uid;              // TrackBuffer.next_track_id (Tracking.py:509,588)
     int32_t n_upd;                 // tracks after _maintain_tracks of this frame = what _update_all covers (k_track -> k_post)
     int32_t skipped;               // bit 0: the last frame was empty for this scene (k_track returned at once): its tracks are in no update list;
-                                   // bits 8..15: size of the global ring after BatchedData.change_buffer_size (0 = FB_FRAMES_BATCH + 1)
+                                   // bits 8..15: size of the global ring after BatchedData.change_buffer_size (0 = FB_FRAMES_BATCH + 1);
+                                   // bits 16..23: two per PHYSICAL slot p of the global ring -- bit 16 + 2p: the frame stored there holds a
+                                   // NaN, bit 17 + 2p: an infinite value (any of the 8 columns; set by whoever writes a frame into the slot)
 };
 static_assert(sizeof(SceneHdr) == 64, "SceneHdr");
+constexpr int kSkipRingShift = 8, kSkipRingMask = 255, kSkipNfShift = 16, kSkipNfMask = 255;
+__host__ __device__ inline int hdr_ring_size(int skipped) { return (skipped >> kSkipRingShift) & kSkipRingMask; }
+// bit 0: a NaN, bit 1: an infinite value among the 8 columns of one row (x, y, z, vx, vy, vz, doppler, peakVal).  One
+// v_cmp_class_f64 per value; the second pass only for the (rare) row that has one.
+__device__ __forceinline__ int row_nonfinite_bits(const double2 (&r)[4])
+{
+    constexpr int kNanInf = 0x3 | 0x4 | 0x200;   // sNaN | qNaN | -inf | +inf
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) any = any || __builtin_amdgcn_class(r[u].x, kNanInf) || __builtin_amdgcn_class(r[u].y, kNanInf);
+    if (!any) return 0;
+    bool nan = false, inf = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        nan = nan || __builtin_amdgcn_class(r[u].x, 0x3) || __builtin_amdgcn_class(r[u].y, 0x3);
+        inf = inf || __builtin_amdgcn_class(r[u].x, 0x204) || __builtin_amdgcn_class(r[u].y, 0x204);
+    }
+    return (nan ? 1 : 0) | (inf ? 2 : 0);
+}
+// The flags word after a frame with row bits `frame_bits` has been written into physical slot `phys`, and what the live
+// frames gs[0 .. len) hold together (bit 0 NaN, bit 1 inf).
+__host__ __device__ inline int nf_flags_with(int flags, int phys, int frame_bits) { return (flags & ~(3 << (2 * phys))) | ((frame_bits & 3) << (2 * phys)); }
+// which ValueError sklearn raises for a cloud with these bits (NaN takes precedence)
+__host__ __device__ inline int nf_error_of(int bits) { return (bits & 1) ? ERR_NONFINITE_NAN : ((bits & 2) ? ERR_NONFINITE_INF : 0); }
 
 // One ClusterTrack.  187 doubles = 1496 B.
 struct TrackRec {

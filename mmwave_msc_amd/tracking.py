@@ -150,6 +150,7 @@ class TrackBuffer:
         self._raw_buf = None         # track_raw's upload block [1, max_pts, 5]
         self._fused_model = None     # attach_posture_model: estimate_posture runs inside track() / track_raw()'s round trip
         self._posture_done = False   # ... and has run for the last frame
+        self._pending = None         # the reference's ValueError of the frame in flight (raised once its results are taken)
 
     def _ensure(self):
         if self._sb is None:
@@ -198,9 +199,28 @@ class TrackBuffer:
         pts[0, :n] = pc
         # an empty cloud still IS a track() call (predict, ageing / expiry, _update_all, an empty ring frame): the C-ABI's
         # count 0 means "frame skipped" (offline_main.py:56), MMW_EMPTY_FRAME means this.  ONE round trip (mmw_frame_host).
-        r = sb.frame_host(np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), np.array([float(self.dt)]), pts=pts,
-                          posture=self._fused_model is not None, reuse_out=True)
+        r = self._frame(sb, np.array([n if n > 0 else _lib.EMPTY_FRAME], np.int32), pts=pts)
         self._take(r, n)
+        self._reraise()
+
+    def _frame(self, sb, n, **kw):
+        """One round trip (mmw_frame_host).  The reference's track() raises ValueError when apply_DBscan is reached with a NaN / an
+        infinite value in the ring (sklearn's input validation, Utils.py:272-278) -- AFTER everything else the frame does: the
+        results are taken as usual, the scene's sticky bit is cleared (the state is exactly what the reference's is when the
+        exception leaves track(); the error comes back with the next frame while the row is in the ring) and the exception --
+        a ValueError -- is raised once they are in place (`_reraise`)."""
+        self._pending = None
+        try:
+            return sb.frame_host(n, np.array([float(self.dt)]), posture=self._fused_model is not None, reuse_out=True, **kw)
+        except _lib.MmwNonFinite as e:
+            sb.clear_errors(_lib.ERRBIT_NONFINITE_NAN | _lib.ERRBIT_NONFINITE_INF)
+            self._pending = e
+            return sb._frame_out
+
+    def _reraise(self):
+        e, self._pending = self._pending, None
+        if e is not None:
+            raise e
 
     def _take(self, r, n):
         self._posture_done = "posture_rows" in r
@@ -229,11 +249,11 @@ class TrackBuffer:
             buf = self._raw_buf = np.zeros((1, self._max_pts, 5))
         for i, k in enumerate(("x", "y", "z", "doppler", "peakVal")):
             buf[0, :m, i] = detObj[k]
-        r = sb.frame_host(np.array([m], np.int32), np.array([float(self.dt)]), raw=buf, want_rows=want_rows,
-                          posture=self._fused_model is not None, reuse_out=True)
+        r = self._frame(sb, np.array([m], np.int32), raw=buf, want_rows=want_rows)
         n = int(r["n_out"][0])
         if n > 0:
             self._take(r, n)
+        self._reraise()
         return (n, r["rows"][0, :n].copy()) if want_rows else n
 
     def estimate_posture(self, model):

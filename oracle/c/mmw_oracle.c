@@ -1057,6 +1057,14 @@ int orc_normalize(const orc_config *c, const double *raw, int n, double *out)
         o[5] = c->tilt_sin * vy + c->tilt_cos * vz;
         o[6] = dop;
         o[7] = pk;
+        /* Non-finite rows.  point_transform_to_standard_axis multiplies full homogeneous 4-vectors by full 4x4 matrices
+         * (Utils.py:311-326: np.dot(T, np.dot(R_inv, [x, y, z, 1]))), zeros included: a NaN or an infinite coordinate meets a
+         * zero in the last row of R_inv (0 * inf = NaN), that NaN meets every row of T -- so ONE non-finite coordinate makes
+         * all three transformed coordinates NaN, and the scene filter (NaN compares false, Utils.py:422-427) drops the row.
+         * The velocity vector [vx, vy, vz, 0] goes the same way: one non-finite component (a NaN / infinite doppler) makes
+         * all three NaN; the row is kept with them when its coordinates pass.  (For finite rows the zero terms change nothing.) */
+        if (!isfinite(x) || !isfinite(y) || !isfinite(z)) o[0] = o[1] = o[2] = NAN;
+        if (!isfinite(vx) || !isfinite(vy) || !isfinite(vz)) o[3] = o[4] = o[5] = NAN;
         if (o[2] <= 2.5 && o[2] > 0 && o[1] > 0) { memcpy(out + (size_t)m * 8, o, sizeof(o)); m++; }
     }
     return m;

@@ -132,3 +132,23 @@ def plant_nonfinite(case: dict, pts: np.ndarray, cnt: np.ndarray, rate: float = 
                 pts[f, s, r, col] = (np.nan, np.inf, -np.inf)[int(rng.integers(0, 3))]
                 planted.append((f, s, r, col))
     return planted
+
+
+def nonfinite_raw_rows(seed: int, n: int = 160) -> np.ndarray:
+    """Raw radar rows (x, y, z, doppler, peakVal) most of which pass normalize_data's scene filter, with NaN / +inf / -inf planted
+    in random columns of every third row (some rows twice), the r == 0 row, and x = 0 with an infinite doppler."""
+    rng = np.random.default_rng(4400 + seed)
+    raw = np.zeros((n, 5))
+    raw[:, 0] = rng.uniform(-3, 3, n)
+    raw[:, 1] = rng.uniform(0.5, 7, n)
+    raw[:, 2] = rng.uniform(-1.6, 0.5, n)
+    raw[:, 3] = rng.normal(0, 0.6, n)
+    raw[:, 4] = rng.integers(0, 400, n)
+    raw[0, :3] = 0.0
+    raw = raw.astype(np.float32).astype(np.float64)
+    for i in range(4, n, 3):
+        raw[i, int(rng.integers(0, 5))] = (np.nan, np.inf, -np.inf)[int(rng.integers(0, 3))]
+        if rng.random() < 0.3:
+            raw[i, int(rng.integers(0, 5))] = (np.nan, np.inf, -np.inf)[int(rng.integers(0, 3))]
+    raw[1, 0], raw[1, 3] = 0.0, np.inf
+    return raw

@@ -450,3 +450,76 @@ def test_batcheddata_init_data_and_change_buffer_size():
         tb2.dt = 0.1
         tb2.track(g["pts"][0, :32].astype(np.float64), batch2)
         batch2.change_buffer_size(0)   # the reference's add_frame would spin forever: MMW_E_ARG here
+
+
+def test_trackbuffer_raises_the_references_valueerror_on_nonfinite_rows():
+    """The `nonfinite` recording (oracle/gen_golden.py): NaN / +-inf rows enter the global ring and sklearn's input validation
+    raises ValueError out of the reference's track() on every frame apply_DBscan is reached while one is there
+    (Utils.py:272-278, Tracking.py:693-697).  The drop-in TrackBuffer raises a ValueError on exactly those frames -- after the
+    frame's results are in place --, keeps the state the exception leaves behind, and carries on like the reference when the
+    caller catches it.  apply_DBscan / normalize_data of the Utils mirror behave as theirs on such rows too."""
+    from mmwave_msc_amd import _lib, utils
+    from mmwave_msc_amd import constants as const
+    from mmwave_msc_amd.tracking import BatchedData, TrackBuffer
+    g = load_scenario("nonfinite")
+    saved = const.TR_MAX_TRACKS
+    const.TR_MAX_TRACKS = int(g["overrides"]["TR_MAX_TRACKS"])
+    try:
+        tb, batch = TrackBuffer(max_pts=g["pts"].shape[1]), BatchedData()
+        n_raised = 0
+        for f in range(g["pts"].shape[0]):
+            c = int(g["cnt"][f])
+            tb.dt = float(g["dt"][f])
+            raised = int(g["raised"][f])
+            if raised:
+                with pytest.raises(ValueError) as ei:
+                    tb.track(g["pts"][f, :c].astype(np.float64), batch)
+                assert isinstance(ei.value, _lib.MmwNonFinite) and ("NaN" if raised == 1 else "infinity") in str(ei.value), f
+                assert tb.last_db_labels is None
+                n_raised += 1
+            else:
+                tb.track(g["pts"][f, :c].astype(np.float64), batch)
+                dbn = int(g["db_n"][f])
+                assert (tb.last_db_labels is None) == (dbn < 0), f
+                if dbn >= 0:
+                    assert np.array_equal(tb.last_db_labels, g["labels"][f, :dbn]), f
+            assert np.array_equal(tb.last_assoc, g["assoc"][f, :c]), f
+            nt = int(g["n_tracks"][f])
+            tracks = tb.effective_tracks
+            assert len(tracks) == nt, f
+            for j, t in enumerate(tracks):
+                w = g["tracks"][f, j]
+                assert close64(t.state.x[:, 0], w["x"]) and close64(t.state.P, w["P"]) and t.cluster.point_num == w["point_num"], (f, j)
+            assert [len(fr) for fr in batch.buffer] == list(g["ring_n"][f, : g["ring_len"][f]]), f
+        assert n_raised == int((g["raised"] > 0).sum()) >= 6
+        tb._sb.check()   # (the sticky bits were cleared frame by frame)
+        tb.close()
+    finally:
+        const.TR_MAX_TRACKS = saved
+    # Utils.apply_DBscan on a cloud with a non-finite value: sklearn's ValueError; which message: NaN wins over infinity
+    z = np.load(os.path.join(GOLDEN, "dbscan.npz"))
+    for n in (61, 700, 1536):
+        for col, val, word in ((0, np.nan, "NaN"), (7, np.inf, "infinity"), (2, -np.inf, "infinity")):
+            pts = z[f"pts_{n}"].astype(np.float64)
+            pts[n // 2, col] = val
+            with pytest.raises(ValueError) as ei:
+                utils.apply_DBscan(pts)
+            assert word in str(ei.value), (n, col)
+        pts = z[f"pts_{n}"].astype(np.float64)
+        pts[0, 6], pts[n - 1, 1] = np.inf, np.nan
+        with pytest.raises(ValueError) as ei:
+            utils.dbscan_labels(pts)
+        assert "NaN" in str(ei.value)
+    # normalize_data: one non-finite coordinate turns all three into NaN (the reference's full 4 x 4 products: 0 * inf) and the
+    # scene filter drops the row; a non-finite doppler leaves three NaN velocities on a kept row -- against the oracle's
+    # restatement, which tests/test_reference_fuzz.py pins on the live reference with the same rows
+    from oracle import c_oracle as co
+    from tests._fuzz import nonfinite_raw_rows
+    zn = np.load(os.path.join(GOLDEN, "normalize.npz"))
+    for seed in range(4):
+        raw = nonfinite_raw_rows(seed)
+        det = {"x": list(raw[:, 0]), "y": list(raw[:, 1]), "z": list(raw[:, 2]), "doppler": list(raw[:, 3]), "peakVal": list(raw[:, 4])}
+        out = utils.normalize_data(det)
+        want = co.normalize(co.default_config(s_height=float(zn["s_height"]), s_tilt=float(zn["s_tilt"])), raw)
+        assert out.shape == want.shape and np.array_equal(out, want, equal_nan=True), seed
+        assert np.isnan(out[:, 3:6]).any() and not np.isnan(out[:, :3]).any() and len(out) < 140

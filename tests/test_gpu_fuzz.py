@@ -157,3 +157,100 @@ def test_scene_reset_after_a_reference_exception_vs_oracle(seed, layout):
     assert resets >= 1
     sb.check()
     sb.close()
+
+
+N_NONFINITE = 24
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("seed", range(5000, 5000 + N_NONFINITE))
+def test_random_configuration_with_nonfinite_rows_vs_oracle(seed, layout):
+    """The non-finite arm (tests/_fuzz.py: plant_nonfinite): NaN / +inf / -inf in random columns of random rows -- x, y, z, the
+    velocities, doppler, peakVal; rows that stay unassigned and rows a track would have taken.  The reference raises ValueError
+    out of apply_DBscan on every frame such a row is in the global ring while the trigger holds (sklearn's input validation,
+    Utils.py:272-278; pinned on the live reference by tests/test_reference_fuzz.py and the `nonfinite` golden).  Here: db_n =
+    MMW_DB_RAISED for exactly those scenes and frames, the sticky bit names sklearn's message (NaN wins over infinity), the
+    frame's association and every scene's state equal the oracle's bit for bit, and after mmw_clear_errors the scene carries
+    on as the reference does after the exception.  seek_inner configurations can raise INSIDE _associate_points_to_tracks (an
+    assigned point's NaN doppler reaches the inner apply_DBscan): the scene is flagged, then reset on both sides."""
+    from mmwave_msc_amd import _lib
+    from oracle import c_oracle as co
+    from tests._fuzz import plant_nonfinite
+    case = draw_case(seed)
+    kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
+    pts, cnt, dts = scene_inputs(case)
+    planted = plant_nonfinite(case, pts, cnt, rate=0.3)
+    sb = make_checked(S, N, layout, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    NF = _lib.ERRBIT_NONFINITE_NAN | _lib.ERRBIT_NONFINITE_INF
+    n_raised = n_inner = 0
+    for f in range(F):
+        want, raised, inner_raised, failed = [None] * S, {}, {}, {}
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c == 0:
+                continue
+            try:
+                want[s] = scenes[s].track(pts[f, s, : max(c, 0)].astype(np.float64), float(dts[f, s]))
+            except co.OracleNonFinite as e:
+                bit = _lib.ERRBIT_NONFINITE_NAN if e.kind == "NaN" else _lib.ERRBIT_NONFINITE_INF
+                if scenes[s].last_db_n == co.DB_RAISED:
+                    raised[s] = bit
+                    want[s] = (scenes[s].last_assoc, None)
+                else:
+                    inner_raised[s] = bit      # inside seek_inner_clusters: the reference's track() stopped half-way
+            except RuntimeError as e:
+                failed[s] = int(str(e).rsplit("rc=", 1)[1])
+        if failed:     # LinAlgError / ZeroDivisionError / a capacity limit: covered by test_random_configuration_vs_oracle
+            break
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f], raise_nonfinite=False)
+        err = sb.errors()
+        for s in range(S):
+            want_bit = raised.get(s, 0) | inner_raised.get(s, 0)
+            assert (err[s] & NF) == want_bit or (s in inner_raised and (err[s] & NF)), (seed, f, s, err[s], raised, inner_raised)
+            assert (err[s] & ~NF) == 0, (seed, f, s, err[s])
+            if s not in inner_raised:   # (a scene that went on past the reference's mid-frame exception may raise at its trigger too)
+                assert (dbn[s] == _lib.DB_RAISED) == (s in raised), (seed, f, s, dbn[s])
+        if raised or inner_raised:
+            with pytest.raises(ValueError):
+                sb.check()
+            sb.clear_errors(NF)
+        if inner_raised:
+            mask = np.zeros(S, bool)
+            mask[list(inner_raised)] = True
+            sb.reset_scenes(mask)
+            for s in inner_raised:
+                scenes[s] = co.OracleScene(cfg, N)
+            n_inner += len(inner_raised)
+        n_raised += len(raised)
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=max(int(ntr.max()), 1))
+        ln, rn = sb.batch_ring()
+        feat, owner = sb.features_host() if f in (F // 2, F - 1) else (None, None)
+        row = 0
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c != 0 and s not in inner_raised:
+                n = max(c, 0)
+                oa, ol = want[s]
+                assert np.array_equal(assoc[s, :n], oa), (seed, f, s)
+                assert (ol is None) == (dbn[s] < 0), (seed, f, s, dbn[s])
+                if ol is not None:
+                    assert dbn[s] == len(ol) and np.array_equal(labels[s, : dbn[s]], ol), (seed, f, s)
+            assert ntr[s] == scenes[s].n_tracks, (seed, f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"seed {seed} f{f} s{s}", exact=True)
+            assert np.array_equal(rn[s, : ln[s]], scenes[s].batch_ring()), (seed, f, s)
+            if feat is not None:
+                of, oo = scenes[s].features()
+                k = len(oo)
+                assert np.all(owner[row: row + k, 0] == s) and np.array_equal(owner[row: row + k, 1], oo), (seed, f, s)
+                if k:
+                    assert np.array_equal(feat[row: row + k], of, equal_nan=True), (seed, f, s)
+                row += k
+        if feat is not None:
+            assert row == len(owner), (seed, f)
+    sb.check()
+    sb.close()
+    assert planted
+    case["seen"] = dict(raised=n_raised, inner=n_inner)

@@ -58,12 +58,30 @@ def test_golden_scenario(name):
         pts[0, :c] = g["pts"][f, :c]
         track_empty = bool(g["overrides"].get("TRACK_EMPTY"))   # the scenario calls track() on its empty frames
         n_arg = c if (c > 0 or not track_empty) else -1             # MMW_EMPTY_FRAME
-        assoc, labels, dbn = sb.step_host(pts, np.array([n_arg], np.int32), np.array([g["dt"][f]]))
+        raised = int(g["raised"][f]) if "raised" in g else 0
+        assoc, labels, dbn = sb.step_host(pts, np.array([n_arg], np.int32), np.array([g["dt"][f]]), raise_nonfinite=False)
         if c == 0 and not track_empty:
             assert dbn[0] == -1
             assert sb.num_tracks()[0] == g["n_tracks"][f]
             continue
-        o_assoc, o_lab = orc.track(pts[0, :c], float(g["dt"][f]))
+        if raised:
+            # the reference raised ValueError out of apply_DBscan (a NaN / an infinite value in the ring, Utils.py:272-278):
+            # db_n = MMW_DB_RAISED, the scene's sticky bit says which message, mmw_check reports MMW_E_NONFINITE -- a ValueError
+            # in the Python binding -- and after mmw_clear_errors the scene carries on in the state the exception left
+            from mmwave_msc_amd import _lib
+            assert dbn[0] == _lib.DB_RAISED, f"{name} f{f}: db_n {dbn[0]}"
+            assert sb.errors()[0] == (_lib.ERRBIT_NONFINITE_NAN, _lib.ERRBIT_NONFINITE_INF)[raised - 1], f"{name} f{f}: which ValueError"
+            with pytest.raises(ValueError) as ei:
+                sb.check()
+            assert ei.value.code == _lib.E_NONFINITE and ("NaN" if raised == 1 else "infinity") in str(ei.value)
+            sb.clear_errors(_lib.ERRBIT_NONFINITE_NAN | _lib.ERRBIT_NONFINITE_INF)
+            with pytest.raises(co.OracleNonFinite):
+                orc.track(pts[0, :c], float(g["dt"][f]))
+            o_assoc, o_lab = orc.last_assoc, None
+            dbn[0] = -1   # (the recording's db_n of a raising frame: no labels)
+        else:
+            assert sb.errors()[0] == 0, f"{name} f{f}"
+            o_assoc, o_lab = orc.track(pts[0, :c], float(g["dt"][f]))
         # (a) golden
         assert np.array_equal(assoc[0, :c], g["assoc"][f, :c]), f"{name} f{f}: association vs golden"
         assert dbn[0] == g["db_n"][f], f"{name} f{f}: db_n {dbn[0]} vs {g['db_n'][f]}"
@@ -94,7 +112,7 @@ def test_golden_scenario(name):
             assert np.array_equal(owner[:, 1], g["owner"][f, :nf]) and np.all(owner[:, 0] == 0)
             assert_feat_equal(feat, g["feat"][f, :nf], ctx=f"{name} f{f}")
             o_feat, o_own = orc.features()
-            assert np.array_equal(feat, o_feat), f"{name} f{f}: features vs oracle"
+            assert np.array_equal(feat, o_feat, equal_nan=True), f"{name} f{f}: features vs oracle"
     sb.close()
 
 

@@ -160,3 +160,24 @@ def test_live_reference_vs_c_oracle_with_nonfinite_rows(seed):
         for r in refs:
             r.close()
     assert planted
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_live_reference_normalize_data_with_nonfinite_rows(seed):
+    """normalize_data (Utils.py:342-434) on raw rows with NaN / +-inf planted in every column: the full 4x4 homogeneous products
+    of point_transform_to_standard_axis turn ONE non-finite coordinate into three NaN coordinates (0 * inf), which the scene
+    filter drops; a non-finite doppler gives three NaN velocities on a row that is kept; peakVal passes through."""
+    from oracle import c_oracle as co
+    from oracle.ref_import import load_reference
+    const, utils, _ = load_reference()
+    from tests._fuzz import nonfinite_raw_rows
+    raw = nonfinite_raw_rows(seed)
+    det = {"x": list(raw[:, 0]), "y": list(raw[:, 1]), "z": list(raw[:, 2]), "doppler": list(raw[:, 3]), "peakVal": list(raw[:, 4])}
+    with np.errstate(all="ignore"):
+        want = utils.normalize_data(det)
+    cfg = co.default_config(s_height=float(const.S_HEIGHT), s_tilt=float(const.S_TILT))
+    got = co.normalize(cfg, raw)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+    assert np.allclose(got, want, rtol=0, atol=1e-12, equal_nan=True)
+    assert np.isnan(want[:, 3:6]).any() and not np.isnan(want[:, :3]).any() and len(want) < 140
