@@ -1713,11 +1713,16 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
 //                    (update_tracks_wave, mmw_kalman.hpp) -- the bulk work the BallTree scenes hide under.
 // The two touch disjoint state: the update covers the hdr->n_upd tracks that existed before this frame's
 // clusters, the spawn appends records behind them.
-// Three waves per SIMD (168 VGPRs): the BallTree path of the worker blocks would take 204 and hold the update waves -- the
-// bulk of the launch -- at two per SIMD; with the cap the workers spill 92 bytes per lane and k_post is 41 -> 37 us
-// (four per SIMD: 300 bytes of spills, 45 us).
+// Two waves per SIMD (no register cap: the BallTree path of the worker blocks takes ~205 VGPRs, the update 156).  Rounds 2-4 ran
+// the launch under a 168-VGPR cap (three waves per SIMD) for the update's sake, the workers spilling 54 VGPRs / 188 bytes of
+// scratch per lane; since the update's broadcasts moved from the LDS to DPP moves (round 4) the third wave buys it nothing --
+// same box, alternating (scripts/ab_libs.sh, profiles/NOTEBOOK.md round 5): 4096 scenes k_post 36-38 us either way, 512 scenes
+// (whose DBSCAN is all in these worker blocks) 16.6 -> 14.5 us, the step 0.0648 -> 0.0627 ms -- and nothing spills.
+#ifndef MMW_POST_OCC   // (diagnostic builds: another register budget for the launch)
+#define MMW_POST_OCC 2
+#endif
 template <int DX>
-__global__ __launch_bounds__(256, 3) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
+__global__ __launch_bounds__(256, MMW_POST_OCC) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
                                               int UMb, int CLb, int UM_out, int parity, int epoch, int32_t *__restrict__ labels_out,
                                               int32_t *__restrict__ db_n_out)
 {

@@ -71,8 +71,14 @@ __device__ __forceinline__ bool dense_pick(const DevCfg &cfg, const DevState &st
 //   * contexts with t_cap > 63 or too few tracks to fill the chip (tracks_dense, mmw_kalman.hpp): the per-scene layout, wave q of a scene's nq takes tracks 4q.., 4(q+nq)..
 // An empty frame (n_pts <= 0) predicts nothing (offline_main.py:56: such frames never reach track()).
 constexpr int kSpecialUnits = 64;
+// Three waves per SIMD (134 VGPRs, nothing spilled).  Rounds 1-4 capped the kernel at 128 VGPRs for a fourth wave, at the price of
+// 2 spilled VGPRs and a scratch-enabled dispatch of 8256 workgroups; same box, alternating (scripts/ab_libs.sh, NOTEBOOK round 5):
+// 4096 scenes 20.4-21.0 us capped against 20.1-20.4, 1024 scenes 11.8 against 11.1.
+#ifndef MMW_PRED_OCC   // (diagnostic builds: another register budget)
+#define MMW_PRED_OCC 3
+#endif
 template <int DX>
-__global__ __launch_bounds__(64, 4) void k_predict(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts,
+__global__ __launch_bounds__(64, MMW_PRED_OCC) void k_predict(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts,
                                                 const double *__restrict__ dt_all, int nq, int parity)
 {
     __shared__ double lds[4 * kPredScratch];

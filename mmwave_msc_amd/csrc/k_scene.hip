@@ -221,7 +221,11 @@ __device__ __forceinline__ void update_round(const Lds &L, TrackRec *trk, int j0
 using namespace scene;
 
 template <int NT, int PPT, int DX, bool F32 = false>
-__global__ __launch_bounds__(NT, NT / 128) void k_scene(DevCfg cfg, DevState st, const void *__restrict__ pts_all, const int32_t *__restrict__ n_pts,
+// Register budget: two workgroups per CU (256 VGPRs per wave) for up to 512 points per frame; four points per thread (513..1024
+// points) need ~265 and would spill 8-10 of them into scratch memory there: those instantiations take ONE workgroup per CU --
+// the unified register file then gives a wave 512 registers and the surplus sits in AGPRs (mmw_api.hip sizes "all scenes
+// resident" accordingly: 256 scenes).
+__global__ __launch_bounds__(NT, PPT >= 4 ? NT / 256 : NT / 128) void k_scene(DevCfg cfg, DevState st, const void *__restrict__ pts_all, const int32_t *__restrict__ n_pts,
                                                        const double *__restrict__ dt_all, int32_t *__restrict__ assoc_out,
                                                        int32_t *__restrict__ db_n_out, int32_t *__restrict__ db_labels_out, int UM_out, int parity)
 {

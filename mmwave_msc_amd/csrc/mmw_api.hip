@@ -380,7 +380,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         // seek_inner (k_inner sits between association and update), the side-stream workers (they claim scenes while the
         // association kernel runs) or more than 63 tracks per scene (a lane per track in its maintenance step).
         const size_t sl = scene_lds_bytes(d);
-        const int per_cu = sl <= 80 * 1024 ? 2 : (sl <= 160 * 1024 ? 1 : 0);
+        // (more than 512 points per frame: four points per thread, a register budget of one workgroup per CU -- k_scene.hip)
+        const int per_cu = (sl <= 80 * 1024 && max_pts <= 512) ? 2 : (sl <= 160 * 1024 ? 1 : 0);
         const bool can = per_cu > 0 && !d.seek_inner && d.t_cap <= 63 && cfg->chain_side_stream <= 0;
         const bool want = cfg->fused_step > 0 || (cfg->fused_step == 0 && cfg->kalman_dense_min_units == 0 && n_scenes <= 256 * per_cu && n_scenes <= kPerSceneMaxScenes);
         c->fused_wanted = d.fused = (can && want) ? 1 : 0;

@@ -62,43 +62,86 @@ def test_track_record_dtype_matches_c_struct():
     assert _lib.SUMMARY_DTYPE.itemsize == 5 * 4 + 4 + (9 + 6 + 57) * 4 + 3 * 4
 
 
-def test_step_kernels_compile_without_scratch():
-    """All three points-per-thread variants of the association kernel are kept free of register spills (a build
-    that spilled, while its LDS-only barrier was still inline assembly, once produced spurious error bits on the
-    GPU; the barrier is compiler builtins now, the no-spill rule stays).  This reads the compiler's own resource
-    report so that a later change cannot reintroduce spills silently."""
+_ISA_CACHE = {}
+
+
+def _device_isa(names):
+    """(resource report, ISA text) of csrc/<name>.hip for gfx950 with the product's flags: ONE device-only compile per file gives
+    both (the remarks on stderr, the assembly on stdout); files compile side by side and are cached for the session."""
     import os
-    import re
     import shutil
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         import pytest
         pytest.skip("hipcc not available")
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmwave_msc_amd", "csrc", "k_track.hip")
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                          "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
-                         capture_output=True, text=True, timeout=600)
-    rep = out.stderr
-    names = re.findall(r"Function Name: (\S*k_track\S*)", rep)
-    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", rep)]
-    vspill = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", rep)]
-    assert len(names) >= 6 and len(scratch) >= 6 and len(vspill) >= 6, rep[-2000:]
-    # no vector register is spilled in any instantiation
-    assert all(v == 0 for v in vspill[: len(names)]), list(zip(names, vspill))
-    # Any instantiation may keep an SGPR-spill stack slot the compiler reserves but never touches (scalars parked in the lanes of a
-    # VGPR by v_writelane): the ISA of such a kernel must not hold a single scratch access -- the instantiations of the
-    # benchmarked configurations (PPT 1 and 2, INNER = PRED = false, fp64 and fp32 rows: mangled "ILi<PPT>ELb0ELb0ELb<F32>E") included
-    hot = [n for n in names if re.search(r"k_trackILi[12]ELb0ELb0ELb[01]E", n)]
-    assert len(hot) == 4, names
-    slotted = [n for n, v in zip(names, scratch) if v != 0]
-    if slotted:
-        asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                              "--cuda-device-only", "-S", "-c", src, "-o", "-"], capture_output=True, text=True, timeout=600).stdout
-        for n in slotted:
-            body = asm[asm.index("\n" + n + ":"):]
-            body = body[: body.index("s_endpgm")]
-            assert not re.search(r"\bscratch_|buffer_(load|store)\S* .*offen", body), n
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmwave_msc_amd", "csrc")
+
+    def one(name):
+        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only",
+                              "-Rpass-analysis=kernel-resource-usage", "-S", "-c", os.path.join(root, name + ".hip"), "-o", "-"],
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stderr, out.stdout
+
+    todo = [n for n in names if n not in _ISA_CACHE]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for n, r in zip(todo, ex.map(one, todo)):
+            _ISA_CACHE[n] = r
+    return {n: _ISA_CACHE[n] for n in names}
+
+
+def _kernel_report(rep):
+    """[(mangled name, scratch bytes per lane, spilled VGPRs, VGPRs, waves per SIMD)] from -Rpass-analysis=kernel-resource-usage."""
+    import re
+    out = []
+    for blk in re.split(r"remark: Function Name: ", rep)[1:]:
+        name = blk.split()[0]
+        f = lambda pat: int(re.search(pat, blk).group(1))
+        out.append((name, f(r"ScratchSize \[bytes/lane\]: (\d+)"), f(r"VGPRs Spill: (\d+)"), f(r" VGPRs: (\d+)"), f(r"Occupancy \[waves/SIMD\]: (\d+)")))
+    return out
+
+
+# The one kernel that is ALLOWED to spill, with the ceiling it must stay under: k_dbscan_startup (frame 0 after a reset: every scene
+# clusters its whole first frame) takes two 512-thread workgroups per CU, i.e. 128 registers per lane, for a BallTree chain that wants
+# ~180 -- measured 3.0 ms per 4096 clouds that way against 4.0 ms unspilled at one workgroup per CU (k_dbscan.hip: launch_dbscan_big).
+_MAY_SPILL = {"k_dbscan_startup": 52}
+
+
+def test_step_kernels_compile_without_scratch():
+    """No kernel of a step touches scratch memory: the association kernel (all its instantiations), the one-workgroup step
+    (k_scene, every points-per-thread variant), the batched Kalman kernels (k_predict, k_post's update), the DBSCAN workers
+    (k_post's worker blocks, k_chain, k_dbscan_big, k_dbscan_huge, k_inner).  Read from the compiler's own resource report AND
+    from the ISA: zero spilled VGPRs, and not one scratch access -- a kernel may keep an SGPR-spill stack slot the compiler
+    reserves but never touches (scalars parked in the lanes of a VGPR by v_writelane).  (A spilling build once cost 9 minutes
+    instead of 16 s on the GPU; round 4's review found 54 spilled VGPRs in k_post and 2 in k_predict that nothing guarded.)"""
+    import re
+    files = ("k_track", "k_scene", "k_kalman", "k_dbscan")
+    isa = _device_isa(files)
+    seen = {}
+    for f in files:
+        rep, asm = isa[f]
+        kernels = _kernel_report(rep)
+        assert kernels, rep[-2000:]
+        for name, scratch, vspill, vgprs, occ in kernels:
+            short = re.search(r"\d+(k_[a-z_]+?)(I|E)", name).group(1)
+            seen.setdefault(short, []).append((name, vgprs, occ))
+            if short in _MAY_SPILL:
+                assert vspill <= _MAY_SPILL[short], (name, vspill)
+                continue
+            assert vspill == 0, (name, vspill, vgprs, occ)
+            if scratch:
+                body = asm[asm.index("\n" + name + ":"):]
+                body = body[: body.index("s_endpgm")]
+                assert not re.search(r"\bscratch_|buffer_(load|store)\S* .*offen", body), (name, scratch)
+    for k in ("k_track", "k_scene", "k_predict", "k_post", "k_chain", "k_dbscan_big", "k_dbscan_huge", "k_inner", "k_dbscan_startup"):
+        assert k in seen, (k, sorted(seen))
+    assert len(seen["k_track"]) == 24 and len(seen["k_scene"]) == 12 and len(seen["k_post"]) == 2 and len(seen["k_predict"]) == 2
+    # the benchmarked instantiations keep the occupancy their launch geometry is sized for
+    for name, vgprs, occ in seen["k_track"]:
+        if re.search(r"k_trackILi[12]ELb0ELb0ELb[01]E", name):
+            assert occ >= (5 if "ILi2E" in name else 4) or vgprs <= 96, (name, vgprs, occ)
 
 
 def test_gate_records_are_not_read_before_the_scalar_cache_invalidate():
@@ -107,18 +150,10 @@ def test_gate_records_are_not_read_before_the_scalar_cache_invalidate():
     unchanging, so the pointer is laundered through an asm statement behind the s_dcache_inv; this reads the ISA: the
     invalidate precedes the marker, the wide scalar loads of the gate loop follow it, and none of them sits in front of
     the invalidate (k_scene loads its 64-byte scene header with one s_load_dwordx16 there: exactly one is allowed)."""
-    import os
     import re
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        import pytest
-        pytest.skip("hipcc not available")
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mmwave_msc_amd", "csrc")
+    isa = _device_isa(("k_track", "k_scene"))
     for src, pat, allowed_before in (("k_track.hip", r"^(_ZN3mmw7k_trackILi\dELb[01]ELb1ELb[01]EE\S*):", 0), ("k_scene.hip", r"^(_ZN3mmw7k_sceneILi\d+ELi\dELi\dELb[01]EE\S*):", 1)):
-        asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only", "-S",
-                              "-c", os.path.join(root, src), "-o", "-"], capture_output=True, text=True, timeout=900).stdout
+        asm = isa[src[:-4]][1]
         names = re.findall(pat, asm, flags=re.M)
         assert len(names) >= 6, (src, names)
         for n in names:
