@@ -119,25 +119,64 @@ def e2e_leg(sb, step, W, F, S, world, barrier, max_over_ranks, dev, stream_a, mo
 
 
 # ---------------------------------------------------------------------------------------------------------------
-def oracle_reference(workers=1, par=None):
+def oracle_reference(workers=1, par=None, procs=1):
     """configs[3] on the CPU oracle: per frame track -> features -> (CNN deferred) -> set_keypoints.  The CNN is a pure
     function of the feature tensor, so the oracle stores every tensor it would have fed to `model.predict`, tags the
     track with the tensor's index instead of real keypoints, and evaluates the fp64 CNN once at the end for the
-    tensor each surviving track was tagged with last: identical to running it every frame, at a fraction of the cost."""
+    tensor each surviving track was tagged with last: identical to running it every frame, at a fraction of the cost.
+    procs > 1: the scenes are cut into blocks that run in child processes started from scratch (scenes are independent; safe
+    in a process that has already initialised the GPU) -- configs[4] at its full 4096 scenes in ~20 s on the GPU box's 16 cores."""
     from mmwave_msc_amd.mars import random_keras_weights
-    from mmwave_msc_amd.synth import make_batch  # noqa: F401
+
+    p = dict(par or E2E_PAR)
+    t0 = time.perf_counter()
+    S = p["S"]
+    procs = max(1, min(int(procs), S // 32 if S >= 64 else 1))
+    if procs == 1:
+        blocks = [_oracle_block((p, 0, S, workers))]
+    else:
+        # (child PROCESSES started from scratch -- `python bench_e2e.py --oracle-block ...` -- not forks of this one, which may
+        #  hold a GPU context, and not multiprocessing's spawn, which re-imports the parent's __main__)
+        import json
+        import os
+        import pickle
+        import subprocess
+        import sys
+        import tempfile
+        edges = [S * i // procs for i in range(procs + 1)]
+        with tempfile.TemporaryDirectory() as tmp:
+            jobs = []
+            for i in range(procs):
+                out = os.path.join(tmp, f"block{i}.pkl")
+                jobs.append((out, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-block",
+                                                    json.dumps([p, edges[i], edges[i + 1], 1]), out])))
+            blocks = []
+            for out, job in jobs:
+                if job.wait() != 0:
+                    raise RuntimeError(f"oracle block process failed (exit code {job.returncode})")
+                with open(out, "rb") as fh:
+                    blocks.append(pickle.load(fh))
+    cat = lambda k, ax: np.concatenate([b[k] for b in blocks], axis=ax)
+    return {"par": p, "pts": cat("pts", 1), "cnt": cat("cnt", 1), "dts": cat("dts", 1),
+            "finals": [f for b in blocks for f in b["finals"]], "want_kp": [k for b in blocks for k in b["want_kp"]],
+            "weights": random_keras_weights(0, 3), "oracle_s": round(time.perf_counter() - t0, 1),
+            "samples_cnn": sum(b["samples_cnn"] for b in blocks)}
+
+
+def _oracle_block(args):
+    """scenes [s0, s1) of oracle_reference's job (module level: a spawned worker imports it)"""
+    from mmwave_msc_amd.mars import random_keras_weights
     from oracle import c_oracle as co
     from oracle.mars_np import mars_forward_np
     import bench
 
-    p = par or E2E_PAR
-    S, N, T, F = p["S"], p["N"], p["T"], p["F"]
-    ids = np.arange(p["seed0"], p["seed0"] + S)
+    p, s0, s1, workers = args
+    S, N, T, F = s1 - s0, p["N"], p["T"], p["F"]
+    ids = np.arange(p["seed0"] + s0, p["seed0"] + s1)
     pts, cnt, dts = bench.generate(ids, F, N, T, workers)
     cfg = co.default_config(tr_max_tracks=T)
     scenes = [co.OracleScene(cfg, N) for _ in range(S)]
     store = []
-    t0 = time.perf_counter()
     for f in range(F):
         for s, sc in enumerate(scenes):
             c = int(cnt[f, s])
@@ -163,8 +202,7 @@ def oracle_reference(workers=1, par=None):
     default = np.array(list(cfg.default_posture), dtype=np.float64)
     want_kp = [np.stack([kp_of[int(r["keypoints"][0])] if r["keypoints"][1] == MARK else default for r in fin])
                if len(fin) else np.zeros((0, 57)) for fin in finals]
-    return {"par": dict(p), "pts": pts, "cnt": cnt, "dts": dts, "finals": finals, "want_kp": want_kp, "weights": w,
-            "oracle_s": round(time.perf_counter() - t0, 1), "samples_cnn": len(need)}
+    return {"pts": pts, "cnt": cnt, "dts": dts, "finals": finals, "want_kp": want_kp, "samples_cnn": len(need)}
 
 
 def e2e_parity_leg(ref, device):
@@ -222,3 +260,13 @@ def e2e_parity_leg(ref, device):
             "keypoint_max_err": float(f"{max_err:.3e}"), "keypoint_tol": KP_TOL, "keypoints_ok": bool(ints_ok and max_err <= KP_TOL),
             "cnn_oracle": "oracle/mars_np.py (fp64 numpy restatement of train.py:71-106; parity unpinned: no Keras / MARS.h5 in the image)",
             "ms_per_step": round(el / F * 1e3, 4), "scene_frames_per_sec": round(S * F / el, 1), "oracle_s": ref["oracle_s"]}
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 4 and sys.argv[1] == "--oracle-block":   # a worker of oracle_reference(procs > 1): CPU only
+        import json
+        import pickle
+        a = json.loads(sys.argv[2])
+        with open(sys.argv[3], "wb") as fh:
+            pickle.dump(_oracle_block(tuple(a)), fh, protocol=pickle.HIGHEST_PROTOCOL)

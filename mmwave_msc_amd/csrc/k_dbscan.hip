@@ -1740,6 +1740,9 @@ __global__ __launch_bounds__(256, MMW_POST_OCC) void k_post(DevCfg cfg, DevState
         __device__ ~WgStamp() { if (w) { w[2] = __builtin_amdgcn_s_memrealtime(); w[3] = __builtin_amdgcn_s_memtime(); } }
     } wg_stamp(st);
 #endif
+    // k_track has finished: no more pushes this step.  Block 0 says so before anything else, in EVERY step (side workers or not: the
+    // stop epoch is what paces the side stream, k_chain claims only when it is exactly one step behind its own)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&st.q[kQStop], epoch);
     if ((int)blockIdx.x < G0) {
         __builtin_amdgcn_s_setprio(3);  // the latency chain goes first whenever it has an instruction ready
         // Side-stream workers (the large contexts): k_track is complete, so the queues' counts are final and their heads only grow --
@@ -1767,8 +1770,6 @@ __global__ __launch_bounds__(256, MMW_POST_OCC) void k_post(DevCfg cfg, DevState
             const int c3 = st.db_count[parity * 4 + 3], c0 = st.q[parity * 8 + kQCount], cb = st.q[kQBig + parity * 8 + kQCount];
             if ((c3 | c0 | cb) == 0) return;  // (uniform: the same words in every thread)
         }
-        // k_track has finished: no more pushes this step.  (Every worker block says so: the first to arrive releases k_chain.)
-        if (threadIdx.x == 0) atomicMax(&st.q[kQStop], epoch);
         {   // list 3 (the clouds k_track did not queue early): a static share per block, as short as a pair count each
             DbLds L;
             db_lds_layout<true>(UMc, CL, true, lds_raw, &L);
@@ -1845,6 +1846,17 @@ __global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, 
             if (have) { __threadfence(); atomicAdd(&(have == 2 ? qb : qs)[kQDone], 1); }
             int s = -1, h = -1, kind = 0;
             for (int spins = 0; spins < kIdleLimit + cfg.n_scenes; spins++) {  // (k_track's first push comes later in a larger context)
+                // Whose pushes are these?  The queues of a parity serve every second step and this launch knows only ITS step's
+                // arguments (output buffers, big_live).  It is paced by the stop epochs alone (no event orders the two streams), and it
+                // idles out after ~3 ms: with steps queued ahead of a stalled context stream (a long upload, a caller's kernel) the
+                // launches of several steps can pass through here before the first k_track runs.  So: claim only while the step
+                // before ours has reached its k_post (the counters of our parity were reset by its k_track, what is pushed now is
+                // ours) and no later step has (ours is over: a launch that comes this late leaves).
+                const int stop = q_load(&st.q[kQStop]);
+#ifndef MMW_MUTANT_CHAIN_NOGATE   // (diagnostic build: tests/test_gpu_runahead.py must FAIL without the two lines below)
+                if (stop - epoch >= 1) break;
+                if (stop - (epoch - 1) < 0) { __builtin_amdgcn_s_sleep(8); continue; }
+#endif
                 const int hb = q_load(&qb[kQHead]), cb = cfg.big_live ? q_load(&qb[kQCount]) : 0;  // (start-up frames: pushed without a release, not ours)
                 if (hb < cb) {
                     if (atomicCAS(&qb[kQHead], hb, hb + 1) == hb) { h = hb; kind = 2; break; }
@@ -1855,7 +1867,7 @@ __global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, 
                     if (atomicCAS(&qs[kQHead], hs, hs + 1) == hs) { h = hs; kind = 1; break; }
                     continue;
                 }
-                if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and both queues are empty: done
+                if (stop - epoch >= 0) break;  // k_post of this step had begun before the queues were looked at, and both are empty: done
                 __builtin_amdgcn_s_sleep(8);
             }
             if (h >= 0) {

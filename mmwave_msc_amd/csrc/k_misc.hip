@@ -389,6 +389,7 @@ __global__ void k_reset(DevCfg cfg, DevState st, const int32_t *__restrict__ fla
 
 void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st)
 {
+    static_assert(MMW_MAX_PTS_LIMIT <= 4 * 256, "k_normalize (and k_track / k_scene) take at most four rows per thread: a larger limit needs a round loop");
     const int r = (cfg.max_pts + 255) / 256;   // rows per thread: 1, 2 or 4 (max_pts <= 1024)
 #define MMW_NORM(RT, R) mmw_launch(k_normalize<RT, R>, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, reinterpret_cast<const RT *>(raw), n_raw, out, n_out)
     if (f32) { if (r <= 1) MMW_NORM(float, 1); else if (r == 2) MMW_NORM(float, 2); else MMW_NORM(float, 4); }

@@ -714,11 +714,10 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
     if (c->ring_frames_bound < c->dc.ring) c->ring_frames_bound++;
     const int u_bound = c->ring_frames_bound * c->dc.max_pts;
     c->dc.big_live = (c->dc.side_worker && c->ring_frames_bound >= c->dc.ring) ? 1 : 0;  // (set again below if the probe turns the workers off)
-    // the chain workers of this step wait on the side stream for what k_track queues (nothing orders them with the
-    // context's stream but the queue itself: they only touch scenes k_track has published)
-    // They must not start long before k_track does -- a caller may have queued other work on the context's stream (the CNN
-    // of the previous frame), beside which eight polling workgroups are a nuisance --: the side stream waits for an event
-    // recorded here, at the head of the step.
+    // the chain workers of this step wait on the side stream for what k_track queues.  Nothing orders them with the context's
+    // stream but the queue protocol itself: they only touch scenes k_track has published, and they claim only while the stop
+    // epoch says that the step in flight is THEIR step (k_chain, k_dbscan.hip) -- a launch that runs early (steps queued ahead of
+    // a stalled context stream) polls and idles out, one that runs late leaves at once.
     if (c->dc.side_worker && !c->side_probed) {
         // first step on this stream set-up: the workers are only used if they really run BESIDE the context's stream
         const int ok = probe_side_streams(c);

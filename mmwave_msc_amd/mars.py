@@ -338,15 +338,22 @@ class MarsCNN(nn.Module):
                 if arith == "f16x3":
                     xc = x.contiguous()
                     h = self._dense1_split(self._hip_convs_split(xc, sflags))
-                    if out is not None and out.is_contiguous() and out.dtype == torch.float32 and out.shape == (xc.shape[0], N_KEYPOINTS):
+                    if out is not None:
+                        if not (out.is_contiguous() and out.dtype == torch.float32 and out.is_cuda and tuple(out.shape) == (xc.shape[0], N_KEYPOINTS)):
+                            raise ValueError(f"MarsCNN.forward(out=...): needs a contiguous fp32 CUDA tensor of shape ({xc.shape[0]}, {N_KEYPOINTS}), "
+                                             f"got {out.dtype} {tuple(out.shape)} contiguous={out.is_contiguous()}")
                         kp = torch.addmm(self.dense2.bias, h, self.dense2.weight.t(), out=out)
                     else:
                         kp = self.dense2(h).contiguous()
                     if fixup and self.has_range_fixup():
                         self._range_fixup(xc, kp, sflags)   # samples outside fp16's range: their rows again, in fp32 (Keras' arithmetic)
                     return kp
+                if out is not None:   # (a caller that passes `out` does not look at the return value: never leave it stale)
+                    raise ValueError("MarsCNN.forward(out=...) is the split-arithmetic path's (arith='f16x3'); this call runs arith=%r" % arith)
                 h = F.relu(self.dense1_dhwc(self._hip_convs(x)))
             return self.dense2(h)
+        if out is not None:
+            raise ValueError("MarsCNN.forward(out=...) is the split-arithmetic GPU path's; this call runs torch's operators")
         if self.three_d:
             h = x.permute(0, 4, 1, 2, 3)
         else:

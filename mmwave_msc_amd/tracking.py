@@ -291,6 +291,11 @@ class TrackBuffer:
         if self._posture is None:
             cap = sb.track_cap
             shape = (cap, sb.ring, 8, 8, 5) if sb.ring > 1 else (cap, 8, 8, 5)
+            # The context moves to a stream of its own that torch knows (so that the feature tensors, the CNN and the scatter are
+            # ordered without host waits) and STAYS there: every later track() / frame_host call runs on it.  Whatever was queued
+            # before -- the model's weights uploaded on another stream a moment ago, work on a stream the caller had bound the
+            # context to -- is waited for once, here.
+            torch.cuda.synchronize(dev)
             st = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st):
                 self._posture = dict(stream=st, feat=torch.zeros(shape, dtype=torch.float32, device=dev),

@@ -39,6 +39,22 @@ def test_e2e_one_rank_of_configs4_vs_oracle():
     assert res["keypoint_max_err"] <= KP_TOL, res
 
 
+def test_e2e_configs4_at_full_size_vs_oracle():
+    """BASELINE.json configs[4] at its stated size, on the one GPU: 4096 scenes x 512 points x TR_MAX_TRACKS 8, cluster -> track ->
+    feature map -> MARS CNN -> keypoints EVERY frame (offline_main.py:57-60) for 6 frames through the pipelined PosturePipeline --
+    the tracker state of ALL 4096 scenes bit-equal to the C oracle's, the keypoints of every live track within 1e-4 of the fp64
+    CNN (oracle/mars_np.py).  The oracle's side runs in child processes, one block of scenes per core (scenes are independent)."""
+    import bench
+    import bench_e2e
+    ref = bench_e2e.oracle_reference(workers=1, par=dict(S=4096, N=512, T=8, F=6, seed0=0, label="configs[4] at 4096 scenes, one GPU"),
+                                     procs=max(2, min(16, bench.effective_cores())))
+    assert len(ref["finals"]) == 4096 and ref["samples_cnn"] > 8192
+    res = bench_e2e.e2e_parity_leg(ref, 0)
+    assert res["tracker_state_bit_equal_vs_oracle"], res
+    assert res["tracks_checked"] >= ref["samples_cnn"] > 8192
+    assert res["keypoint_max_err"] <= KP_TOL, res
+
+
 def _run_loop(sb, pts, cnt, dts, model, pipelined):
     import torch
     from mmwave_msc_amd.posture import PosturePipeline

@@ -1,0 +1,109 @@
+"""Seeded random differential test of `posture.PosturePipeline` -- TrackBuffer.estimate_posture (Tracking.py:705-734) after every
+track(), pipelined one / two frames behind the tracker (tickets, creation-ordinal scatter, the CNN on a second stream) -- against
+the frame-by-frame reference loop on the oracle: oracle/c's tracker and feature map, oracle/mars_np.py's fp64 CNN, keypoints
+assigned to the tracks the reference would assign them to.
+
+The configurations are tests/_fuzz.py's (random constants, ragged clouds, skipped and empty frames, targets that vanish: tracks
+expire while their CNN is still in flight -- lifetimes of 0.2 .. 1.5 s against 12 frames of 50 .. 200 ms), with the ring pinned to
+the two sizes a MARS model exists for: FB_FRAMES_BATCH = 0 -> define_CNN (train.py:33-68, feature tensors (8,8,5)) and
+FB_FRAMES_BATCH = 2 -> define_CNN_3D (train.py:71-106); MODEL_MIN_INPUT is 0 / 30 / 100 as drawn.  Both schedules (one stream,
+two streams).  Tracker state bit-equal, owners equal, keypoints of every live track within 1e-4 (relative above 1) of the oracle."""
+import numpy as np
+import pytest
+
+from tests._fuzz import draw_case, scene_inputs
+from tests._golden import assert_tracks_match
+
+pytestmark = pytest.mark.gpu
+KP_TOL = 1e-4
+SEEDS = [s for s in range(7000, 7040) if s % 8 != 5][:32]     # (seek_inner configurations have no PosturePipeline use)
+
+
+def _case(seed):
+    case = draw_case(seed, max_pts=600, max_scenes=6, frames=12)
+    kw = case["cfg"]
+    ring = 1 if seed % 3 == 0 else 3
+    kw["fb_frames_batch"] = ring - 1
+    # every cluster apply_DBscan finds becomes a track: keep the list below the capacity of every layout (tests/_fuzz.py)
+    kw["db_min_samples"] = int(max(kw["db_min_samples"], -(-ring * case["N"] // (62 - kw["tr_max_tracks"])) + 1))
+    return case
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("seed", SEEDS)
+def test_posture_pipeline_random_configuration_vs_oracle(seed, overlap):
+    import torch
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.batch import SceneBatch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.posture import PosturePipeline
+    from oracle import c_oracle as co
+    from oracle.mars_np import mars_forward_np
+    case = _case(seed)
+    kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
+    ring = kw["fb_frames_batch"] + 1
+    pts, cnt, dts = scene_inputs(case)
+    w = random_keras_weights(seed=seed, frames=ring)
+    # ---- the reference loop on the oracle: track -> features -> CNN -> keypoints, scene by scene, frame by frame ----
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, N) for _ in range(S)]
+    n_cnn = 0
+    failed = False
+    for f in range(F):
+        for s in range(S):
+            c = int(cnt[f, s])
+            if c == 0:
+                continue                                   # offline_main.py:56: neither track() nor estimate_posture()
+            try:
+                scenes[s].track(pts[f, s, : max(c, 0)].astype(np.float64), float(dts[f, s]))
+            except RuntimeError:
+                failed = True                              # LinAlgError / ZeroDivisionError cases: tests/test_gpu_fuzz.py's business
+                break
+            feat, owner = scenes[s].features()
+            if len(owner):
+                n_cnn += len(owner)
+                scenes[s].set_keypoints(mars_forward_np(w, feat.astype(np.float64)).astype(np.float32), owner)
+        if failed:
+            break
+    if failed:
+        pytest.skip("the reference raises in this configuration (covered by tests/test_gpu_fuzz.py)")
+    # ---- the pipeline ----
+    dev = torch.device("cuda", 0)
+    model = MarsCNN.from_keras_weights(w).to(dev)
+    sb = SceneBatch(_lib.default_config(**kw), S, N, device=0)
+    pipe = PosturePipeline(sb, model, S * sb.track_cap, overlap=overlap)
+    if overlap and pipe.B is pipe.A:
+        pipe.close(); sb.close()
+        pytest.skip("no second stream on an independent hardware queue on this box")
+    with torch.cuda.stream(pipe.A):
+        d_pts = torch.from_numpy(pts).to(dev).double()
+        d_cnt = torch.from_numpy(cnt).to(dev)
+        d_dt = torch.from_numpy(dts).to(dev)
+    pipe.A.synchronize()
+    for f in range(F):
+        sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+        pipe.after_step()
+        if f == F // 2 and seed % 2 == 0:
+            pipe.drain()                                   # (drain() in the middle of a run is part of the interface)
+    pipe.close()
+    sb.check()
+    assert not pipe.range_overflowed
+    ntr = sb.num_tracks()
+    trk = sb.tracks(cap=max(int(ntr.max()), 1))
+    worst, n_kp, n_default = 0.0, 0, 0
+    default = np.array(list(cfg.default_posture), dtype=np.float32)
+    for s in range(S):
+        want = scenes[s].tracks()
+        assert ntr[s] == len(want), (seed, s)
+        got = trk[s, : ntr[s]]
+        assert_tracks_match(got, want, ctx=f"seed {seed} s{s}", exact=True)
+        if len(want):
+            wk = want["keypoints"].astype(np.float64)
+            err = np.abs(got["keypoints"].astype(np.float64) - wk) / np.maximum(1.0, np.abs(wk))
+            worst = max(worst, float(err.max()))
+            n_kp += len(want)
+            n_default += int(sum(np.array_equal(r, default) for r in want["keypoints"]))
+    assert worst <= KP_TOL, (seed, worst)
+    assert pipe.rows_total >= n_cnn, (pipe.rows_total, n_cnn)   # (>: a scene whose frame was skipped is estimated again, from the same tensors)
+    sb.close()
+    case["seen"] = dict(tracks=n_kp, cnn=n_cnn, default_posture=n_default, worst=worst)
