@@ -12,9 +12,12 @@ given are used as they are.
 A "step" = one radar frame for every scene of the job (one `mmw_step` per rank).  Inputs for
 all W+K frames are resident in HBM before the timed region.  One JSON line on rank 0.
 
-Workload: BASELINE.json configs[2] -- 4096 scenes x 512 points, TR_MAX_TRACKS = 8 -- with scene
-s holding 1 + (s mod 8) walking targets, so that 7/8 of the scenes keep calling apply_DBscan
-every frame (a scene whose track list is full never clusters again).
+Workload: BASELINE.json configs[2] -- 4096 scenes x 512 points, TR_MAX_TRACKS = 8 -- with every
+scene holding K = T = 8 walking targets, SURVEY.md §8(d)'s population (`--population full`, the
+default since round 5: 7.75 tracks per scene, 16 M gate evaluations per step).  The population of
+rounds 1-4 -- scene s holds 1 + (s mod 8) targets, so that 7/8 of the scenes keep calling
+apply_DBscan every frame, 4.5 tracks per scene -- is the second leg of the line (`mixed_population`;
+`--population mixed` makes it the headline again and K = T the second leg, `full_tracks`).
 Scaling: "strong" (default for N > 1) shards the 4096 scenes of configs[2]/[4] over the ranks;
 "weak" gives every rank `--scenes` scenes.  No data-path collective either way; one RCCL
 all-gather of the track table closes the timed region when N > 1.
@@ -159,14 +162,19 @@ FLOP_PER_TRACK_UPDATE = 5900.0
 FLOP_PER_POINT_STATS = 66.0
 
 
-def workload_label(S_total, N, T, world, scaling, S_rank):
+def population_label(population, T):
+    return (f"EVERY scene holds {T} targets (SURVEY.md §8d: K = T)" if population == "full"
+            else f"targets per scene = 1 + (scene_id mod {T}) (the headline population of rounds 1-4)")
+
+
+def workload_label(S_total, N, T, world, scaling, S_rank, population="full"):
     tag = ""
     if (S_total, N, T) == (4096, 512, 8):
         tag = "; BASELINE.json configs[2]"
     elif (S_total, N, T) == (256, 256, 4):
         tag = "; BASELINE.json configs[1]"
     return (f"{S_total} scenes x {N} pts x TR_MAX_TRACKS={T}, DBSCAN+gating+KF (TrackBuffer.track), "
-            f"targets per scene = 1 + (scene_id mod {T}){tag}")
+            f"{population_label(population, T)}{tag}")
 
 
 def self_launch(args, argv):
@@ -261,7 +269,10 @@ def main():
                     help="mmw_config.chain_side_stream: 0 = the library's choice (on above 512 scenes), 1 = on, -1 = off, "
                          "2 = on without the concurrency probe (counter collection serialises kernels)")
     ap.add_argument("--no-shards", action="store_true", help="skip the shard legs (one rank's share of the 2/4/8-GPU job on this GPU)")
-    ap.add_argument("--no-full", action="store_true", help="skip the K = T population leg (every scene holds TR_MAX_TRACKS targets)")
+    ap.add_argument("--population", choices=("full", "mixed"), default="full",
+                    help="targets per scene of the headline workload: full (default) = every scene holds TR_MAX_TRACKS targets (SURVEY.md "
+                         "§8(d): K = T), mixed = scene s holds 1 + (s mod TR_MAX_TRACKS) (the headline of rounds 1-4); the other one is the second leg")
+    ap.add_argument("--no-full", action="store_true", help="skip the second population's leg")
     ap.add_argument("--rows", choices=("f32", "f64"), default="f64",
                     help="how the resident frames are stored in HBM: f64 (default: 64 B per point, mmw_step -- the reference's float64 arrays, "
                          "what rounds 1-3 timed) or f32 (32 B per point, mmw_step_f32 promotes them to fp64 as they are loaded -- exact, the "
@@ -308,14 +319,15 @@ def main():
     t_gen = time.perf_counter()
     ids = np.arange(lo, hi)
     workers = args.gen_workers if args.gen_workers > 0 else max(1, min(32, cores // max(world, 1)))
-    pts, cnt, dts = generate(ids, F, N, args.tracks, workers=workers)
+    pts, cnt, dts = generate(ids, F, N, args.tracks, workers=workers, population=args.population)
+    other_pop = "mixed" if args.population == "full" else "full"
     t_gen = time.perf_counter() - t_gen
     cpu, finals = {}, None
     if single and not args.no_cpu:
         cpu, finals = cpu_legs(pts, cnt, dts, args.tracks, cores, W, args.py_scenes_per_core, args.py_frames, args.c_scenes)
     full_host, cpu_full, finals_full = None, {}, None
     if single and not args.no_full:
-        full_host = generate(ids, F, N, args.tracks, workers=workers, population="full")
+        full_host = generate(ids, F, N, args.tracks, workers=workers, population=other_pop)
         if not args.no_cpu:
             cpu_full, finals_full = cpu_legs(*full_host, args.tracks, cores, W, args.py_scenes_per_core, args.py_frames, args.c_scenes)
     def cpu_e2e_leg(p_, c_, d_, tracks_, what):
@@ -559,8 +571,9 @@ def main():
         shards["note"] = ("one rank's share of the G-GPU job (scenes 0..S/G-1) stepped on this one GPU; projected_whole_node = G x that "
                           "rank's scene-frames/s (no data-path collective; the once-per-run all-gather of 324 B per track is not in it)")
 
-    # ---- SURVEY.md §8(d)'s population: every scene holds K = T targets (all tracks spawn in the first frames, apply_DBscan is
-    #      never called again: 1.8x the gate / Kalman work of the mixed population, no clustering) ----
+    # ---- the other population (headline K = T: every scene holds T targets, all tracks spawn in the first frames and apply_DBscan
+    #      is hardly called again; mixed: scene s holds 1 + (s mod T), 0.55x the gate / Kalman work, 7/8 of the scenes cluster
+    #      every frame) ----
     full = None
     if full_host is not None:
         fp_, fc_, fd_ = full_host
@@ -572,7 +585,7 @@ def main():
         el_f, k_f = timed_window(ctx, d_fp, d_fc, d_fd, S)
         stf = ctx.stats()
         kt_ms = k_f["k_track"]
-        full = {"workload": f"{S} scenes x {N} pts x TR_MAX_TRACKS={args.tracks}, EVERY scene holds {args.tracks} targets (SURVEY.md §8d: K = T)",
+        full = {"workload": f"{S} scenes x {N} pts x TR_MAX_TRACKS={args.tracks}, " + population_label(other_pop, args.tracks),
                 "value": round(S * K / el_f, 1), "unit": "scene-frames/s", "ms_per_step": round(el_f / K * 1e3, 4), "kernels_avg_ms": k_f,
                 "step_kernels": STEP_NAMES[ctx.step_kind()],
                 "gate_evals_per_step": round(float(stf[6]) / K, 1), "tracks_per_scene": round(float(stf[5]) / max(float(stf[2]), 1.0), 2),
@@ -665,7 +678,10 @@ def main():
                 lib_hash = _lib.load().mmw_version().decode().rsplit("src:", 1)[-1]
                 key = f"{S}x{N}x{args.tracks}"
                 ent = tj.get(key, {}).get(_lib.load().mmw_kernel_name(dom).decode())
-                if tj.get("src_hash") == lib_hash and isinstance(ent, dict):
+                if tj.get("src_hash") == lib_hash and isinstance(ent, dict) and tj.get("population", "mixed") != args.population:
+                    traffic_src = (f"null: profiles/traffic.json was collected on the {tj.get('population', 'mixed')} population, this run is "
+                                   f"--population {args.population}")
+                elif tj.get("src_hash") == lib_hash and isinstance(ent, dict):
                     # FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, bytes per launch
                     traffic = ent.get("hbm_bytes_per_launch_fetch_x2")
                     traffic_src = (f"profiles/traffic.json[{key}]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on "
@@ -691,7 +707,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el / K * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": workload_label(S_total, N, args.tracks, world, scaling, S),
+                "workload": workload_label(S_total, N, args.tracks, world, scaling, S, args.population),
+                "population": args.population,
                 "scenes_total": S_total, "scenes_per_gpu": S, "points_per_frame": N, "max_tracks": args.tracks, "frames_resident": F,
                 "rows": ("fp32 in HBM (32 B per point), promoted to fp64 in registers by mmw_step_f32: exact, outputs bit-equal to the fp64 entry's"
                          if rows32 else "fp64 in HBM (64 B per point), mmw_step"),
@@ -741,7 +758,7 @@ def main():
         if shards is not None:
             line["shards"] = shards
         if full is not None:
-            line["full_tracks"] = full
+            line["full_tracks" if other_pop == "full" else "mixed_population"] = full
         if cold is not None:
             line["cold_start"] = cold
         if ingest is not None:

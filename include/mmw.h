@@ -215,6 +215,12 @@ int mmw_set_chain_side_stream(mmw_ctx *ctx, int32_t on);
 #define MMW_STREAM_LEGACY ((void *)1)
 int mmw_set_stream(mmw_ctx *ctx, void *hip_stream);
 int mmw_synchronize(mmw_ctx *ctx);                                   /* sync */
+/* Hand-over WITHOUT a host wait: whatever is queued on `hip_stream` after this call starts only when everything queued on the
+ * context's stream so far has finished (an event recorded on the context's stream, hipStreamWaitEvent on the other).  For a
+ * consumer on another stream of what the context wrote into device memory -- the RCCL all-gather of the track table on the
+ * communicator's stream, a torch kernel reading mmw_features' rows.  hip_stream: a raw hipStream_t; NULL =
+ * the legacy default stream (what torch reports as current_stream().cuda_stream == 0), MMW_STREAM_LEGACY the same. */
+int mmw_stream_wait(mmw_ctx *ctx, void *hip_stream);
 int mmw_get_dims(const mmw_ctx *ctx, int32_t *n_scenes, int32_t *max_pts, int32_t *track_cap, int32_t *ring, int32_t *ring_rows);
 
 /* Thin device-memory helpers so a ctypes host needs no HIP binding. */

@@ -36,7 +36,7 @@ EXPORTS = [
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
     "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small", "mmw_mars_range_fixup",
-    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors",
+    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors", "mmw_stream_wait",
 ]
 
 
@@ -202,6 +202,7 @@ def load():
         "mmw_set_stream": (C.c_int, [vp, vp]),
         "mmw_pop_frame": (C.c_int, [vp, vp]),
         "mmw_synchronize": (C.c_int, [vp]),
+        "mmw_stream_wait": (C.c_int, [vp, vp]),
         "mmw_get_dims": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p]),
         "mmw_dev_alloc": (C.c_int, [vp, C.c_size_t, vpp]),
         "mmw_dev_free": (C.c_int, [vp, vp]),

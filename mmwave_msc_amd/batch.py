@@ -111,6 +111,14 @@ class SceneBatch:
         ptr = int(s.cuda_stream)
         self.set_stream(ptr if ptr else 1)
 
+    def stream_wait(self, stream=None):
+        """mmw_stream_wait: work queued on `stream` (a torch stream; default torch's current one on this device) after this call
+        starts only when everything queued on the context's stream so far has finished -- no host wait.  For consumers of device
+        buffers the context wrote (the all-gather of the track table, a torch op on feature rows) that run on another stream."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._chk(self.L.mmw_stream_wait(self.h, int(s.cuda_stream)))
+
     def set_chain_side_stream(self, on: bool):
         """Small-cloud DBSCAN workers beside the association kernel (second stream) on / off, from the next step on."""
         self._chk(self.L.mmw_set_chain_side_stream(self.h, 1 if on else 0))

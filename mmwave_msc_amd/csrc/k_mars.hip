@@ -13,6 +13,7 @@
 // (d,h,w,c), so Dense-1 takes Keras' weight rows as they are.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace mmw {
 
@@ -537,27 +538,38 @@ extern "C" int mmw_diag_conv_stamps(unsigned long long *out /*[8]*/, int reset)
 }
 #endif
 
+// per DEVICE (a process may drive several GPUs, each from its own thread: dist.LocalShardedTracker): the dynamic-LDS attribute
+// (> 64 KB: without it the launch fails on that device) and the CU count behind the grid, taken once on whichever thread gets
+// there first -- as launch_mars_dense1 does (k_dense.hip).  Returns 0, or -1 when the attribute could not be set.
 template <int NZ>
-static void launch_conv16_t(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
-                            int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream)
+static int launch_conv16_t(const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
+                           int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream)
 {
-    static bool prepared = false;
-    if (!prepared) {
-        (void)hipFuncSetAttribute((const void *)k_mars_conv16<NZ>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv16<NZ>::kLds);
-        prepared = true;
-    }
+    struct DevPrep { std::once_flag once; int n_cu = 256; bool ok = false; };
+    static DevPrep g_prep[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    DevPrep &P = g_prep[dev];
+    std::call_once(P.once, [&]() {
+        if (hipFuncSetAttribute((const void *)k_mars_conv16<NZ>, hipFuncAttributeMaxDynamicSharedMemorySize, Conv16<NZ>::kLds) != hipSuccess) return;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) P.n_cu = prop.multiProcessorCount;
+        P.ok = true;
+    });
+    if (!P.ok) return -1;
     int grid = (B + 3) / 4;
-    if (grid > 256) grid = 256;  // one workgroup of four sample-waves per CU, persistent over samples
+    if (grid > P.n_cu) grid = P.n_cu;  // one workgroup of four sample-waves per CU, persistent over samples
     hipLaunchKernelGGL(k_mars_conv16<NZ>, dim3(grid), dim3(256), Conv16<NZ>::kLds, stream, feat, w1, b1, w2, b2,
                        reinterpret_cast<_Float16 *>(out16), ld_out, B, range_flag, sample_flags);
+    return 0;
 }
 
-void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
-                        int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream)
+int launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
+                       int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream)
 {
-    if (B <= 0) return;
-    if (nz == 3) launch_conv16_t<3>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, sample_flags, stream);
-    else launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, sample_flags, stream);
+    if (B <= 0) return 0;
+    if (nz == 3) return launch_conv16_t<3>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, sample_flags, stream);
+    return launch_conv16_t<1>(feat, w1, b1, w2, b2, out16, ld_out, B, range_flag, sample_flags, stream);
 }
 
 // ---- samples that left fp16's range under the split arithmetic, recomputed in Keras' own fp32 -- on the device, no host wait ----

@@ -67,7 +67,7 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
                        hipStream_t stream);
 int launch_mars_head_small(const float *act, long long lda, const float *w1, long long ldw, const float *bias1, const float *w2, const float *bias2,
                            float *hidden, float *kp, int n_rows, int K, int N1, int NOUT, hipStream_t stream, const int32_t *dev_rows = nullptr);
-void launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
+int launch_mars_conv16(int nz, const float *feat, const float *w1, const float *b1, const float *w2, const float *b2, void *out16, long long ld_out,
                         int B, int32_t *range_flag, int32_t *sample_flags, hipStream_t stream);
 }  // namespace mmw
 
@@ -98,6 +98,7 @@ struct mmw_ctx {
     int32_t *d_row_off = nullptr;     // [S+1]
     int32_t *h_rows = nullptr;        // pinned [kTickets]: eligible-track totals of the outstanding mmw_features_async calls
     hipEvent_t feat_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t handoff_ev = nullptr;     // mmw_stream_wait: recorded on the context's stream, waited for by the caller's
     int32_t feat_cap[4] = {0, 0, 0, 0};
     float *d_posture = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -486,6 +487,7 @@ int mmw_destroy(mmw_ctx *c)
     void *pinned[] = {c->h_in, c->h_out, c->h_hdr, c->h_q};
     for (void *p : pinned) if (p) hipHostFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
+    if (c->handoff_ev) hipEventDestroy(c->handoff_ev);
     if (c->h_rows) hipHostFree(c->h_rows);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->side_gate) hipEventDestroy(c->side_gate);
@@ -632,6 +634,18 @@ int mmw_synchronize(mmw_ctx *c)
     if (!c) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MMW_OK;
+}
+
+int mmw_stream_wait(mmw_ctx *c, void *hip_stream)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t other = hip_stream == MMW_STREAM_LEGACY ? hipStreamLegacy : (hipStream_t)hip_stream;   // (NULL is the legacy default stream already)
+    if (other == c->stream) return MMW_OK;   // one stream: ordered as it is
+    if (!c->handoff_ev) HIPCHK(c, hipEventCreateWithFlags(&c->handoff_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->handoff_ev, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(other, c->handoff_ev, 0));
     return MMW_OK;
 }
 
@@ -1161,7 +1175,8 @@ int mmw_mars_conv_split(void *hip_stream, int32_t frames, const float *feat, con
     if ((frames != 3 && frames != 1) || n < 0 || ld_out < 2 * (int64_t)frames * 2048 || (ld_out & 7) != 0 || ((uintptr_t)out16 & 15) != 0 ||
         (n > 0 && (!feat || !w1 || !b1 || !w2 || !b2 || !out16)))
         return fail(nullptr, MMW_E_ARG, "mmw_mars_conv_split: bad argument (frames must be 3 or 1, ld_out >= 2 * frames * 2048 and a multiple of 8)");
-    launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, ld_out, n, range_flag, sample_flags, (hipStream_t)hip_stream);
+    if (launch_mars_conv16(frames, feat, w1, b1, w2, b2, out16, ld_out, n, range_flag, sample_flags, (hipStream_t)hip_stream) != 0)
+        return fail(nullptr, MMW_E_HIP, "mmw_mars_conv_split: hipFuncSetAttribute(max dynamic LDS) failed on this device");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, MMW_E_HIP, "mmw_mars_conv_split launch -> %s", hipGetErrorString(e));
     return MMW_OK;

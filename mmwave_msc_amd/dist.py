@@ -29,24 +29,39 @@ def tensor_to_summaries(t: torch.Tensor, slots: int) -> np.ndarray:
     return np.ascontiguousarray(a).view(SUMMARY_DTYPE).reshape(-1, slots)
 
 
-def all_gather_tables(local: torch.Tensor, counts=None) -> torch.Tensor:
+def exchange_row_counts(rows: int, device="cpu"):
+    """Every rank's row count (one small all-gather + a host read: done ONCE per table shape by ShardedTracker, then cached)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [int(rows)]
+    world = dist.get_world_size()
+    t = torch.tensor([int(rows)], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    return [int(r.item()) for r in every]
+
+
+def all_gather_tables(local: torch.Tensor, counts=None, out=None, pad=None, force_collective: bool = False) -> torch.Tensor:
     """All-gather the per-rank summary tensors ([rows_r, SUMMARY_WORDS] int32) into the global
     table ordered by rank (= by global scene id).  Ranks may own different row counts:
     shorter shards are padded for the collective and trimmed afterwards.
-    `local` must be complete on torch's current stream: when `SceneBatch.track_table_dev` filled it, the context has
-    to run on that stream (`SceneBatch.follow_torch_stream`) or be synchronised first."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    `counts` = every rank's row count when the caller already knows them (no size exchange, no host read in front of the
+    collective); `out` / `pad` = buffers of [world * max(counts), W] / [max(counts), W] to reuse.  `local` must be complete on
+    the stream the collective runs on (torch's current stream): `ShardedTracker.gather_table` hands it over with an event
+    (`SceneBatch.stream_wait`).  force_collective: run the collective even for a world of one (the one-rank RCCL test)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return local
     world = dist.get_world_size()
-    rows = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    all_rows = [torch.zeros_like(rows) for _ in range(world)]
-    dist.all_gather(all_rows, rows)
-    all_rows = [int(r.item()) for r in all_rows]
+    all_rows = list(counts) if counts is not None else exchange_row_counts(local.shape[0], local.device)
+    assert len(all_rows) == world and all_rows[dist.get_rank()] == local.shape[0], (all_rows, local.shape)
     mx = max(all_rows)
     padded = local
     if local.shape[0] < mx:
-        padded = torch.cat([local, torch.zeros((mx - local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)])
-    out = torch.empty((world * mx, local.shape[1]), dtype=local.dtype, device=local.device)
+        if pad is None or pad.shape != (mx, local.shape[1]) or pad.device != local.device:
+            pad = torch.zeros((mx, local.shape[1]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]].copy_(local)
+        padded = pad
+    if out is None or out.shape != (world * mx, local.shape[1]) or out.device != local.device:
+        out = torch.empty((world * mx, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, padded.contiguous())
     if all(r == mx for r in all_rows):
         return out
@@ -92,6 +107,7 @@ class ShardedTracker:
             batch_factory = lambda c, s, n, d: SceneBatch(c, s, n, device=0 if d is None else int(d))   # noqa: E731
         self.sb = batch_factory(cfg, self.S, int(max_pts), device)
         self._table = None
+        self._gather = {}    # per slots: every rank's row count (exchanged once) and the collective's buffers
         self.pipe = None
         if stream is not None:
             self.sb.follow_torch_stream(stream)
@@ -111,18 +127,39 @@ class ShardedTracker:
         if self.pipe is not None:
             self.pipe.drain()
 
-    def gather_table(self, slots: int) -> torch.Tensor:
-        """Every rank's track summaries (`slots` per scene, scene ids global) all-gathered, ordered by global scene id."""
+    def gather_table(self, slots: int, force_collective: bool = False) -> torch.Tensor:
+        """Every rank's track summaries (`slots` per scene, scene ids global) all-gathered, ordered by global scene id.
+        The table is written on the CONTEXT's stream (k_table); the collective runs on torch's current stream: the hand-over is an
+        event (`mmw_stream_wait`), whatever stream either side is on -- no host wait, no reliance on the caller having bound the
+        context to torch's stream.  Row counts are exchanged once per table shape and cached, the collective's buffers reused."""
+        slots = int(slots)
         if hasattr(self.sb, "track_table_dev") and getattr(self.sb, "h", None) is not None:
             dev = torch.device("cuda", self.sb.device)
-            if self._table is None or self._table.shape[0] != self.S * int(slots):
-                self._table = torch.zeros((self.S * int(slots), SUMMARY_WORDS), dtype=torch.int32, device=dev)
-            self.sb.track_table_dev(self._table.data_ptr(), int(slots), scene_base=self.lo)
+            if self._table is None or self._table.shape[0] != self.S * slots:
+                self._table = torch.zeros((self.S * slots, SUMMARY_WORDS), dtype=torch.int32, device=dev)
+                self._gather = {}
+            self.sb.track_table_dev(self._table.data_ptr(), slots, scene_base=self.lo)
             if self.world > 1 and dist.get_backend() != "nccl":   # (gloo: host tensors; the table must have been written first)
                 self.sb.synchronize()
-                return all_gather_tables(self._table.cpu())
-            return all_gather_tables(self._table)
-        return all_gather_tables(summaries_to_tensor(self.sb.track_table_host(int(slots), scene_base=self.lo)))
+                local = self._table.cpu()
+            else:
+                self.sb.stream_wait(torch.cuda.current_stream(dev))
+                local = self._table
+        else:
+            local = summaries_to_tensor(self.sb.track_table_host(slots, scene_base=self.lo))
+        if self.world == 1 and not force_collective:
+            return local
+        g = self._gather.get(slots) if isinstance(getattr(self, "_gather", None), dict) else None
+        if g is None or g["device"] != local.device:
+            counts = exchange_row_counts(local.shape[0], local.device)
+            mx = max(counts)
+            g = dict(counts=counts, device=local.device,
+                     out=torch.empty((len(counts) * mx, local.shape[1]), dtype=local.dtype, device=local.device),
+                     pad=torch.zeros((mx, local.shape[1]), dtype=local.dtype, device=local.device) if local.shape[0] < mx else None)
+            if not isinstance(getattr(self, "_gather", None), dict):
+                self._gather = {}
+            self._gather[slots] = g
+        return all_gather_tables(local, counts=g["counts"], out=g["out"], pad=g["pad"], force_collective=force_collective)
 
     def close(self):
         if self.pipe is not None:

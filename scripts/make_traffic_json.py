@@ -27,6 +27,7 @@ big, small = sys.argv[1], sys.argv[2]
 res = {"4096x512x8": table(big), "512x512x8": table(small),
        # the build the counters were collected on: bench.py quotes them only for a library built from the same sources
        "src_hash": source_hash(),
+       "population": "full",   # bench.py's default headline population since round 5 (K = T); quoted only for runs of the same one
        "source": f"{big} / {small}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of bench.py --no-cpu --no-e2e --no-e2e-parity "
                  f"--no-cold --no-shards --no-full --no-ingest --no-single --steps 10 --warmup 10 (--chain-side-stream 2 at 4096 scenes, --scenes 512 for the shard)",
        "_note": "KiB -> bytes; read side given raw and x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads: MI355X_MICROARCH.md). "

@@ -414,3 +414,109 @@ def test_local_sharded_tracker_two_contexts_on_two_threads_vs_oracle():
             assert int(tab["alive"][s].sum()) == alive, s
             assert np.array_equal(tab["x"][s, :alive], want["x"][:alive].astype(np.float32)), s
     lt.close()
+
+
+def test_local_sharded_tracker_with_posture_model_two_contexts():
+    """Two contexts in ONE process, each on its own host thread with its own MarsCNN copy and PosturePipeline (the one-process
+    form of SURVEY.md §8e).  The launchers of the CNN kernels keep per-device state (dynamic-LDS attribute, CU count) behind a
+    std::once_flag: two first calls from two threads must not race, and every context ends with the oracle's tracker state and
+    keypoints within 1e-4 of the fp64 CNN.  (On an 8-GPU node `devices` names eight GPUs; here both contexts share the one.)"""
+    import torch
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.dist import LocalShardedTracker
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    from mmwave_msc_amd.posture import PosturePipeline
+    from oracle import c_oracle as co
+    from oracle.mars_np import mars_forward_np
+    import bench
+    S, N, F, T = 96, 256, 8, 4
+    pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=4)
+    w = random_keras_weights(seed=5, frames=3)
+    lt = LocalShardedTracker(lambda: _lib.default_config(tr_max_tracks=T), S, N, devices=[0, 0])
+
+    def run_shard(g, sh):
+        sb, lo, hi = sh["sb"], sh["lo"], sh["hi"]
+        dev = torch.device("cuda", sh["device"])
+        torch.cuda.set_device(dev)
+        model = MarsCNN.from_keras_weights(w).to(dev)
+        pipe = PosturePipeline(sb, model, (hi - lo) * sb.track_cap, overlap=(g == 0))
+        with torch.cuda.stream(pipe.A):
+            d_pts = torch.from_numpy(np.ascontiguousarray(pts[:, lo:hi])).to(dev).double()
+            d_cnt = torch.from_numpy(np.ascontiguousarray(cnt[:, lo:hi])).to(dev)
+            d_dt = torch.from_numpy(np.ascontiguousarray(dts[:, lo:hi])).to(dev)
+        pipe.A.synchronize()
+        for f in range(F):
+            sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+            pipe.after_step()
+        pipe.close()
+        sb.check()
+        ntr = sb.num_tracks()
+        return ntr, sb.tracks(cap=max(int(ntr.max()), 1)), pipe.rows_total
+
+    res = lt.run(run_shard)
+    cfg = co.default_config(tr_max_tracks=T)
+    worst, n_kp = 0.0, 0
+    for sh, (ntr, trk, rows) in zip(lt.shards, res):
+        assert rows > 0
+        for s in range(sh["lo"], sh["hi"]):
+            orc = co.OracleScene(cfg, N)
+            for f in range(F):
+                c = int(cnt[f, s])
+                orc.track(pts[f, s, :c].astype(np.float64), float(dts[f, s]))
+                feat, owner = orc.features()
+                if len(owner):
+                    orc.set_keypoints(mars_forward_np(w, feat.astype(np.float64)).astype(np.float32), owner)
+            want = orc.tracks()
+            k = s - sh["lo"]
+            assert ntr[k] == len(want), s
+            for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "lifetime", "point_num", "is_static", "ring_n"):
+                assert np.array_equal(trk[k, : ntr[k]][name], want[name]), (s, name)
+            if len(want):
+                wk = want["keypoints"].astype(np.float64)
+                worst = max(worst, float((np.abs(trk[k, : ntr[k]]["keypoints"].astype(np.float64) - wk) / np.maximum(1.0, np.abs(wk))).max()))
+                n_kp += len(want)
+    assert n_kp > S and worst <= KP_TOL, (n_kp, worst)
+    lt.close()
+
+
+def _rccl_one_rank(port, q):
+    """child process: a one-rank process group on RCCL (backend "nccl"), a real mmw_track_table all-gathered through it"""
+    import os
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch
+    import torch.distributed as dist
+    from mmwave_msc_amd import _lib
+    from mmwave_msc_amd.dist import ShardedTracker, tensor_to_summaries
+    from mmwave_msc_amd.synth import make_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    S, N, F, slots = 24, 256, 6, 4
+    pts, cnt, dts = make_batch(range(300, 300 + S), F, N, 3)
+    st = ShardedTracker(_lib.default_config(), S, N, device=0)     # the context keeps ITS OWN stream: the gather hands over by event
+    for f in range(F):
+        st.sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+    out = []
+    for _ in range(3):                                             # (the second and third call reuse counts and buffers)
+        g = st.gather_table(slots, force_collective=True)
+        torch.cuda.synchronize()
+        out.append(tensor_to_summaries(g, slots).copy())
+    want = st.sb.track_table_host(slots, scene_base=0)
+    ok = all(all(np.array_equal(o[n], want[n]) for n in want.dtype.names) for o in out)
+    q.put((bool(ok), dist.get_backend(), int(want["alive"].sum()), tuple(out[0].shape)))
+    st.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_all_gather_of_a_real_track_table():
+    """SURVEY.md §8(e)'s one collective on the real backend: backend "nccl" (= RCCL) with a world of one -- all the box offers --,
+    `ShardedTracker.gather_table(force_collective=True)`: the table k_table writes on the context's own stream, handed to the
+    communicator's stream by an event (`mmw_stream_wait`), through `dist.all_gather_into_tensor`, equal to the host read-back."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank, args=(_free_port(), q))
+    p.start()
+    ok, backend, alive, shape = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert ok and backend == "nccl" and alive >= 24 and shape == (24, 4)
