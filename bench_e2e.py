@@ -126,7 +126,7 @@ def oracle_reference(workers=1, par=None, procs=1):
     tensor each surviving track was tagged with last: identical to running it every frame, at a fraction of the cost.
     procs > 1: the scenes are cut into blocks that run in child processes started from scratch (scenes are independent; safe
     in a process that has already initialised the GPU) -- configs[4] at its full 4096 scenes in ~20 s on the GPU box's 16 cores."""
-    from mmwave_msc_amd.mars import random_keras_weights
+    from mmwave_msc_amd.marsweights import random_keras_weights
 
     p = dict(par or E2E_PAR)
     t0 = time.perf_counter()
@@ -148,8 +148,10 @@ def oracle_reference(workers=1, par=None, procs=1):
             jobs = []
             for i in range(procs):
                 out = os.path.join(tmp, f"block{i}.pkl")
+                # (one BLAS / OpenMP thread per child: the children ARE the parallelism)
+                env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
                 jobs.append((out, subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-block",
-                                                    json.dumps([p, edges[i], edges[i + 1], 1]), out])))
+                                                    json.dumps([p, edges[i], edges[i + 1], 1]), out], env=env)))
             blocks = []
             for out, job in jobs:
                 if job.wait() != 0:
@@ -165,7 +167,7 @@ def oracle_reference(workers=1, par=None, procs=1):
 
 def _oracle_block(args):
     """scenes [s0, s1) of oracle_reference's job (module level: a spawned worker imports it)"""
-    from mmwave_msc_amd.mars import random_keras_weights
+    from mmwave_msc_amd.marsweights import random_keras_weights   # (no torch in a worker)
     from oracle import c_oracle as co
     from oracle.mars_np import mars_forward_np
     import bench

@@ -438,6 +438,22 @@ typedef struct mmw_uart_cfg {
 int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, double *raw /*[max_obj][5]*/, double *range_out /*[max_obj]*/,
                    int32_t max_obj, int32_t *n_obj, uint32_t *frame_number, size_t *packet_start, size_t *packet_len);
 
+/* The batched, device-side form of that input step: the host only FINDS the packet, the GPU decodes it.
+ * mmw_find_tlv (host, no GPU work) = the packet part of mmw_parse_uart -- last magic word, whole packet present, objects
+ * announced, first TLV = detected points, its objects inside the buffer -- without decoding an object: *body_offset = offset
+ * from buf of the TLV BODY (u16 numObj, u16 xyzQFormat, numObj x six int16: rangeIdx, dopplerIdx, peakVal, x, y, z; 12 bytes per
+ * object, ReadDataIWR1443.py:107-150), -1 if there is none; *n_obj = the count the body announces (the caller checks it
+ * against max_pts); returns 1 / 0 / MMW_E_ARG and the packet position as mmw_parse_uart does.
+ * mmw_normalize_tlv = ReadIWR14xx.read's decode (ReadDataIWR1443.py:153-171) + Utils.normalize_data (Utils.py:342-434) for
+ * every scene in ONE kernel, fused ahead of mmw_step: packets (dev) = the bytes as they arrived, all scenes' packets in one
+ * buffer; tlv_offset[S] (dev) = byte offset into `packets` of each scene's TLV body (2-byte aligned), < 0 = no detected-points
+ * TLV this frame (n_out = 0: mmw_step skips the scene's frame, offline_main.py:56); cfg (host) as for mmw_parse_uart;
+ * pts[S][max_pts][8] / n_out[S] (dev) as mmw_normalize writes them -- bit-equal to mmw_parse_uart + mmw_normalize on the same
+ * bytes.  12 bytes per object cross PCIe instead of 20 (fp32 raw rows) or 40 (fp64).  Objects beyond max_pts are not read. */
+int mmw_find_tlv(const uint8_t *buf, size_t len, int64_t *body_offset, int32_t *n_obj, uint32_t *frame_number, size_t *packet_start,
+                 size_t *packet_len);
+int mmw_normalize_tlv(mmw_ctx *ctx, const uint8_t *packets, const int64_t *tlv_offset, const mmw_uart_cfg *cfg, double *pts, int32_t *n_out);
+
 /* Work counters accumulated by the kernels since the last reset (sync):
  * [0] k_track algorithmic bytes  [1] k_dbscan algorithmic bytes  [2] scene-frames stepped
  * [3] apply_DBscan calls  [4] sum of U over those calls  [5] sum of tracks entering track()

@@ -36,7 +36,7 @@ EXPORTS = [
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
     "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small", "mmw_mars_range_fixup",
-    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors", "mmw_stream_wait",
+    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors", "mmw_stream_wait", "mmw_find_tlv", "mmw_normalize_tlv",
 ]
 
 
@@ -45,6 +45,12 @@ class MmwPostureModel(C.Structure):
     _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
                 ("dense1_w", C.c_void_p), ("dense1_ld", C.c_int64), ("dense1_b", C.c_void_p), ("dense2_w", C.c_void_p),
                 ("dense2_b", C.c_void_p)]
+
+
+class MmwUartCfg(C.Structure):
+    """struct mmw_uart_cfg (include/mmw.h): the scales ReadIWR14xx.__parseConfigFile derives from the radar .cfg."""
+    _fields_ = [("range_idx_to_meters", C.c_double), ("doppler_resolution_mps", C.c_double),
+                ("num_doppler_bins", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MmwConfig(C.Structure):
@@ -255,6 +261,8 @@ def load():
         "mmw_mars_dense1_split": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, i32, i32, i32]),
         "mmw_mars_head_small": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, i32, i32, i32]),
         "mmw_parse_uart": (C.c_int, [vp, C.c_size_t, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "mmw_find_tlv": (C.c_int, [vp, C.c_size_t, vp, vp, vp, vp, vp]),
+        "mmw_normalize_tlv": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "mmw_format_frames": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)

@@ -217,6 +217,13 @@ class SceneBatch:
         fn = self.L.mmw_normalize_f32 if f32 else self.L.mmw_normalize
         self._chk(fn(self.h, raw_ptr, n_raw_ptr, pts_ptr, n_out_ptr))
 
+    def normalize_tlv_dev(self, packets_ptr, tlv_offset_ptr, uart_cfg, pts_ptr, n_out_ptr):
+        """mmw_normalize_tlv: the radar's own wire format (detected-points TLV bodies, 12 B per object) decoded as ReadIWR14xx.read
+        does (ReadDataIWR1443.py:153-171) and normalised (Utils.normalize_data) in one kernel: packets (device bytes),
+        tlv_offset[S] (device int64: byte offset of each scene's TLV body, < 0 = none), uart_cfg (`_lib.MmwUartCfg`, host)
+        -> pts[S][max_pts][8] fp64, n_out[S] (device)."""
+        self._chk(self.L.mmw_normalize_tlv(self.h, packets_ptr, tlv_offset_ptr, C.byref(uart_cfg), pts_ptr, n_out_ptr))
+
     def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray, raise_nonfinite: bool = True):
         """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S]).  raise_nonfinite=False: a scene
         whose apply_DBscan call raised sklearn's ValueError (a NaN / infinite row in its ring) does not raise here -- its db_n is

@@ -20,29 +20,20 @@ namespace mmw {
 // algorithmic bytes, three quarters of them WRITES (64 B per kept row against 20 B read): about half the 6.3 TB/s a plain copy
 // reaches on this chip.  Staging both sides through LDS in whole lines (54.7 us) and one round instead of two per scene (55.5 us)
 // changed nothing: neither coalescing nor the chain's length is what bounds it.
-template <typename RT, int R>
-__global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const RT *__restrict__ raw, const int32_t *__restrict__ n_raw,
-                                                   double *__restrict__ out, int32_t *__restrict__ n_out)
+// The body both entries share: R raw rows (x, y, z, doppler, peakVal as doubles) of this thread -> the reference's arithmetic ->
+// ordered compaction -> whole-row stores.  All 256 threads of the workgroup call (one barrier).
+template <int R>
+__device__ __forceinline__ void normalize_rows(const DevCfg &cfg, int s, int n, const double (&v)[R][5], double *__restrict__ out,
+                                               int32_t *__restrict__ n_out, int *wcnt /* LDS [R * 4] */)
 {
-    __shared__ int wcnt[R * 4];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NP = cfg.max_pts;
-    const int n = min(max(n_raw[s], 0), NP);
-    const RT *in = raw + (size_t)s * NP * 5;
-    double *dst = out + (size_t)s * NP * 8;
-    RT v[R][5];
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-        const int i = q * 256 + tid;
-#pragma unroll
-        for (int c = 0; c < 5; c++) v[q][c] = i < n ? in[i * 5 + c] : (RT)0;
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double *dst = out + (size_t)s * cfg.max_pts * 8;
     double o[R][8];
     unsigned long long bal[R];
 #pragma unroll
     for (int q = 0; q < R; q++) {
         const int i = q * 256 + tid;
-        const double x = (double)v[q][0], y = (double)v[q][1], z = (double)v[q][2], dop = (double)v[q][3], pk = (double)v[q][4];
+        const double x = v[q][0], y = v[q][1], z = v[q][2], dop = v[q][3], pk = v[q][4];
         const double r = sqrt((x * x + y * y) + z * z);
         double vx, vy, vz;
         if (r == 0) { vx = 0; vy = dop; vz = 0; }           // Utils.py:387-390
@@ -82,6 +73,70 @@ __global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const RT *__restr
         }
     }
     if (tid == 0) n_out[s] = total;
+}
+
+template <typename RT, int R>
+__global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const RT *__restrict__ raw, const int32_t *__restrict__ n_raw,
+                                                   double *__restrict__ out, int32_t *__restrict__ n_out)
+{
+    __shared__ int wcnt[R * 4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int NP = cfg.max_pts;
+    const int n = min(max(n_raw[s], 0), NP);
+    const RT *in = raw + (size_t)s * NP * 5;
+    double v[R][5];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const int i = q * 256 + tid;
+#pragma unroll
+        for (int c = 0; c < 5; c++) v[q][c] = i < n ? (double)in[i * 5 + c] : 0.0;
+    }
+    normalize_rows<R>(cfg, s, n, v, out, n_out, wcnt);
+}
+
+// The radar's own wire format in, ring rows out: per scene the body of the detected-points TLV of an IWR1443 UART packet
+// (MMWDEMO_UART_MSG_DETECTED_POINTS: u16 numObj, u16 xyzQFormat, then numObj x six little-endian int16 -- rangeIdx, dopplerIdx,
+// peakVal, x, y, z; 12 bytes per object, ReadDataIWR1443.py:107-150), decoded as ReadIWR14xx.read decodes it (153-171: doppler
+// indices above numDopplerBins / 2 - 1 get 65535 subtracted in int16, doppler = idx * dopplerResolutionMps, x, y, z / 2^Q) and
+// normalised in the same registers.  packets: the bytes as they arrived (any 2-byte alignment of a body); tlv_offset[s] = byte
+// offset of scene s's TLV BODY, < 0 = no detected-points TLV this frame (n_out = 0: the scene's frame is skipped).  The host only
+// finds magic words (mmw_find_tlv).  numObj beyond max_pts is clamped (mmw_find_tlv reports the count: the caller checks).
+template <int R>
+__global__ __launch_bounds__(256) void k_normalize_tlv(DevCfg cfg, const uint8_t *__restrict__ packets, const long long *__restrict__ tlv_offset,
+                                                       double half_bins, double doppler_res, double *__restrict__ out,
+                                                       int32_t *__restrict__ n_out)
+{
+    __shared__ int wcnt[R * 4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const long long off = tlv_offset[s];
+    int n = 0;
+    double q = 1.0;
+    const unsigned short *body = nullptr;
+    if (off >= 0) {   // uniform
+        body = reinterpret_cast<const unsigned short *>(packets + off);
+        const int num = body[0], qfmt = body[1];
+        n = min(num, cfg.max_pts);
+        q = ldexp(1.0, qfmt);
+    }
+    double v[R][5];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = r * 256 + tid;
+        unsigned short w[6] = {0, 0, 0, 0, 0, 0};
+        if (i < n) {
+            const unsigned short *o = body + 2 + (size_t)i * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) w[c] = o[c];
+        }
+        short dop = (short)w[1];
+        if ((double)dop > half_bins) dop = (short)((int)dop - 65535);   // ReadDataIWR1443.py:150-157 (wraps in int16)
+        v[r][0] = (double)(short)w[3] / q;
+        v[r][1] = (double)(short)w[4] / q;
+        v[r][2] = (double)(short)w[5] / q;
+        v[r][3] = (double)dop * doppler_res;
+        v[r][4] = (double)(short)w[2];
+    }
+    normalize_rows<R>(cfg, s, n, v, out, n_out, wcnt);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,6 +450,14 @@ void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_
     if (f32) { if (r <= 1) MMW_NORM(float, 1); else if (r == 2) MMW_NORM(float, 2); else MMW_NORM(float, 4); }
     else { if (r <= 1) MMW_NORM(double, 1); else if (r == 2) MMW_NORM(double, 2); else MMW_NORM(double, 4); }
 #undef MMW_NORM
+}
+void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, const long long *tlv_offset, double half_bins, double doppler_res, double *out,
+                          int32_t *n_out, hipStream_t st)
+{
+    const int r = (cfg.max_pts + 255) / 256;
+#define MMW_NORM_TLV(R) mmw_launch(k_normalize_tlv<R>, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, packets, tlv_offset, half_bins, doppler_res, out, n_out)
+    if (r <= 1) MMW_NORM_TLV(1); else if (r == 2) MMW_NORM_TLV(2); else MMW_NORM_TLV(4);
+#undef MMW_NORM_TLV
 }
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st)
 {

@@ -43,6 +43,8 @@ void launch_dbscan_huge(const DevCfg &cfg, const DevState &st, int UM, int u_bou
 void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
 void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
+void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, const long long *tlv_offset, double half_bins, double doppler_res, double *out,
+                          int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
                      hipStream_t st, const int32_t *n_in = nullptr, int32_t *total_out = nullptr);
@@ -706,6 +708,21 @@ static int normalize_impl(mmw_ctx *c, const void *raw, bool f32, const int32_t *
 int mmw_normalize(mmw_ctx *c, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out) { return normalize_impl(c, raw, false, n_raw, pts, n_out); }
 int mmw_normalize_f32(mmw_ctx *c, const float *raw, const int32_t *n_raw, double *pts, int32_t *n_out) { return normalize_impl(c, raw, true, n_raw, pts, n_out); }
 
+int mmw_normalize_tlv(mmw_ctx *c, const uint8_t *packets, const int64_t *tlv_offset, const mmw_uart_cfg *cfg, double *pts, int32_t *n_out)
+{
+    if (!c || !packets || !tlv_offset || !cfg || !pts || !n_out) return fail(c, MMW_E_ARG, "mmw_normalize_tlv: null pointer");
+    if (((uintptr_t)pts & 15) != 0 || ((uintptr_t)packets & 1) != 0) return fail(c, MMW_E_ARG, "mmw_normalize_tlv: pts must be 16-byte aligned, packets 2-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    EventPair ep;
+    prof_arm(c, MMW_K_NORMALIZE, ep);
+    static_assert(sizeof(long long) == sizeof(int64_t), "tlv offsets");
+    launch_normalize_tlv(c->dc, packets, reinterpret_cast<const long long *>(tlv_offset), cfg->num_doppler_bins / 2.0 - 1, cfg->doppler_resolution_mps, pts,
+                         n_out, c->stream);
+    prof_armed_done(c, ep);
+    HIPCHK(c, hipGetLastError());
+    return MMW_OK;
+}
+
 static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n);
 int mmw_step(mmw_ctx *c, const double *pts, const int32_t *n_pts, const double *dt, int32_t *assoc, int32_t *db_labels, int32_t *db_n)
 {
@@ -1248,14 +1265,13 @@ static int read_stats(mmw_ctx *c, uint64_t *out, int words)
     return MMW_OK;
 }
 
-int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, double *raw, double *range_out, int32_t max_obj,
-                   int32_t *n_obj, uint32_t *frame_number, size_t *packet_start, size_t *packet_len)
+// The packet part of ReadIWR14xx.read (ReadDataIWR1443.py:47-113), shared by mmw_parse_uart and mmw_find_tlv: the LAST magic word
+// that starts in buf[0 .. len-8), the whole packet present, objects announced, the first TLV = detected points and its objects
+// inside the buffer.  Returns 1 with *body = offset of the TLV body (u16 numObj, u16 Q, objects) from buf, 0 otherwise.
+static int find_tlv_body(const uint8_t *buf, size_t len, size_t *body, uint32_t *num_obj, uint32_t *qfmt, uint32_t *frame_number, size_t *packet_start,
+                         size_t *packet_len)
 {
-    if (!buf || !cfg || !raw || !n_obj || max_obj < 0) return MMW_E_ARG;
     static const uint8_t magic[8] = {2, 1, 4, 3, 6, 5, 8, 7};
-    auto u32 = [&](size_t o) { return (uint32_t)buf[o] | ((uint32_t)buf[o + 1] << 8) | ((uint32_t)buf[o + 2] << 16) | ((uint32_t)buf[o + 3] << 24); };
-    auto u16 = [&](size_t o) { return (uint32_t)buf[o] | ((uint32_t)buf[o + 1] << 8); };
-    *n_obj = 0;
     if (frame_number) *frame_number = 0;
     if (packet_start) *packet_start = 0;
     if (packet_len) *packet_len = 0;
@@ -1267,8 +1283,9 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
     if (packet_start) *packet_start = start;
     const size_t rem = len - start;
     if (rem <= 16) return 0;
-    const uint8_t *base = buf + start;
-    buf = base;  // offsets below are relative to the packet
+    const uint8_t *p = buf + start;  // offsets below are relative to the packet
+    auto u32 = [&](size_t o) { return (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8) | ((uint32_t)p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); };
+    auto u16 = [&](size_t o) { return (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8); };
     const size_t total = u32(12);
     if (rem < total || total < 36) return 0;
     if (packet_len) *packet_len = total;
@@ -1279,10 +1296,25 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
     const uint32_t tlv_type = u32(idx);
     idx += 8;  // type, length
     if (tlv_type != 1) return 0;
-    const uint32_t num = u16(idx), qfmt = u16(idx + 2);
-    idx += 4;
+    const uint32_t num = u16(idx), q = u16(idx + 2);
+    if (idx + 4 + (size_t)num * 12 > rem) return 0;
+    *body = start + idx;
+    *num_obj = num;
+    *qfmt = q;
+    return 1;
+}
+
+int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, double *raw, double *range_out, int32_t max_obj,
+                   int32_t *n_obj, uint32_t *frame_number, size_t *packet_start, size_t *packet_len)
+{
+    if (!buf || !cfg || !raw || !n_obj || max_obj < 0) return MMW_E_ARG;
+    *n_obj = 0;
+    size_t body = 0;
+    uint32_t num = 0, qfmt = 0;
+    if (!find_tlv_body(buf, len, &body, &num, &qfmt, frame_number, packet_start, packet_len)) return 0;
     if ((int64_t)num > (int64_t)max_obj) return MMW_E_ARG;
-    if (idx + (size_t)num * 12 > rem) return 0;
+    auto u16 = [&](size_t o) { return (uint32_t)buf[o] | ((uint32_t)buf[o + 1] << 8); };
+    size_t idx = body + 4;
     const double q = ldexp(1.0, (int)qfmt);
     const double half = cfg->num_doppler_bins / 2.0 - 1;
     for (uint32_t o = 0; o < num; o++, idx += 12) {
@@ -1297,6 +1329,19 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
         raw[o * 5 + 4] = (double)peak;
         if (range_out) range_out[o] = (double)range_idx * cfg->range_idx_to_meters;
     }
+    *n_obj = (int32_t)num;
+    return 1;
+}
+
+int mmw_find_tlv(const uint8_t *buf, size_t len, int64_t *body_offset, int32_t *n_obj, uint32_t *frame_number, size_t *packet_start, size_t *packet_len)
+{
+    if (!buf || !body_offset || !n_obj) return MMW_E_ARG;
+    *body_offset = -1;
+    *n_obj = 0;
+    size_t body = 0;
+    uint32_t num = 0, qfmt = 0;
+    if (!find_tlv_body(buf, len, &body, &num, &qfmt, frame_number, packet_start, packet_len)) return 0;
+    *body_offset = (int64_t)body;
     *n_obj = (int32_t)num;
     return 1;
 }

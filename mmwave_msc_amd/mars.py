@@ -46,30 +46,7 @@ def deinterleave_split(a2: torch.Tensor):
     return v[:, :, 0, :].reshape(r, -1), v[:, :, 1, :].reshape(r, -1)
 
 
-def random_keras_weights(seed: int = 0, frames: int = 3) -> dict:
-    """Seeded random weights with Keras shapes (Glorot-like scales, non-trivial BN stats)."""
-    rng = np.random.default_rng(seed)
-    three_d = frames > 1
-    k = (3, 3, 3) if three_d else (3, 3)
-    flat = (frames if three_d else 1) * 64 * 32
-    hidden = 512 * (3 if three_d else 1)
-
-    def glorot(shape, fan_in, fan_out):
-        lim = np.sqrt(6.0 / (fan_in + fan_out))
-        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
-
-    rf = int(np.prod(k))
-    w = {
-        "conv1_w": glorot(k + (5, 16), rf * 5, rf * 16), "conv1_b": rng.normal(0, 0.05, 16).astype(np.float32),
-        "conv2_w": glorot(k + (16, 32), rf * 16, rf * 32), "conv2_b": rng.normal(0, 0.05, 32).astype(np.float32),
-        "bn1_gamma": rng.uniform(0.5, 1.5, 32).astype(np.float32), "bn1_beta": rng.normal(0, 0.1, 32).astype(np.float32),
-        "bn1_mean": rng.normal(0.2, 0.1, 32).astype(np.float32), "bn1_var": rng.uniform(0.05, 0.5, 32).astype(np.float32),
-        "dense1_w": glorot((flat, hidden), flat, hidden), "dense1_b": rng.normal(0, 0.05, hidden).astype(np.float32),
-        "bn2_gamma": rng.uniform(0.5, 1.5, hidden).astype(np.float32), "bn2_beta": rng.normal(0, 0.1, hidden).astype(np.float32),
-        "bn2_mean": rng.normal(0.2, 0.1, hidden).astype(np.float32), "bn2_var": rng.uniform(0.05, 0.5, hidden).astype(np.float32),
-        "dense2_w": glorot((hidden, N_KEYPOINTS), hidden, N_KEYPOINTS), "dense2_b": rng.normal(0, 0.05, N_KEYPOINTS).astype(np.float32),
-    }
-    return w
+from .marsweights import random_keras_weights  # noqa: E402,F401  (torch-free module: CPU-side tools import it without torch)
 
 
 class MarsCNN(nn.Module):

@@ -49,9 +49,72 @@ def parse_config_file(path: str) -> dict:
     return p
 
 
-class _UartCfg(C.Structure):
-    _fields_ = [("range_idx_to_meters", C.c_double), ("doppler_resolution_mps", C.c_double),
-                ("num_doppler_bins", C.c_int32), ("reserved", C.c_int32)]
+_UartCfg = _lib.MmwUartCfg
+
+
+def uart_cfg(config_parameters: dict) -> "_lib.MmwUartCfg":
+    """struct mmw_uart_cfg from the reference's configParameters dict (rangeIdxToMeters, dopplerResolutionMps, numDopplerBins)."""
+    return _lib.MmwUartCfg(float(config_parameters["rangeIdxToMeters"]), float(config_parameters["dopplerResolutionMps"]),
+                           int(config_parameters["numDopplerBins"]), 0)
+
+
+def find_tlv(buf) -> tuple:
+    """mmw_find_tlv on a bytes-like object: (found, body_offset, n_obj, frame_number, packet_start, packet_len) -- the packet
+    part of ReadIWR14xx.read (ReadDataIWR1443.py:47-113) without decoding an object: what the host does per packet when the
+    GPU decodes the detected-points TLV itself (SceneBatch.normalize_tlv_dev)."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    off, n = C.c_int64(-1), C.c_int32(0)
+    frame = C.c_uint32(0)
+    start, plen = C.c_size_t(0), C.c_size_t(0)
+    rc = _lib.load().mmw_find_tlv(a.ctypes.data, len(a), C.byref(off), C.byref(n), C.byref(frame), C.byref(start), C.byref(plen))
+    if rc < 0:
+        raise _lib.MmwError(rc, "mmw_find_tlv: bad arguments")
+    return rc == 1, int(off.value), int(n.value), int(frame.value), int(start.value), int(plen.value)
+
+
+def encode_tlv_bodies(raw: np.ndarray, counts: np.ndarray, qfmt: int, doppler_resolution_mps: float, stride: int = 0) -> np.ndarray:
+    """A synthetic sensor: the detected-points TLV BODIES an IWR1443 would have sent for raw rows (x, y, z, doppler, peakVal) --
+    u16 numObj, u16 xyzQFormat, then per object int16 rangeIdx (0), dopplerIdx = round(doppler / resolution), peakVal, and
+    x, y, z = round(coordinate * 2^Q) (ReadDataIWR1443.py:107-150) -- one body per scene at a fixed stride (default: the smallest
+    multiple of 16 that holds max_pts objects).  raw[..., N, 5], counts[...] -> uint8 [..., stride].  Used by the tests and by
+    bench_ingest.py's `tlv` leg; decoding them (mmw_parse_uart / mmw_normalize_tlv) gives the QUANTISED rows, not `raw`."""
+    raw = np.asarray(raw)
+    lead, N = raw.shape[:-2], raw.shape[-2]
+    if stride <= 0:
+        stride = (4 + 12 * N + 15) // 16 * 16
+    assert stride >= 4 + 12 * N and stride % 2 == 0
+    out = np.zeros(lead + (stride,), dtype=np.uint8)
+    words = out.view(np.uint16).reshape(lead + (stride // 2,))
+    cnt = np.clip(np.asarray(counts), 0, N).astype(np.uint16)
+    words[..., 0] = cnt
+    words[..., 1] = qfmt
+    obj = np.zeros(lead + (N, 6), dtype=np.int16)
+    obj[..., 1] = np.clip(np.rint(raw[..., 3].astype(np.float64) / doppler_resolution_mps), -32768, 32767).astype(np.int16)
+    obj[..., 2] = np.clip(np.rint(raw[..., 4].astype(np.float64)), -32768, 32767).astype(np.int16)
+    obj[..., 3:6] = np.clip(np.rint(raw[..., 0:3].astype(np.float64) * float(2 ** qfmt)), -32768, 32767).astype(np.int16)
+    valid = np.arange(N).reshape((1,) * len(lead) + (N,)) < cnt[..., None]
+    obj[~valid] = 0
+    words[..., 2: 2 + 6 * N] = obj.view(np.uint16).reshape(lead + (6 * N,))
+    return out
+
+
+def decode_tlv_bodies_numpy(bodies: np.ndarray, cfg: dict):
+    """The reference's decode (ReadDataIWR1443.py:153-171, numpy-1.26 int16 wrap) of `encode_tlv_bodies`-shaped bodies, in numpy:
+    (raw[..., N, 5] float64, counts[...]).  The checker's restatement -- the product decodes on the device."""
+    lead, stride = bodies.shape[:-1], bodies.shape[-1]
+    words = np.ascontiguousarray(bodies).view(np.uint16).reshape(lead + (stride // 2,))
+    cnt = words[..., 0].astype(np.int32)
+    q = np.ldexp(1.0, words[..., 1].astype(np.int32))
+    N = (stride - 4) // 12
+    obj = words[..., 2: 2 + 6 * N].reshape(lead + (N, 6)).view(np.int16)
+    dop = obj[..., 1].copy()
+    hi = dop > (cfg["numDopplerBins"] / 2 - 1)
+    dop[hi] = (dop[hi].astype(np.int32) - 65535).astype(np.int16)
+    raw = np.zeros(lead + (N, 5))
+    raw[..., 0:3] = obj[..., 3:6] / q[..., None, None]
+    raw[..., 3] = dop * cfg["dopplerResolutionMps"]
+    raw[..., 4] = obj[..., 2]
+    return raw, cnt
 
 
 class UartFrameParser:

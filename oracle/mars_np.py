@@ -37,9 +37,46 @@ def _bn(x, g, be, m, v):
     return g * (x - m) / np.sqrt(v + BN_EPS) + be
 
 
+_W64 = {}   # id(weight dict) -> its float64 copy (9.5 M parameters: converting them per call dominated small batches)
+
+
+def _weights64(w):
+    ent = _W64.get(id(w))
+    if ent is None or ent[0] is not w:
+        if len(_W64) > 8:
+            _W64.clear()
+        ent = (w, {k: np.asarray(v, dtype=np.float64) for k, v in w.items()})
+        _W64[id(w)] = ent
+    return ent[1]
+
+
+def _blas_threads():
+    """The BLAS pool sized to the CPUs this process may really use (a container on a 256-thread host under a 16-CPU quota:
+    256 BLAS threads only throttle each other)."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        import contextlib
+        return contextlib.nullcontext()
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            n = min(n, max(1, int(float(a) / float(b) + 0.5)))
+    except (AttributeError, OSError, ValueError):
+        pass
+    return threadpool_limits(limits=max(1, n))
+
+
 def mars_forward_np(w, x):
     """x: (B,3,8,8,5) or (B,8,8,5) -> (B,57), float64."""
-    w = {k: np.asarray(v, dtype=np.float64) for k, v in w.items()}
+    with _blas_threads():
+        return _forward(_weights64(w), x)
+
+
+def _forward(w, x):
     h = np.asarray(x, dtype=np.float64)
     h = np.maximum(_conv_same(h, w["conv1_w"], w["conv1_b"]), 0.0)
     h = np.maximum(_conv_same(h, w["conv2_w"], w["conv2_b"]), 0.0)

@@ -67,3 +67,140 @@ def test_parse_config_file(tmp_path):
     assert p["numDopplerBins"] == 16.0 and p["numRangeBins"] == 256 and p["framePeriodicity"] == 100.0
     assert abs(p["rangeIdxToMeters"] - (3e8 * 5500 * 1e3) / (2 * 68 * 1e12 * 256)) < 1e-15
     assert abs(p["dopplerResolutionMps"] - 3e8 / (2 * 77 * 1e9 * (7 + 58) * 1e-6 * 16 * 3)) < 1e-15
+
+
+def _tlv_case(rng, S, N, cfgp):
+    """S chunks as a serial port might deliver them: most hold one complete detected-points packet (random object count, Q format,
+    int16 fields incl. negative coordinates and doppler indices on both sides of the reference's wrap threshold), some none."""
+    chunks, kinds = [], []
+    for s in range(S):
+        kind = int(rng.integers(0, 10))
+        n = int(rng.integers(0, N + 1)) if kind != 3 else N
+        o = np.zeros((n, 6), dtype=np.int64)
+        o[:, 0] = rng.integers(0, 256, n)
+        o[:, 1] = rng.integers(-40, 41, n)
+        o[:, 2] = rng.integers(0, 4000, n)
+        o[:, 3] = rng.integers(-1500, 1500, n)
+        o[:, 4] = rng.integers(20, 3600, n)
+        o[:, 5] = rng.integers(-900, 300, n)
+        q = int(rng.choice([7, 8, 9, 9, 9]))
+        lead = b"\x00" * int(2 * rng.integers(0, 4))            # (bodies 2-byte aligned, not always 4)
+        if kind == 0:
+            pkt = _packet(7 + s, o, qfmt=q, num_det=0)            # header announces no objects
+        elif kind == 1:
+            pkt = _packet(7 + s, o, qfmt=q, tlv_type=2)           # another TLV first
+        elif kind == 2:
+            pkt = _packet(7 + s, o, qfmt=q)[:-6] if n else _packet(7 + s, o, qfmt=q)   # the last object is not all there yet
+        else:
+            pkt = _packet(7 + s, o, qfmt=q)
+        chunks.append(lead + pkt + (b"\x00\x00" if kind == 4 else b""))
+        kinds.append(kind)
+    return chunks, kinds
+
+
+@pytest.mark.parametrize("N", [64, 200, 600])
+def test_device_tlv_decode_and_normalize_equals_host_parse_then_normalize(N):
+    """mmw_find_tlv + mmw_normalize_tlv (the GPU decodes the detected-points TLV of every scene's packet and normalises it in one
+    kernel; ReadDataIWR1443.py:107-171, Utils.py:342-434) against mmw_parse_uart + mmw_normalize on the same bytes: the rows that
+    reach track() and their counts bit-equal, scene by scene; scenes without a complete detected-points packet get n = 0.  Then both
+    paths through mmw_step for three frames: identical association and track state."""
+    import ctypes as C
+    from mmwave_msc_amd import _lib, radar
+    from mmwave_msc_amd.batch import SceneBatch
+    rng = np.random.default_rng(40 + N)
+    S = 48
+    cfgp = {"rangeIdxToMeters": 0.0436, "dopplerResolutionMps": 0.1252, "numDopplerBins": 32.0}
+    ucfg = radar.uart_cfg(cfgp)
+    sb_dev = SceneBatch(_lib.default_config(db_min_samples=10), S, N)
+    sb_host = SceneBatch(_lib.default_config(db_min_samples=10), S, N)
+    L = _lib.load()
+    n_rows = 0
+    for frame in range(3):
+        chunks, kinds = _tlv_case(rng, S, N, cfgp)
+        # ---- host path: one mmw_parse_uart per packet, then mmw_normalize ----
+        raw = np.zeros((S, N, 5))
+        n_raw = np.zeros(S, np.int32)
+        rcs = np.zeros(S, np.int32)
+        for s, ch in enumerate(chunks):
+            a = np.frombuffer(ch, dtype=np.uint8)
+            rows = np.zeros((N, 5))
+            n = C.c_int32(0)
+            rc = L.mmw_parse_uart(a.ctypes.data, len(a), C.byref(ucfg), rows.ctypes.data, None, N, C.byref(n), None, None, None)
+            assert rc in (0, 1), (s, rc)
+            raw[s], n_raw[s], rcs[s] = rows, n.value, rc
+        want_pts, want_n = sb_host.normalize_host(raw, n_raw)
+        # ---- device path: the host only finds the bodies ----
+        blob = b"".join(chunks)
+        offs = np.full(S, -1, np.int64)
+        base = 0
+        for s, ch in enumerate(chunks):
+            found, off, n_obj, _, _, _ = radar.find_tlv(ch)
+            assert found == (rcs[s] == 1) and (not found or n_obj == n_raw[s]), (s, kinds[s], found, rcs[s])
+            if found:
+                assert n_obj <= N
+                offs[s] = base + off
+            base += len(ch)
+        b_pk = sb_dev.buf("tlv_bytes", len(blob) + 16).upload(np.frombuffer(blob, dtype=np.uint8))
+        b_of = sb_dev.buf("tlv_off", S * 8).upload(offs)
+        b_out = sb_dev.buf("tlv_pts", S * N * 64)
+        b_no = sb_dev.buf("tlv_n", S * 4)
+        sb_dev.normalize_tlv_dev(b_pk.ptr, b_of.ptr, ucfg, b_out.ptr, b_no.ptr)
+        got_n = b_no.download((S,), np.int32)
+        got_pts = b_out.download((S, N, 8), np.float64)
+        assert np.array_equal(got_n, want_n), (frame, got_n, want_n)
+        for s in range(S):
+            assert np.array_equal(got_pts[s, : got_n[s]], want_pts[s, : want_n[s]]), (frame, s, kinds[s])
+        n_rows += int(got_n.sum())
+        # ---- both through TrackBuffer.track ----
+        dt = np.full(S, 0.1)
+        b_dt = sb_dev.buf("tlv_dt", S * 8).upload(dt)
+        b_as = sb_dev.buf("tlv_assoc", S * N * 4)
+        sb_dev.step_dev(b_out.ptr, b_no.ptr, b_dt.ptr, b_as.ptr)
+        a_host, _, _ = sb_host.step_host(want_pts, want_n, dt)
+        a_dev = b_as.download((S, N), np.int32)
+        for s in range(S):
+            assert np.array_equal(a_dev[s, : got_n[s]], a_host[s, : want_n[s]]), (frame, s)
+    assert n_rows > S * N // 8
+    nt_d, nt_h = sb_dev.num_tracks(), sb_host.num_tracks()
+    assert np.array_equal(nt_d, nt_h)
+    td, th = sb_dev.tracks(cap=max(int(nt_d.max()), 1)), sb_host.tracks(cap=max(int(nt_h.max()), 1))
+    for name in ("x", "P", "centroid", "spread_est", "group_disp_est", "lifetime", "point_num", "ring_n"):
+        assert np.array_equal(td[name], th[name]), name
+    sb_dev.check(); sb_host.check()
+    sb_dev.close(); sb_host.close()
+
+
+def test_device_tlv_decode_of_the_recorded_uart_chunks():
+    """The byte chunks of the reference's recorded read() session (tests/golden/uart.npz): wherever radar.UartFrameParser reports
+    a decoded packet, the GPU's decode + normalize of that packet's TLV body equals mmw_normalize of the parser's rows."""
+    from mmwave_msc_amd import _lib, radar
+    from mmwave_msc_amd.batch import SceneBatch
+    g = np.load(GOLD, allow_pickle=True)
+    cfg = g["cfg"]
+    cfgp = {"rangeIdxToMeters": float(cfg[0]), "dopplerResolutionMps": float(cfg[1]), "numDopplerBins": float(cfg[2])}
+    p = radar.UartFrameParser(cfgp)
+    N = 256
+    sb = SceneBatch(_lib.default_config(), 1, N)
+    ucfg = radar.uart_cfg(cfgp)
+    decoded = 0
+    for i in range(int(g["n_chunks"])):
+        before = bytes(p.byteBuffer[: p.byteBufferLength]) + g[f"chunk{i}"].tobytes()
+        ok, fn, det = p.feed(g[f"chunk{i}"].tobytes())
+        if not ok:
+            continue
+        found, off, n_obj, frame, _, _ = radar.find_tlv(before)
+        assert found and n_obj == det["numObj"] and frame == fn
+        raw = np.zeros((1, N, 5))
+        k = det["numObj"]
+        raw[0, :k] = np.stack([det["x"], det["y"], det["z"], det["doppler"], det["peakVal"].astype(np.float64)], axis=1)
+        want_pts, want_n = sb.normalize_host(raw, np.array([k], np.int32))
+        b_pk = sb.buf("tlv_bytes", len(before) + 16).upload(np.frombuffer(before, dtype=np.uint8))
+        b_of = sb.buf("tlv_off", 8).upload(np.array([off], np.int64))
+        b_out, b_no = sb.buf("tlv_pts", N * 64), sb.buf("tlv_n", 4)
+        sb.normalize_tlv_dev(b_pk.ptr, b_of.ptr, ucfg, b_out.ptr, b_no.ptr)
+        got_n = int(b_no.download((1,), np.int32)[0])
+        assert got_n == int(want_n[0])
+        assert np.array_equal(b_out.download((1, N, 8), np.float64)[0, :got_n], want_pts[0, :got_n])
+        decoded += 1
+    assert decoded >= 1
+    sb.close()
