@@ -170,37 +170,23 @@ def test_device_tlv_decode_and_normalize_equals_host_parse_then_normalize(N):
     sb_dev.close(); sb_host.close()
 
 
-def test_device_tlv_decode_of_the_recorded_uart_chunks():
-    """The byte chunks of the reference's recorded read() session (tests/golden/uart.npz): wherever radar.UartFrameParser reports
-    a decoded packet, the GPU's decode + normalize of that packet's TLV body equals mmw_normalize of the parser's rows."""
-    from mmwave_msc_amd import _lib, radar
-    from mmwave_msc_amd.batch import SceneBatch
+def test_find_tlv_agrees_with_the_recorded_uart_session():
+    """The byte chunks of the reference's recorded read() session (tests/golden/uart.npz).  The recording holds no DECODED packet
+    -- under numpy 2 the reference's decode branch raises, so the generator could only record the other paths (no magic word,
+    incomplete packet, no objects announced, another TLV first) --: on every buffer state of the session mmw_find_tlv reports the
+    frame number the reference read from the header and no detected-points body, as mmw_parse_uart does."""
+    from mmwave_msc_amd import radar
     g = np.load(GOLD, allow_pickle=True)
     cfg = g["cfg"]
     cfgp = {"rangeIdxToMeters": float(cfg[0]), "dopplerResolutionMps": float(cfg[1]), "numDopplerBins": float(cfg[2])}
     p = radar.UartFrameParser(cfgp)
-    N = 256
-    sb = SceneBatch(_lib.default_config(), 1, N)
-    ucfg = radar.uart_cfg(cfgp)
-    decoded = 0
+    complete = 0
     for i in range(int(g["n_chunks"])):
-        before = bytes(p.byteBuffer[: p.byteBufferLength]) + g[f"chunk{i}"].tobytes()
-        ok, fn, det = p.feed(g[f"chunk{i}"].tobytes())
-        if not ok:
-            continue
-        found, off, n_obj, frame, _, _ = radar.find_tlv(before)
-        assert found and n_obj == det["numObj"] and frame == fn
-        raw = np.zeros((1, N, 5))
-        k = det["numObj"]
-        raw[0, :k] = np.stack([det["x"], det["y"], det["z"], det["doppler"], det["peakVal"].astype(np.float64)], axis=1)
-        want_pts, want_n = sb.normalize_host(raw, np.array([k], np.int32))
-        b_pk = sb.buf("tlv_bytes", len(before) + 16).upload(np.frombuffer(before, dtype=np.uint8))
-        b_of = sb.buf("tlv_off", 8).upload(np.array([off], np.int64))
-        b_out, b_no = sb.buf("tlv_pts", N * 64), sb.buf("tlv_n", 4)
-        sb.normalize_tlv_dev(b_pk.ptr, b_of.ptr, ucfg, b_out.ptr, b_no.ptr)
-        got_n = int(b_no.download((1,), np.int32)[0])
-        assert got_n == int(want_n[0])
-        assert np.array_equal(b_out.download((1, N, 8), np.float64)[0, :got_n], want_pts[0, :got_n])
-        decoded += 1
-    assert decoded >= 1
-    sb.close()
+        chunk = g[f"chunk{i}"].tobytes()
+        before = (bytes(p.byteBuffer[: p.byteBufferLength]) + chunk) if p.byteBufferLength + len(chunk) < radar.MAX_BUFFER else bytes(p.byteBuffer[: p.byteBufferLength])
+        ok, fn, det = p.feed(chunk)
+        found, off, n_obj, frame, start, plen = radar.find_tlv(before)
+        assert ok == int(g[f"ok{i}"]) == 0 and not found and off == -1 and n_obj == 0, i
+        assert frame == fn == int(g[f"frame{i}"]), (i, frame, fn)
+        complete += int(plen > 0)
+    assert complete >= 3
