@@ -1,9 +1,11 @@
-# SQ counter passes for the two tracker kernels (diagnosis only)
+# SQ counter passes for the tracker kernels (issue / stall / LDS counters per kernel; diagnosis only):
+#   bash scripts/pmc_sq.sh [sq1 sq2 ...]   (SCENES=512 for the one-workgroup step, POP=mixed for the 1 + s mod 8 population)
+# The program follows `--` directly (no env / bash -c hop); counters in their own runs, with --kernel-trace only.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
   rm -rf gpurun_out/$name
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --gen-workers 1 --scenes 4096 --steps 6 --warmup 6 > $GRAFT_REPO_ROOT/gpurun_out/$name.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-e2e --no-e2e-parity --no-cold --no-shards --no-full --no-ingest --no-single --gen-workers 1 --scenes ${SCENES:-4096} --population ${POP:-full} --steps 10 --warmup 10 --chain-side-stream 2 > $GRAFT_REPO_ROOT/gpurun_out/$name.log 2>&1)
 }
 PASSES=${@:-sq1 sq2 sq3 sq4 sq5}
 want() { [[ " $PASSES " == *" $1 "* ]]; }
@@ -22,5 +24,5 @@ for name in ("sq1","sq2","sq3","sq4","sq5"):
             if not (k.startswith("k_") or "k_" in k): continue
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,d in acc.items():
-        print(name,k,{c: round(sum(v[len(v)//2:])/max(len(v[len(v)//2:]),1)) for c,v in d.items()})
+        print(name,k,{c: round(sum(v[len(v)//2:])/max(len(v[len(v)//2:]),1)) for c,v in d.items()}, "launches", len(next(iter(d.values()))))
 PY
