@@ -602,8 +602,9 @@ __device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevSt
 
 // When the track-wise layout is used: it needs one lane per bin (t_cap <= 63), and it only pays when there are more
 // waves than the chip runs at once -- a small context (256 scenes x 4 tracks) is bound by the latency of one wave, and
-// the lists put two more dependent loads in front of it (k_predict 8.3 -> 9.2 us there).  The threshold is 1024 waves;
-// MMW_DENSE_MIN_UNITS in the environment of mmw_create overrides it (the parity tests run both layouts on small contexts).
+// the lists put two more dependent loads in front of it (k_predict 8.3 -> 9.2 us there).  The threshold is 1024 waves for
+// contexts of more than 512 scenes; mmw_config.kalman_dense_min_units overrides it (the parity tests run both layouts on small
+// contexts: tests/_layouts.py).
 __host__ __device__ inline bool tracks_dense(const DevCfg &cfg, int nq) { return cfg.t_cap <= 63 && cfg.n_scenes * nq > cfg.dense_min_units; }
 // Contexts whose step is launch latency (<= kSmallContextScenes scenes, per-scene layout -- mmw_create picks it for them unless
 // told otherwise): _predict_all runs at the head of k_track (k_track.hip, PRED instantiations) and k_predict is not

@@ -29,6 +29,11 @@ import torch
 from ._lib import NKP
 
 
+class PostureRangeError(RuntimeError):
+    """drain() / close(): the split-fp16 CNN left keypoints meaningless (samples beyond fp16's range that the device-side fp32 repair
+    could not take); every other track's keypoints are valid, `range_overflowed` stays set on the pipeline."""
+
+
 class PosturePipeline:
     def __init__(self, sb, model, cap_rows: int, tracker_stream=None, cnn_stream=None, overlap: bool = True, time_cnn: bool = False):
         self.sb, self.model, self.cap = sb, model, int(cap_rows)
@@ -158,24 +163,26 @@ class PosturePipeline:
         self.f = self.cnn_done = self.scattered = 0
         self.A.synchronize()
         self.B.synchronize()
-        # the asynchronous path cannot recompute a frame that is long scattered: it reports (mars.MarsCNN.range_overflow)
+        # The asynchronous path cannot recompute a frame that is long scattered.  Keypoints that are MEANINGLESS -- samples outside
+        # fp16's range that were not repaired: more than MMW_RANGE_FIXUP_CAP (64) of them in one batch of the 3-frame model, any
+        # at all in the single-frame model (no fp32 kernel) -- are an error, not a warning: Keras' fp32 would have been finite.
         if getattr(self.model, "arith", None) == "f16x3" and hasattr(self.model, "range_overflow") and self.model.range_overflow():
-            import warnings
             self.range_overflowed = True
-            warnings.warn("MarsCNN (split-fp16 arithmetic): inputs or activations left fp16's range during this run and were NOT repaired (the "
-                          "single-frame model has no fp32 kernel; the 3-frame model repairs up to 64 samples per batch on the device): the "
-                          "keypoints of the samples concerned are meaningless -- use MarsCNN(arith='f32' / 'torch') for such data",
-                          RuntimeWarning, stacklevel=2)
+            raise PostureRangeError("MarsCNN (split-fp16 arithmetic): inputs or activations left fp16's range during this run and were NOT repaired "
+                                    "(the 3-frame model repairs up to 64 samples per batch on the device, the single-frame model none): the keypoints "
+                                    "of the samples concerned are meaningless -- use MarsCNN(arith='f32' / 'torch') for such data")
 
     def close(self):
         """drain(), then hand the tracker back as it was found: its side-stream workers on again if this pipeline turned
         them off.  The pipeline must not be used afterwards."""
         if self._closed:
             return
-        self.drain()
-        self._closed = True
-        if self._side_was_on and self.B is not self.A and self.sb.h:
-            self.sb.set_chain_side_stream(True)
+        try:
+            self.drain()
+        finally:   # (also when drain() raises PostureRangeError)
+            self._closed = True
+            if self._side_was_on and self.B is not self.A and self.sb.h:
+                self.sb.set_chain_side_stream(True)
 
     def __del__(self):
         try:

@@ -24,7 +24,7 @@ for f in range(F):
 sb.synchronize()
 out = np.zeros(32, dtype=np.uint64)
 sb._chk(sb.L.mmw_stats_get_ext(sb.h, out.ctypes.data))
-names_t = ["stage points", "gate records -> LDS", "gating", "class split", "centroid/minmax/spread", "dispersion D",
+names_t = ["stage points", "gate (records as SGPR operands)", "gating", "class split", "centroid/minmax/spread", "dispersion D",
            "track-ring rows+barrier", "maintenance", "update", "global ring append", "DBSCAN screens + push"]
 frames = float(out[2])
 tot = float(out[8:19].sum())

@@ -166,7 +166,21 @@ def test_pipeline_repairs_out_of_range_samples_on_the_tracker_stream():
     for i in range(1, min(n, 40)):               # the others: untouched by the repair, the split arithmetic's (within 1e-4 of fp32's)
         s_i, j_i = int(own[i, 0]), int(own[i, 1])
         assert np.abs(trk[s_i, j_i]["keypoints"] - want32[i]).max() <= 1e-4 * max(1.0, float(np.abs(want32[i]).max())), i
-    pipe.close(); sb.close()
+    # ... and MORE out-of-range samples than the device-side repair holds (MMW_RANGE_FIXUP_CAP = 64) in one batch: their keypoints
+    # would be meaningless -- an error at drain(), not a warning; close() still hands the tracker back
+    from mmwave_msc_amd.posture import PostureRangeError
+    sb.reset()
+    for f in range(F):
+        sb.step_dev(d_pts[f].data_ptr(), d_cnt[f].data_ptr(), d_dt[f].data_ptr())
+        pipe.after_step()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(pipe.A):
+        pipe.feat[d][:80, 0, 0, 0, :] = 1.0e5
+    torch.cuda.synchronize()
+    with pytest.raises(PostureRangeError):
+        pipe.close()
+    assert pipe.range_overflowed and pipe._closed
+    sb.close()
 
 
 def test_features_async_tickets_and_uid_scatter():
