@@ -159,11 +159,13 @@ def test_scene_reset_after_a_reference_exception_vs_oracle(seed, layout):
     sb.close()
 
 
-N_NONFINITE = 24
+import os as _os
+N_NONFINITE = int(_os.environ.get("MMW_FUZZ_NF_CASES", "24"))      # (a one-off wider window: MMW_FUZZ_NF_CASES=512, as MMW_FUZZ_CASES)
+NF_SEED0 = int(_os.environ.get("MMW_FUZZ_NF_SEED0", "5000"))
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
-@pytest.mark.parametrize("seed", range(5000, 5000 + N_NONFINITE))
+@pytest.mark.parametrize("seed", range(NF_SEED0, NF_SEED0 + N_NONFINITE))
 def test_random_configuration_with_nonfinite_rows_vs_oracle(seed, layout):
     """The non-finite arm (tests/_fuzz.py: plant_nonfinite): NaN / +inf / -inf in random columns of random rows -- x, y, z, the
     velocities, doppler, peakVal; rows that stay unassigned and rows a track would have taken.  The reference raises ValueError

@@ -16,7 +16,9 @@ from tests._golden import assert_tracks_match
 
 pytestmark = pytest.mark.gpu
 KP_TOL = 1e-4
-SEEDS = [s for s in range(7000, 7040) if s % 8 != 5][:32]     # (seek_inner configurations have no PosturePipeline use)
+import os as _os
+_SEED0, _CASES = int(_os.environ.get("MMW_FUZZ_POSTURE_SEED0", "7000")), int(_os.environ.get("MMW_FUZZ_POSTURE_CASES", "32"))
+SEEDS = [s for s in range(_SEED0, _SEED0 + 2 * _CASES) if s % 8 != 5][:_CASES]     # (seek_inner configurations have no PosturePipeline use)
 
 
 def _case(seed):
