@@ -211,8 +211,9 @@ def test_random_configuration_with_nonfinite_rows_vs_oracle(seed, layout):
         for s in range(S):
             want_bit = raised.get(s, 0) | inner_raised.get(s, 0)
             assert (err[s] & NF) == want_bit or (s in inner_raised and (err[s] & NF)), (seed, f, s, err[s], raised, inner_raised)
-            assert (err[s] & ~NF) == 0, (seed, f, s, err[s])
-            if s not in inner_raised:   # (a scene that went on past the reference's mid-frame exception may raise at its trigger too)
+            if s not in inner_raised:   # (a scene that went on past the reference's MID-frame exception may raise at its trigger too, or
+                #  meet the ZeroDivisionError / LinAlgError the reference never got to: it is reset below)
+                assert (err[s] & ~NF) == 0, (seed, f, s, err[s])
                 assert (dbn[s] == _lib.DB_RAISED) == (s in raised), (seed, f, s, dbn[s])
         if raised or inner_raised:
             with pytest.raises(ValueError):
