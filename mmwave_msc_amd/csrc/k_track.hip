@@ -238,6 +238,13 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     // memory, loaded speculatively and ignored), each row's 8 columns straight into registers: they are
     // gated from registers and only later parked in the LDS tile.
     const int my_slot = tid < cfg.t_cap ? st.order[(size_t)s * cfg.t_cap + tid] : 0;
+    // ... and the three scalars the frame's first decisions hang on (point count, dt, track count), AHEAD of the
+    // points: a count read after them retires after them, and a track count read only once the count has been
+    // looked at is a second full round trip before the first barrier -- every workgroup paid both.
+    const int n_raw = n_pts[s];
+    SceneHdr *hdr = st.hdr + s;
+    const double dt = dt_all[s];
+    int T = hdr->n_tracks;
     double2 pr[PPT][4];
     {
         const void *frame = frame_of(pts_all, s, NP, F32);
@@ -247,9 +254,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             load_point_row<F32>(frame, i, i < NP, pr[q]);
         }
     }
-    const int n_raw = n_pts[s];
     const int n = n_raw < 0 ? 0 : n_raw;  // MMW_EMPTY_FRAME: track() on an empty cloud
-    SceneHdr *hdr = st.hdr + s;
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;  // ... and its queue counters (kQCount, kQHead, kQDone)
@@ -264,10 +269,8 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         }
         return;
     }
-    const double dt = dt_all[s];
     int32_t *order = st.order + (size_t)s * cfg.t_cap;
     TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
-    int T = hdr->n_tracks;
     const int Tin = T;
     int err = 0;
 #ifdef MMW_STAMPS
@@ -388,12 +391,16 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     STAMP(2);  // gating
     PROBE(2);
     // ---- _get_gated_clouds: order-preserving split by class (Tracking.py:605-629) ----
+    int gp_len, gp_skw, gp_s[MMW_RING_MAX], gp_n[MMW_RING_MAX];   // (thread kThreads - 1: the global ring's header words, see below)
     {
         const int NB = (n + 63) / 64;
         unsigned long long mybal[PPT];
         // ring state of track `tid` (thread T: of the global ring), needed after the scans below: requested now so
         // that the global round trip runs under the ballots and scans (T <= t_cap <= 64 < 256 threads)
         int sd_len = 0, sd_rs[MMW_RING_MAX] = {0, 0, 0, 0}, sd_size = cfg.ring;
+        gp_len = 0; gp_skw = 0;
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) { gp_s[k] = 0; gp_n[k] = 0; }
         if (tid < T) {
             const TrackRec *rec = trk + L.slot[tid];
             sd_len = rec->ring_len;
@@ -405,6 +412,15 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             if (INNER && hdr_ring_size(hdr->skipped)) sd_size = hdr_ring_size(hdr->skipped);  // BatchedData.change_buffer_size on the global ring
 #pragma unroll
             for (int k = 0; k < MMW_RING_MAX; k++) sd_rs[k] = hdr->g_slot[k];
+        } else if (tid == kThreads - 1) {
+            // the thread that pushes this frame into the global ring (behind the split): the ring's header words, requested NOW --
+            // as one thread's fresh round trip plus a serial walk over LDS-indexed copies behind the barrier the push held its wave,
+            // and with it the whole workgroup at the statistics' barrier, for ~7 k of a workgroup's 77 k cycles (probe timeline,
+            // profiles/NOTEBOOK.md round 5)
+            gp_len = hdr->g_len;
+            gp_skw = hdr->skipped;
+#pragma unroll
+            for (int k = 0; k < MMW_RING_MAX; k++) { gp_s[k] = hdr->g_slot[k]; gp_n[k] = hdr->g_n[k]; }
         }
 #pragma unroll
         for (int q = 0; q < PPT; q++) {
@@ -498,32 +514,44 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     //      end of the kernel wants the older frames' rows, and their loads can be in flight during the phases
     //      in between.  (The split above was the last reader of the ring state before this frame.) ----
     if (tid == kThreads - 1) {
-        int len = hdr->g_len;
-        int *gs = L.misc + 4, *gn = L.misc + 8;  // small indexed arrays live in LDS, not in scratch
-        for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = hdr->g_slot[k]; gn[k] = hdr->g_n[k]; }
-        const int skw = hdr->skipped;
-        const int gsz = (INNER && hdr_ring_size(skw)) ? hdr_ring_size(skw) : cfg.ring;
-        while (len >= gsz && len > 0) {
-            const int first = gs[0];
-            for (int k = 1; k < len; k++) { gs[k - 1] = gs[k]; gn[k - 1] = gn[k]; }
-            gs[len - 1] = first;
-            len--;
+        // (registers and unrolled selects throughout: no dependent LDS or global read but the one of this frame's count)
+        int len = gp_len;
+        const int gsz = (INNER && hdr_ring_size(gp_skw)) ? hdr_ring_size(gp_skw) : cfg.ring;
+#pragma unroll
+        for (int it = 0; it < MMW_RING_MAX; it++) {   // pop_frame while len >= size (a ring of fixed size pops at most once)
+            if (len >= gsz && len > 0) {
+                const int first = gp_s[0];
+#pragma unroll
+                for (int k = 1; k < MMW_RING_MAX; k++) if (k < len) { gp_s[k - 1] = gp_s[k]; gp_n[k - 1] = gp_n[k]; }
+#pragma unroll
+                for (int k = 0; k < MMW_RING_MAX; k++) if (k == len - 1) gp_s[k] = first;
+                len--;
+            }
         }
-        gn[len] = L.cls_n[0];
-        L.misc[1] = gs[len];
+        const int nun = L.cls_n[0];
+        int phys = gp_s[0];
+#pragma unroll
+        for (int k = 1; k < MMW_RING_MAX; k++) if (k == len) phys = gp_s[k];
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) if (k == len) gp_n[k] = nun;
         len++;
         int U = 0;
-        for (int k = 0; k < len; k++) U += gn[k];
-        for (int k = 0; k < MMW_RING_MAX; k++) { hdr->g_slot[k] = gs[k]; hdr->g_n[k] = k < len ? gn[k] : 0; }
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) { if (k >= len) gp_n[k] = 0; U += gp_n[k]; }
+        int *gs = L.misc + 4, *gn = L.misc + 8;   // (what the later phases read: slots and counts of the live frames, oldest first)
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) { gs[k] = gp_s[k]; gn[k] = gp_n[k]; hdr->g_slot[k] = gp_s[k]; hdr->g_n[k] = gp_n[k]; }
         hdr->g_len = len;
         hdr->db_u = U;
+        L.misc[1] = phys;
         L.misc[3] = len;
         L.misc[13] = U;
         // the ring's non-finite flags (two bits per physical slot, SceneHdr.skipped): this frame's replace those of the slot it
         // was written to; [15] = the new flags | what the live frames hold together << 8, for the trigger below
-        const int nff = nf_flags_with((skw >> kSkipNfShift) & kSkipNfMask, L.misc[1], L.misc[15]);
+        const int nff = nf_flags_with((gp_skw >> kSkipNfShift) & kSkipNfMask, phys, L.misc[15]);
         int live = 0;
-        for (int k = 0; k < len; k++) live |= (nff >> (2 * gs[k])) & 3;
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) if (k < len) live |= (nff >> (2 * gp_s[k])) & 3;
         L.misc[15] = nff | (live << 8);
     }
     PROBE(3);

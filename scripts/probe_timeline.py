@@ -10,7 +10,8 @@ from mmwave_msc_amd import _lib  # noqa: E402
 from mmwave_msc_amd.batch import SceneBatch  # noqa: E402
 
 S, N, T, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 512, 8, 30
-pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=16)
+POP = sys.argv[2] if len(sys.argv) > 2 else "full"
+pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=16, population=POP)
 sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
 bp = sb.alloc(S * N * 64); bn = sb.alloc(S * 4); bd = sb.alloc(S * 8)
 for f in range(F):
