@@ -1651,18 +1651,13 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
 // FIRST -- they are the ones that cluster their whole ring, 100-250 us on a chain worker -- was tried: no measurable gain in either
 // window, and they are the filler k_track's tail wants.)  The key is n_upd, which nothing in this launch writes: n_tracks may be
 // raised by a spawning worker between the two passes, and a scene counted in one bin but scattered into another would break the
-// permutation.  ... and the number of tracks in this frame's update lists, for the next k_predict: its idle waves leave on
-// one word (bin 0 of the counts is otherwise unused; 4096 workgroups adding to it in k_track cost 12 us).
+// permutation.
 // hist: LDS, t_cap + 3 ints.  Loads in batches of eight per thread, all in flight at once.
 __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevState &st, int parity, int *hist)
 {
     const int tid = threadIdx.x, nb = cfg.t_cap + 1, S = cfg.n_scenes;
-    int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
-    int part = 0;
-    for (int t = 1 + tid; t <= cfg.t_cap; t += 256) part += t * cnt[t];
     for (int i = tid; i <= nb + 1; i += 256) hist[i] = 0;
     __syncthreads();
-    if (part) atomicAdd(&hist[nb + 1], part);
     for (int base = 0; base < S; base += 256 * 8) {
         int key[8];
 #pragma unroll
@@ -1680,7 +1675,6 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
     }
     __syncthreads();
     if (tid == 0) {
-        cnt[0] = hist[nb + 1];
         int run = 0;
         for (int b = 0; b < nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
     }
@@ -2114,8 +2108,7 @@ void launch_inner(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, i
 void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, int UM, int u_bound, int parity, int epoch, int32_t *labels,
                  int32_t *db_n, hipStream_t stream)
 {
-    int nq = (cfg.tr_max_tracks + 3) / 4;
-    if (nq < 1) nq = 1;
+    const int nq = kalman_waves_per_scene(cfg.tr_max_tracks);
     const int S = cfg.n_scenes, units = cfg.fused ? 0 : S * nq;  // (fused step: _update_all ran inside k_scene, only the DBSCAN workers are left)
     int G0 = S < 256 ? S : 256;
     const int umc = dbscan_class_um(0, UM), cl = dbscan_class_cl(0, UM, cfg.t_cap, cfg.db_min_samples);

@@ -20,49 +20,6 @@
 
 namespace mmw {
 
-// Which (scene, track) a 16-lane group of wave `unit` takes when the work is laid out over the lists "scenes by track
-// count, most tracks first" (st.upd_list / st.upd_count of `parity`): entry k = 4 * unit + group is track k % t of
-// the (k / t)-th scene of its bin.  Returns false for a group past the end.  Needs t_cap <= 63 (one lane per bin).
-struct DenseBins {
-    int incl, excl, total;
-};
-__device__ __forceinline__ DenseBins dense_bins(const DevCfg &cfg, const DevState &st, int parity, int lane)
-{
-    const int nb = cfg.t_cap, t_of_lane = nb - lane;
-    const int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
-    DenseBins B;
-    B.incl = (lane < nb) ? t_of_lane * cnt[t_of_lane] : 0;
-    const int mine = B.incl;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(B.incl, o); if (lane >= o) B.incl += v; }
-    B.total = __shfl(B.incl, 63);
-    B.excl = B.incl - mine;
-    return B;
-}
-__device__ __forceinline__ bool dense_pick(const DevCfg &cfg, const DevState &st, int parity, const DenseBins &B, int unit, int lane, int g,
-                                           int &my_s, int &my_j)
-{
-    // branch-free up to ONE load per lane (four uniform loads behind four branches were four round trips in a row): every lane
-    // ends up with a valid address -- idle groups entry 0 of the fullest bin, and scene 0 / track 0 as their answer
-    const int nb = cfg.t_cap;
-    int my_t = nb, my_r = 0;
-    bool live = false;
-    my_j = 0;
-#pragma unroll
-    for (int gg = 0; gg < 4; gg++) {
-        const int k = unit * 4 + gg;  // uniform
-        const unsigned long long hit = __ballot(lane < nb && B.incl > k);
-        const bool valid = k < B.total && hit != 0;
-        const int b = valid ? __ffsll((long long)hit) - 1 : 0;  // first bin whose inclusive count exceeds k
-        const int base = __shfl(B.excl, b), t = nb - b;
-        const int rel = valid ? k - base : 0, r = rel / t, j = rel - r * t;
-        if (g == gg) { my_t = t; my_r = r; my_j = j; live = valid; }
-    }
-    const int sc = st.upd_list[((size_t)parity * (cfg.t_cap + 1) + my_t) * cfg.n_scenes + my_r];
-    my_s = live ? sc : 0;
-    return live;
-}
-
 // k_predict, 64-thread workgroups = one wave = four tracks.  The tracks of the context come from three places:
 //   * units [0, n_dense): the scenes tracked in the PREVIOUS frame, by their update lists (tracks 0 .. n_upd-1),
 //     four real tracks per wave whatever the scenes hold;
@@ -86,35 +43,58 @@ __global__ __launch_bounds__(64, MMW_PRED_OCC) void k_predict(DevCfg cfg, DevSta
     double *Wj = lds + g * kPredScratch;
     int err = 0;
     if (tracks_dense(cfg, nq)) {
-        const int prev = parity ^ 1, n_dense = cfg.n_scenes * nq;
-        // (bin 0 of the counts = the total: the dense work takes the first ceil(total / 4) units, every other unit of the launch
-        //  -- the kSpecialUnits behind the dense range always, and the idle rest of the dense range: after a frame in which
-        //  EVERY scene spawned tracks, the first frames after a reset, that is all of them; 64 waves alone took 555 us for the
-        //  4096 scenes of the start-up -- serves the two lists below)
-        // (the dependent round trips of a wave -- total, bin counts, list entry, scene words, slot, record -- are what this launch
-        //  lasts, at 20 waves per CU: the bin counts are requested with the total, the scene's four words together: 6 -> 4)
-        const int total = st.upd_count[(size_t)prev * (cfg.t_cap + 1)];
-        const DenseBins B = dense_bins(cfg, st, prev, lane);
-        int nd = (total + 3) >> 2;
-        nd = nd < n_dense ? nd : n_dense;
-        if ((int)blockIdx.x < nd) {
-            for (int unit = blockIdx.x; unit * 4 < B.total; unit += n_dense) {
-                int s, j;
-                bool live = dense_pick(cfg, st, prev, B, unit, lane, g, s, j);   // (idle groups: s = j = 0)
-                const int n = n_pts[s], nt = st.hdr[s].n_tracks, slot = st.order[(size_t)s * cfg.t_cap + j];
-                const double dt = dt_all[s];
-                // (j < n_tracks: a scene that mmw_reset_scenes has emptied since the lists were built holds no track -- its
-                //  stale records must not be predicted, nor their error bits come back on the fresh scene)
-                live = live && frame_reaches_track(n, cfg.max_pts) && j < nt;
-                if (!__any(live)) continue;
-                TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? slot : 0);
-                int e1 = 0;
-                predict_one_track<DX>(cfg, st, rec, live, s, j, dt, Wj, lane, c, e1);
-                if (e1 && live) atomicOr(&st.hdr[s].err, e1);
+        const int prev = parity ^ 1, n_dense = cfg.n_scenes * nq, unit = blockIdx.x;
+        // (unit w < n_dense serves shard w mod shards of last frame's update lists; every unit without dense work -- the
+        //  kSpecialUnits behind the dense range always, and the idle rest of every shard: after a frame in which EVERY scene
+        //  spawned tracks, the first frames after a reset, that is all of them; 64 waves alone took 555 us for the 4096 scenes
+        //  of the start-up -- serves the two lists below)
+        // (the dependent round trips of a wave are what this launch lasts, at 12 waves per CU: the shard lengths and this group's
+        //  list entry are requested together, then the scene's four words AND the record, whose address the entry holds: two)
+        const int nsh = upd_shards(n_dense);
+        int tot[kUpdShards];
+#pragma unroll
+        for (int i = 0; i < kUpdShards; i++) tot[i] = st.upd_count[prev * kUpdWords + i];
+        if (unit < n_dense) {
+            int e;
+            UpdCursor C = upd_cursor(cfg, st, unit, n_dense, prev, g, e);
+            if (C.k - g < C.tot) {
+                do {
+                    bool live = C.k < C.tot;
+                    const int s = live ? e >> 12 : 0, j = live ? (e >> 6) & 63 : 0;
+                    const int n = n_pts[s], nt = st.hdr[s].n_tracks;
+                    const double dt = dt_all[s];
+                    TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + (live ? (e & 63) : 0);
+                    stage_record<16>(rec, Wj, c);   // (requested with the scene's words, before they are looked at)
+                    wave_sync();
+                    // (j < n_tracks: a scene that mmw_reset_scenes has emptied since the lists were built holds no track -- its
+                    //  stale records must not be predicted, nor their error bits come back on the fresh scene)
+                    live = live && frame_reaches_track(n, cfg.max_pts) && j < nt;
+                    if (__any(live)) {
+                        int e1 = 0;
+                        predict_staged_track<DX>(cfg, st, rec, live, s, j, dt, Wj, lane, c, e1);
+                        if (e1 && live) atomicOr(&st.hdr[s].err, e1);
+                    }
+                    wave_sync();   // (the staging area is the next entry's)
+                    C.k += C.stride4;
+                    if (C.k - g < C.tot) e = C.list[C.k < C.last ? C.k : C.last];
+                } while (C.k - g < C.tot);
+                return;
             }
-            return;
         }
-        const int pool = (int)gridDim.x - nd, me = (int)blockIdx.x - nd;
+        // this unit's place among the launch's idle ones: the units of shard i are w = i, i + shards, ...; the first
+        // ceil(tot[i] / 4) of them are busy
+        int pool = (int)gridDim.x - n_dense, me = unit < n_dense ? 0 : unit - n_dense;
+#pragma unroll
+        for (int i = 0; i < kUpdShards; i++) {
+            if (i < nsh) {
+                const int units_i = (n_dense - i + nsh - 1) / nsh;
+                int busy = (tot[i] + 3) >> 2;
+                busy = busy < units_i ? busy : units_i;
+                const int before = unit < n_dense ? (unit > i ? (unit - i + nsh - 1) / nsh : 0) : units_i;
+                pool += units_i - busy;
+                me += before > busy ? before - busy : 0;
+            }
+        }
         const int count = st.spc_count[prev];
         for (int i = me; i < count; i += pool) {
             const int s = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2], first = st.spc_list[((size_t)prev * cfg.n_scenes + i) * 2 + 1];
@@ -175,11 +155,7 @@ __global__ __launch_bounds__(64, MMW_PRED_OCC) void k_predict(DevCfg cfg, DevSta
     if (err) atomicOr(&st.hdr[s].err, err);
 }
 
-static int waves_per_scene(const DevCfg &cfg)
-{
-    int nq = (cfg.tr_max_tracks + 3) / 4;
-    return nq < 1 ? 1 : nq;
-}
+static int waves_per_scene(const DevCfg &cfg) { return kalman_waves_per_scene(cfg.tr_max_tracks); }
 
 void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, const double *dt, int parity, hipStream_t stream)
 {

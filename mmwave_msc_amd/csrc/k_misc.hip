@@ -435,7 +435,7 @@ __global__ void k_reset(DevCfg cfg, DevState st, const int32_t *__restrict__ fla
         }
     }
     if (flags) return;
-    for (int e = g; e < 2 * (cfg.t_cap + 1); e += gridDim.x * blockDim.x) st.upd_count[e] = 0;
+    for (int e = g; e < 2 * kUpdWords; e += gridDim.x * blockDim.x) st.upd_count[e] = 0;
     if (g < 2) st.spc_count[g] = 0;
     if (g == 0) st.q[kQTimeout] = 0;   // (a bounded wait that gave up is reported by mmw_check until the context is reset)
     const size_t tot = (size_t)cfg.n_scenes * cfg.t_cap;

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT, PPT >= 4 ? NT / 256 : NT / 128) void k_scene(De
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths and queue counters (k_post's workers)
     if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;
     if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = 0;
-    if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
+    if (s == 0 && tid < kUpdWords) st.upd_count[(parity ^ 1) * kUpdWords + tid] = 0;
     if (s == 0 && tid == NT - 1) st.spc_count[parity ^ 1] = 0;
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {

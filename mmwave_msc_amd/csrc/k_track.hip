@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
     if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;  // ... and its queue counters (kQCount, kQHead, kQDone)
     if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = 0;  // ... and those of the large clouds' queue
-    if (s == 0 && tid <= cfg.t_cap) st.upd_count[(parity ^ 1) * (cfg.t_cap + 1) + tid] = 0;
+    if (s == 0 && tid < kUpdWords) st.upd_count[(parity ^ 1) * kUpdWords + tid] = 0;       // ... and the lengths of its update lists
     if (s == 0 && tid == kThreads - 1) st.spc_count[parity ^ 1] = 0;
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
         if (tid == 0) {
@@ -914,6 +914,10 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     STAMP(7);  // maintenance
 
     // (_update_all, Tracking.py:598-603, is batched over all tracks in the next launch: k_post)
+    // (track-wise layout only: this scene's tracks join the update list of its shard, mmw_device.hpp)
+    const int upd_units = cfg.n_scenes * kalman_waves_per_scene(cfg.tr_max_tracks);
+    const bool upd_on = tracks_dense(cfg, kalman_waves_per_scene(cfg.tr_max_tracks));
+    const int upd_sh = (int)blockIdx.x % upd_shards(upd_units);
     int upd_pos = -1;
     STAMP(8);  // update
     // ---- DBSCAN trigger (Tracking.py:693-697) ----
@@ -923,10 +927,10 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         hdr->n_upd = T;
         const int nfw = L.misc[15];
         hdr->skipped = (INNER ? (hdr->skipped & (kSkipRingMask << kSkipRingShift)) : 0) | ((nfw & kSkipNfMask) << kSkipNfShift);
-        // this scene's tracks join the update list of their count (k_post lays _update_all out over tracks): the
-        // slot is requested here and written at the very end of the kernel -- the atomic's round trip (a microsecond
+        // this scene's tracks join the update list of this workgroup's shard (k_post lays _update_all out over tracks): the
+        // place is requested here and written at the very end of the kernel -- the atomic's round trip (a microsecond
         // under 4096 workgroups) must not sit in front of the screen below
-        if (T > 0) upd_pos = atomicAdd(&st.upd_count[parity * (cfg.t_cap + 1) + T], 1);
+        if (T > 0 && upd_on) upd_pos = atomicAdd(&st.upd_count[parity * kUpdWords + upd_sh], T);
         bool need = U > 0 && T < cfg.tr_max_tracks;
         const int nfe = nf_error_of(nfw >> 8);
         if (need && nfe) {
@@ -1025,7 +1029,10 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
         atomicAdd(&sl[5], (unsigned long long)Tin);
         atomicAdd(&sl[6], (unsigned long long)n * (unsigned long long)Tin);
     }
-    if (tid == 0 && upd_pos >= 0) st.upd_list[((size_t)parity * (cfg.t_cap + 1) + T) * cfg.n_scenes + upd_pos] = s;
+    if (tid < 64) {   // (wave 0: its lane 0 holds the place; T <= 63 entries, one store instruction)
+        const int pos = __builtin_amdgcn_readfirstlane(upd_pos);
+        if (pos >= 0 && tid < T) st.upd_list[((size_t)parity * kUpdShards + upd_sh) * upd_region(cfg.n_scenes, cfg.t_cap) + pos + tid] = upd_pack(s, tid, L.slot[tid]);
+    }
     WGTIME(1);
 }
 

@@ -411,8 +411,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     ALLOC(c->d_probe, 4 * sizeof(int32_t));
     ALLOC(c->st.gate_buf, S * cap * kGateRec * sizeof(double));
     ALLOC(c->st.perm, 2 * S * sizeof(int32_t));
-    ALLOC(c->st.upd_count, 2 * (size_t)(cap + 1) * sizeof(int32_t));
-    ALLOC(c->st.upd_list, 2 * (size_t)(cap + 1) * S * sizeof(int32_t));
+    ALLOC(c->st.upd_count, 2 * (size_t)kUpdWords * sizeof(int32_t));
+    ALLOC(c->st.upd_list, 2 * (size_t)kUpdShards * upd_region((int)S, cap) * sizeof(int32_t));
     ALLOC(c->st.spc_count, 2 * sizeof(int32_t));
     ALLOC(c->st.spc_list, 4 * S * sizeof(int32_t));
     c->st.inner_buf = nullptr;
@@ -431,7 +431,8 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         hipMemset(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->d_q, 0, kQWords * sizeof(int32_t)) != hipSuccess || hipMemset(c->d_db_list, 0, 4 * S * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->st.upd_count, 0, 2 * (size_t)(cap + 1) * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(c->st.upd_count, 0, 2 * (size_t)kUpdWords * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(c->st.upd_list, 0, 2 * (size_t)kUpdShards * upd_region((int)S, cap) * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.spc_count, 0, 2 * sizeof(int32_t)) != hipSuccess ||
         hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }

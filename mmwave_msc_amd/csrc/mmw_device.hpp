@@ -134,8 +134,9 @@ struct DevState {
                                    // the same three words at q[kQBig + 8p + ...] for the queue of the larger clouds (ring = list 1)
     int32_t *perm;                 // [2][S] by step parity: scene handled by unit b of k_predict / k_track / k_post, heaviest scenes (most tracks) first; k_post builds the next step's
     double *gate_buf;              // [S][t_cap][kGateRec] gate matrices of this frame, by effective_tracks position (k_predict -> k_track)
-    int32_t *upd_count;            // [2][t_cap+1] by step parity: scenes that hold t tracks to update this frame (k_track -> k_post)
-    int32_t *upd_list;             // [2][t_cap+1][S] ... and which ones: _update_all is laid out over the TRACKS, four per wave
+    int32_t *upd_count;            // [2][kUpdWords] by step parity: tracks in each of the kUpdShards update lists of this frame (k_track -> k_post, next k_predict)
+    int32_t *upd_list;             // [2][kUpdShards][upd_region] ... and the tracks: one packed word each (upd_pack: scene, position, record slot) --
+                                   // _update_all / _predict_all are laid out over the TRACKS of the context, four per wave
     int32_t *spc_count;            // [2] by step parity: scenes the next k_predict cannot take from the update lists ...
     int32_t *spc_list;             // [2][S][2] ... (scene, first new track): scenes that spawned tracks this frame
     int32_t *inner_buf;            // [S][kInnerHdr + inner_cap] seek_inner_clusters calls of the last frame (cfg.seek_inner; mmw_get_inner)
@@ -143,6 +144,19 @@ struct DevState {
     char *huge_scratch;            // [workers][huge_stride] BallTree carve-ups of the clouds of more than kBigCloudMax points (k_dbscan_huge); null when no ring of the context can hold one
     size_t huge_stride;
 };
+// The update lists (track-wise Kalman kernels).  A scene's workgroup of k_track appends its T tracks to the list of its SHARD
+// (workgroup index mod shards: eight counters instead of one word that every workgroup of the launch adds to) with one atomicAdd;
+// the consumers' unit w serves shard w mod shards, entries 4 (w / shards) .. + 3, so the list entry and the list's length are ONE
+// round trip (the entry is read speculatively, clamped into the region) and the record's address is in the entry: two dependent
+// round trips in front of a track's arithmetic where the lists "scenes by track count" of rounds 2-4 had four (bin counts, list
+// entry, order[], record).
+constexpr int kUpdShards = 8, kUpdWords = 16;
+__host__ __device__ inline int kalman_waves_per_scene(int tr_max_tracks) { const int nq = (tr_max_tracks + 3) / 4; return nq < 1 ? 1 : nq; }
+__host__ __device__ inline int upd_shards(int n_units) { return n_units < kUpdShards ? (n_units < 1 ? 1 : n_units) : kUpdShards; }
+__host__ __device__ inline size_t upd_region(int n_scenes, int t_cap) { return ((size_t)(n_scenes + kUpdShards - 1) / kUpdShards + 1) * (size_t)t_cap; }
+__host__ __device__ inline int upd_pack(int s, int j, int slot) { return (s << 12) | (j << 6) | slot; }   // (t_cap <= 63, n_scenes < 2^19: tracks_dense)
+constexpr int kUpdMaxScenes = 1 << 19;
+
 // Contexts of at most this many scenes run a two-launch step (mmw_kalman.hpp: pred_in_track, k_dbscan.hip: k_post takes the large
 // clouds): their step is launch latency.  768 = what is resident at once with the PRED build of k_track (three workgroups
 // per CU); measured 0.0777 -> 0.0705 ms at 768 scenes, 0.0937 -> 0.1128 at 1024.

@@ -587,25 +587,33 @@ __device__ __forceinline__ void predict_math_cols(const DevCfg &cfg, TrackRec *r
 
 // ... for a record that is still in global memory: `Wj` = the group's kPredScratch doubles = [staged record | scratch];
 // the gate record goes to gate_buf[s][j] (by effective_tracks position).
+// (the arithmetic alone, on a record already staged in Wj: the track-wise k_predict stages it before it has looked at the scene's words)
 template <int DX>
-__device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
-                                                  double *Wj, int lane, int c, int &err)
+__device__ __forceinline__ void predict_staged_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
+                                                     double *Wj, int lane, int c, int &err)
 {
-    stage_record<16>(rec, Wj, c);
-    wave_sync();
 #ifdef MMW_PRED_LDS   // (diagnostic builds: the element-wise form with its LDS scratch, as before round 4's column form)
     predict_math<DX, 16, true>(cfg, rec, st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec, live, dt, Wj, Wj + kRecStage, lane, c, err);
 #else
     predict_math_cols<DX>(cfg, rec, st.gate_buf + ((size_t)s * cfg.t_cap + j) * kGateRec, live, dt, Wj, lane, c, err);
 #endif
 }
+template <int DX>
+__device__ __forceinline__ void predict_one_track(const DevCfg &cfg, const DevState &st, TrackRec *rec, bool live, int s, int j, double dt,
+                                                  double *Wj, int lane, int c, int &err)
+{
+    stage_record<16>(rec, Wj, c);
+    wave_sync();
+    predict_staged_track<DX>(cfg, st, rec, live, s, j, dt, Wj, lane, c, err);
+}
 
-// When the track-wise layout is used: it needs one lane per bin (t_cap <= 63), and it only pays when there are more
+// When the track-wise layout is used: a list entry packs (scene, position, slot) into one word (t_cap <= 63, fewer than 2^19
+// scenes), and it only pays when there are more
 // waves than the chip runs at once -- a small context (256 scenes x 4 tracks) is bound by the latency of one wave, and
-// the lists put two more dependent loads in front of it (k_predict 8.3 -> 9.2 us there).  The threshold is 1024 waves for
-// contexts of more than 512 scenes; mmw_config.kalman_dense_min_units overrides it (the parity tests run both layouts on small
-// contexts: tests/_layouts.py).
-__host__ __device__ inline bool tracks_dense(const DevCfg &cfg, int nq) { return cfg.t_cap <= 63 && cfg.n_scenes * nq > cfg.dense_min_units; }
+// the lists put a dependent load in front of it (k_predict 8.3 -> 9.2 us there with the two of rounds 2-4).  The threshold is
+// 1024 waves for contexts of more than 512 scenes; mmw_config.kalman_dense_min_units overrides it (the parity tests run both
+// layouts on small contexts: tests/_layouts.py).
+__host__ __device__ inline bool tracks_dense(const DevCfg &cfg, int nq) { return cfg.t_cap <= 63 && cfg.n_scenes < kUpdMaxScenes && cfg.n_scenes * nq > cfg.dense_min_units; }
 // Contexts whose step is launch latency (<= kSmallContextScenes scenes, per-scene layout -- mmw_create picks it for them unless
 // told otherwise): _predict_all runs at the head of k_track (k_track.hip, PRED instantiations) and k_predict is not
 // launched -- one kernel boundary less.
@@ -616,46 +624,43 @@ __host__ __device__ inline bool pred_in_track(const DevCfg &cfg)
     return cfg.n_scenes <= kSmallContextScenes && !tracks_dense(cfg, nq) && !cfg.seek_inner && !cfg.fused;
 }
 
-// _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of the list
-// "scenes by track count, most tracks first" that k_track built this frame (st.upd_list / st.upd_count; every scene
-// in it was tracked this frame and holds hdr->n_upd = its bin's count) -- entry k is track k % t of the (k / t)-th
-// scene of its bin.  Four real tracks per wave whatever the scenes hold (per-scene waves ran at 75 % of their lanes
-// with 1..8 tracks per scene).  This frame's new tracks (spawn_scene, in worker blocks of the same launch) are not in
-// the lists: they are not updated (Tracking.py:598-603 runs before _add_tracks).  `lds` = this wave's 4 * kUpdScratch
-// doubles.  Needs t_cap <= 63 (one lane per bin).
+// _update_all laid out over the TRACKS of the context: wave `unit` takes four consecutive entries of ITS SHARD of the update
+// lists k_track built this frame (mmw_device.hpp: upd_shards; every scene in them was tracked this frame, entries = its tracks
+// 0 .. hdr->n_upd - 1).  Four real tracks per wave whatever the scenes hold (per-scene waves ran at 75 % of their lanes with
+// 1..8 tracks per scene).  This frame's new tracks (spawn_scene, in worker blocks of the same launch) are not in the lists: they
+// are not updated (Tracking.py:598-603 runs before _add_tracks).  `lds` = this wave's 4 * kUpdScratch doubles.
+struct UpdCursor {
+    const int32_t *list;
+    int tot, k, stride4, last;   // this 16-lane group's entry index, the step between its entries, the region's last index
+};
+__device__ __forceinline__ UpdCursor upd_cursor(const DevCfg &cfg, const DevState &st, int unit, int n_units, int parity, int g, int &entry)
+{
+    const int nsh = upd_shards(n_units), sh = unit % nsh, u = unit / nsh;
+    const size_t region = upd_region(cfg.n_scenes, cfg.t_cap);
+    UpdCursor C;
+    C.list = st.upd_list + ((size_t)parity * kUpdShards + sh) * region;
+    C.stride4 = ((n_units - sh + nsh - 1) / nsh) * 4;   // (the grid is sized for tr_max_tracks per scene; a scene may hold more right after a frame of many new clusters)
+    C.last = (int)region - 1;
+    C.k = u * 4 + g;
+    C.tot = st.upd_count[parity * kUpdWords + sh];
+    entry = C.list[C.k < C.last ? C.k : C.last];   // with the length, not behind it: past the length it is stale and ignored
+    return C;
+}
 template <int DX>
-__device__ __forceinline__ void update_tracks_dense(const DevCfg &cfg, const DevState &st, int unit0, int n_units, int parity, double *lds)
+__device__ __forceinline__ void update_tracks_dense(const DevCfg &cfg, const DevState &st, int unit, int n_units, int parity, double *lds)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const int nb = cfg.t_cap;                       // bins t = t_cap .. 1, lane b <-> t = t_cap - b
-    const int t_of_lane = nb - lane;
-    const int32_t *cnt = st.upd_count + (size_t)parity * (cfg.t_cap + 1);
-    int incl = (lane < nb) ? t_of_lane * cnt[t_of_lane] : 0;  // tracks in this bin
-    const int mine = incl;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    const int total = __shfl(incl, 63);
-    const int excl = incl - mine;
-    // (the grid is sized for tr_max_tracks per scene; a scene may hold more right after a frame of many new clusters)
-    for (int unit = unit0; unit * 4 < total; unit += n_units) {
-    int my_s = 0, my_j = 0;
-    bool live = false;
-#pragma unroll
-    for (int gg = 0; gg < 4; gg++) {
-        const int k = unit * 4 + gg;            // uniform
-        const unsigned long long hit = __ballot(lane < nb && incl > k);
-        if (k < total && hit) {
-            const int b = __ffsll((long long)hit) - 1;  // first bin whose inclusive count exceeds k
-            const int base = __shfl(excl, b), t = nb - b;
-            const int rel = k - base, r = rel / t, j = rel - r * t;
-            const int sc = st.upd_list[((size_t)parity * (cfg.t_cap + 1) + t) * cfg.n_scenes + r];
-            if (g == gg) { my_s = sc; my_j = j; live = true; }
-        }
-    }
-    TrackRec *rec = st.trk + (size_t)my_s * cfg.t_cap + (live ? st.order[(size_t)my_s * cfg.t_cap + my_j] : 0);
-    int err = 0;
-    update_one_track<DX>(rec, live, lds + g * kUpdScratch, lane, c, err);
-    if (err && live) atomicOr(&st.hdr[my_s].err, err);
+    int e;
+    UpdCursor C = upd_cursor(cfg, st, unit, n_units, parity, g, e);
+    while (C.k - g < C.tot) {   // (uniform)
+        const bool live = C.k < C.tot;
+        const int my_s = live ? e >> 12 : 0;
+        TrackRec *rec = st.trk + (size_t)my_s * cfg.t_cap + (live ? (e & 63) : 0);
+        int err = 0;
+        update_one_track<DX>(rec, live, lds + g * kUpdScratch, lane, c, err);
+        if (err && live) atomicOr(&st.hdr[my_s].err, err);
+        C.k += C.stride4;
+        if (C.k - g < C.tot) e = C.list[C.k < C.last ? C.k : C.last];
     }
 }
 

@@ -72,7 +72,7 @@ int main()
     hipMalloc(&din, sizeof(h)); hipMalloc(&dout, 8192 * 256 * 8); hipMalloc(&dt, 8192 * 8);
     hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice);
     const int n = 4096;
-    struct { int grid, block; const char *what; } cfgs[] = {{256, 64, "1 wave per CU"}, {256, 256, "1 wave per SIMD"}, {512, 256, "2 waves per SIMD"}, {1024, 256, "4 waves per SIMD"}};
+    struct { int grid, block; const char *what; } cfgs[] = {{256, 64, "1 wave per CU"}, {256, 256, "1 wave per SIMD"}, {512, 256, "2 waves per SIMD"}, {1024, 256, "4 waves per SIMD"}, {2048, 256, "8 waves per SIMD"}};
     for (auto &c : cfgs) {
         unsigned long long t;
         hipLaunchKernelGGL(k_dep, dim3(c.grid), dim3(c.block), 0, 0, din, dout, dt, n); hipDeviceSynchronize();
@@ -83,6 +83,19 @@ int main()
         hipLaunchKernelGGL(k_ind, dim3(c.grid), dim3(c.block), 0, 0, din, dout, dt, n); hipDeviceSynchronize();
         hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
         printf(" | 8 independent v_fma_f64 chains: %6.2f cycles per instruction", (double)t / n);
+        {   // the same loop 64 x longer between two events: wave instructions per SIMD and nanosecond (wall clock, whatever the shader clock does)
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            const int nl = n * 64;
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_ind, dim3(c.grid), dim3(c.block), 0, 0, din, dout, dt, nl);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
+            const double waves_per_simd = (double)c.grid * (c.block / 64) / 1024.0;
+            printf(" (long run: %6.2f cycles, %.3f ns per instruction and wave, %.3f ns per instruction and SIMD = %.1f TFLOP/s fp64 chip-wide)",
+                   (double)t / nl, ms * 1e6 / nl, ms * 1e6 / nl / (waves_per_simd < 1 ? 1 : waves_per_simd),
+                   2.0 * 64 * nl * (double)c.grid * (c.block / 64) / (ms * 1e-3) * 1e-12);
+        }
         hipLaunchKernelGGL(k_lds, dim3(c.grid), dim3(c.block), 0, 0, din, dout, dt, 1024); hipDeviceSynchronize();
         hipLaunchKernelGGL(k_lds, dim3(c.grid), dim3(c.block), 0, 0, din, dout, dt, 1024); hipDeviceSynchronize();
         hipMemcpy(&t, dt, 8, hipMemcpyDeviceToHost);
