@@ -1652,11 +1652,23 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
 // window, and they are the filler k_track's tail wants.)  The key is n_upd, which nothing in this launch writes: n_tracks may be
 // raised by a spawning worker between the two passes, and a scene counted in one bin but scattered into another would break the
 // permutation.
-// hist: LDS, t_cap + 3 ints.  Loads in batches of eight per thread, all in flight at once.
+// TWO classes, each by descending track count: first the scenes that CAN reach apply_DBscan next frame (fewer than TR_MAX_TRACKS
+// tracks: Tracking.py:693-697), then the full ones.  A cloud that needs the BallTree is a 45-60 us chain that starts when its
+// scene's workgroup of k_track ends; pushed from the launch's first round it is finished long before k_post, pushed from the last
+// one it is what k_post's block 0 -- and with it the step -- waits for.  With "most tracks first" alone the scenes that can push
+// were the LAST of the launch: at K = T block 0 left at 45-60 us in two frames of three while the update blocks were done at 35
+// (scripts/wg_times_post_frames.py, NOTEBOOK round 5).  (A full scene can still trigger when a track expires in this frame's
+// maintenance; rare, and correct either way -- the order is a schedule, not a decision.)
+// hist: LDS, 2 (t_cap + 1) + 1 ints.  Loads in batches of eight per thread, all in flight at once.
 __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevState &st, int parity, int *hist)
 {
     const int tid = threadIdx.x, nb = cfg.t_cap + 1, S = cfg.n_scenes;
-    for (int i = tid; i <= nb + 1; i += 256) hist[i] = 0;
+    auto bin_of = [&](int key) {
+        const int t = key < 0 ? 0 : (key > cfg.t_cap ? cfg.t_cap : key);
+        // (within the first class the scenes WITHOUT tracks lead: they cluster their whole ring, the 100-250 us chains of the large queue)
+        return t == 0 ? 0 : (t < cfg.tr_max_tracks ? 0 : nb) + (nb - t);   // bins 1 .. nb - 1: most tracks first
+    };
+    for (int i = tid; i <= 2 * nb; i += 256) hist[i] = 0;
     __syncthreads();
     for (int base = 0; base < S; base += 256 * 8) {
         int key[8];
@@ -1666,17 +1678,13 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
             key[u] = sc < S ? st.hdr[sc].n_upd : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            if (base + u * 256 + tid < S) {
-                const int t = key[u] < 0 ? 0 : (key[u] > cfg.t_cap ? cfg.t_cap : key[u]);
-                atomicAdd(&hist[nb - 1 - t], 1);  // bin 0 = most tracks
-            }
-        }
+        for (int u = 0; u < 8; u++)
+            if (base + u * 256 + tid < S) atomicAdd(&hist[bin_of(key[u])], 1);
     }
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int b = 0; b < nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
+        for (int b = 0; b <= 2 * nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
     for (int base = 0; base < S; base += 256 * 8) {
@@ -1689,10 +1697,7 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int sc = base + u * 256 + tid;
-            if (sc < S) {
-                const int t = key[u] < 0 ? 0 : (key[u] > cfg.t_cap ? cfg.t_cap : key[u]);
-                st.perm[(size_t)(parity ^ 1) * S + atomicAdd(&hist[nb - 1 - t], 1)] = sc;
-            }
+            if (sc < S) st.perm[(size_t)(parity ^ 1) * S + atomicAdd(&hist[bin_of(key[u])], 1)] = sc;
         }
     }
 }

@@ -260,25 +260,21 @@ __device__ __forceinline__ void update_math(TrackRec *rec, bool live, const doub
     wave_sync();
 }
 
-// Lane K of every 16-lane row, to all lanes of that row: the one DPP control the 64-bit moves take (row_newbcast).  All 64 lanes
-// must be active (a DPP read of a disabled lane returns nothing useful), hence only in wave-uniform code; the wait states between a
-// VALU write and a DPP read of the same register are the asm's own (the compiler does not see a DPP instruction in it).
+// Lane K of every 16-lane row, to all lanes of that row: the one DPP control the 64-bit moves take (row_newbcast), as ONE
+// v_mov_b64_dpp through the compiler's own builtin -- it knows the instruction is a DPP move, keeps the wait states a VALU write
+// -> DPP read needs by SCHEDULING other work in between, and interleaves independent chains of products.  (Rounds 4-5 issued it
+// from inline asm with a leading `s_nop 1` of its own, every broadcast chained to the accumulator it feeds so that the scheduler
+// would not line all of them up: 492 of the update's 2249 instructions were s_nop, a fifth of its issue slots.)  All 64 lanes
+// must be active (a DPP read of a disabled lane returns nothing useful), hence only in wave-uniform code.
 template <int K>
 __device__ __forceinline__ double row_bcast(double v)
 {
-    double r;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
-    return r;
+    return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false);
 }
-
-// ... with a value the move has to wait for (never read): the chain of products then takes its broadcasts one at a time instead
-// of the scheduler lining all of them up first (36 .. 135 live doubles: 124 VGPRs spilled under k_post's budget)
 template <int K>
-__device__ __forceinline__ double row_bcast_after(double v, double dep)
+__device__ __forceinline__ double row_bcast_after(double v, double)
 {
-    double r;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K), "v"(dep));
-    return r;
+    return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, false);
 }
 
 // update_math for the batched kernels (16 lanes per track) with the operands the lanes of a track share -- S^-1, Rc, rows of K,

@@ -100,9 +100,24 @@ __device__ __forceinline__ void lds_barrier()
 // scales by rp[r] last; det = signed product of the pivots in order.
 // On return lanes 6..11 hold columns 0..5 of the inverse in v; det is valid in every lane of the group.
 // All 64 lanes must call; the result (false = a zero pivot) is per group.
+// Lane k (0..5, a constant once the loops below are unrolled) of every 16-lane row to all lanes of that row, as one DPP move
+// (row_newbcast: v_mov_b64_dpp for a double, v_mov_b32_dpp for an int) -- not a trip through the LDS crossbar (ds_bpermute), which
+// is what __shfl(x, row base + k) compiles to.  All 64 lanes must be active.
+template <typename T>
+__device__ __forceinline__ T lu_row_bcast(T x, int k)
+{
+    switch (k) {
+    case 0: return __builtin_amdgcn_mov_dpp(x, 0x150, 0xf, 0xf, false);
+    case 1: return __builtin_amdgcn_mov_dpp(x, 0x151, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_mov_dpp(x, 0x152, 0xf, 0xf, false);
+    case 3: return __builtin_amdgcn_mov_dpp(x, 0x153, 0xf, 0xf, false);
+    case 4: return __builtin_amdgcn_mov_dpp(x, 0x154, 0xf, 0xf, false);
+    default: return __builtin_amdgcn_mov_dpp(x, 0x155, 0xf, 0xf, false);
+    }
+}
 __device__ __forceinline__ bool lu6_inverse_cols(double (&v)[6], int lane, double &det)
 {
-    const int c = lane & 15, gb = lane & ~15;
+    const int c = lane & 15;
     if (c >= 6) {
 #pragma unroll
         for (int i = 0; i < 6; i++) v[i] = (c - 6 == i) ? 1.0 : 0.0;
@@ -125,11 +140,11 @@ __device__ __forceinline__ bool lu6_inverse_cols(double (&v)[6], int lane, doubl
 #pragma unroll
         for (int i = k + 1; i < 6; i++) l[i] = ((p == i) ? v[k] : v[i]) * rpl;  // row i after the swap k <-> p
         // what lane k found, for the whole group
-        p = __shfl(p, gb + k);
-        pv = __shfl(pv, gb + k);
-        rp[k] = __shfl(rpl, gb + k);
+        p = lu_row_bcast(p, k);
+        pv = lu_row_bcast(pv, k);
+        rp[k] = lu_row_bcast(rpl, k);
 #pragma unroll
-        for (int i = k + 1; i < 6; i++) l[i] = __shfl(l[i], gb + k);
+        for (int i = k + 1; i < 6; i++) l[i] = lu_row_bcast(l[i], k);
         if (!(fabs(pv) > 0.0)) ok = false;
         if (p != k) neg = !neg;
         d = (k == 0) ? pv : d * pv;  // the pivots in order
@@ -151,7 +166,7 @@ __device__ __forceinline__ bool lu6_inverse_cols(double (&v)[6], int lane, doubl
 #pragma unroll
     for (int k = 1; k < 6; k++) {
 #pragma unroll
-        for (int r = 0; r < k; r++) u[r][k] = __shfl(v[r], gb + k);
+        for (int r = 0; r < k; r++) u[r][k] = lu_row_bcast(v[r], k);
     }
 #pragma unroll
     for (int k = 5; k >= 0; k--) {
