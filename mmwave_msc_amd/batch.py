@@ -224,10 +224,11 @@ class SceneBatch:
         -> pts[S][max_pts][8] fp64, n_out[S] (device)."""
         self._chk(self.L.mmw_normalize_tlv(self.h, packets_ptr, tlv_offset_ptr, C.byref(uart_cfg), pts_ptr, n_out_ptr))
 
-    def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray, raise_nonfinite: bool = True):
+    def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray, raise_nonfinite: bool = True, check: bool = True):
         """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S]).  raise_nonfinite=False: a scene
         whose apply_DBscan call raised sklearn's ValueError (a NaN / infinite row in its ring) does not raise here -- its db_n is
-        DB_RAISED (-2), its sticky bit stays set (`errors()`, `clear_errors()`), every other scene's results are as always."""
+        DB_RAISED (-2), its sticky bit stays set (`errors()`, `clear_errors()`), every other scene's results are as always.
+        check=False: no scene error raises (the caller reads `errors()`); failures of the call itself still do."""
         pts = np.ascontiguousarray(pts, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         dt = np.ascontiguousarray(dt, dtype=np.float64)
@@ -237,7 +238,8 @@ class SceneBatch:
         dbn = np.full(self.S, -1, dtype=np.int32)
         rc = self.L.mmw_step_host(self.h, pts.ctypes.data, n.ctypes.data, dt.ctypes.data,
                                   assoc.ctypes.data, labels.ctypes.data, dbn.ctypes.data)
-        if not (rc == _lib.E_NONFINITE and not raise_nonfinite):   # (the results are complete either way: the check is the last thing)
+        scene_error = rc in (_lib.E_NONFINITE, _lib.E_SINGULAR, _lib.E_DIVZERO, _lib.E_CAPACITY)   # (the results are complete: the check is the last thing)
+        if not ((rc == _lib.E_NONFINITE and not raise_nonfinite) or (scene_error and not check)):
             self._chk(rc)
         return assoc, labels, dbn
 

@@ -12,12 +12,13 @@ import bench  # noqa: E402
 from mmwave_msc_amd import _lib  # noqa: E402
 from mmwave_msc_amd.batch import SceneBatch  # noqa: E402
 
-S, N, T, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 512, 8, 60
+S, N, T, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 512, 8, int(os.environ.get("FRAMES", "60"))
+RESET_AT = int(os.environ.get("RESET_AT", "10"))   # frame at which the counters are cleared (FRAMES=160 RESET_AT=100: the window in which scenes that lost tracks re-cluster)
 pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=16)
 sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
 bp = sb.alloc(S * N * 64); bn = sb.alloc(S * 4); bd = sb.alloc(S * 8)
 for f in range(F):
-    if f == 10:
+    if f == RESET_AT:
         sb.stats_reset()
     bp.upload(pts[f].astype(np.float64)); bn.upload(cnt[f]); bd.upload(dts[f])
     sb.step_dev(bp.ptr, bn.ptr, bd.ptr)

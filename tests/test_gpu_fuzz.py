@@ -206,7 +206,9 @@ def test_random_configuration_with_nonfinite_rows_vs_oracle(seed, layout):
                 failed[s] = int(str(e).rsplit("rc=", 1)[1])
         if failed:     # LinAlgError / ZeroDivisionError / a capacity limit: covered by test_random_configuration_vs_oracle
             break
-        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f], raise_nonfinite=False)
+        # (a scene that goes on past the reference's MID-frame exception may meet the ZeroDivisionError / LinAlgError the reference
+        #  never got to -- seed 41205 of a wide window: that must not end the step's read-out; its bits are looked at below)
+        assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f], raise_nonfinite=False, check=not inner_raised)
         err = sb.errors()
         for s in range(S):
             want_bit = raised.get(s, 0) | inner_raised.get(s, 0)
@@ -216,7 +218,7 @@ def test_random_configuration_with_nonfinite_rows_vs_oracle(seed, layout):
                 assert (err[s] & ~NF) == 0, (seed, f, s, err[s])
                 assert (dbn[s] == _lib.DB_RAISED) == (s in raised), (seed, f, s, dbn[s])
         if raised or inner_raised:
-            with pytest.raises(ValueError):
+            with pytest.raises((ValueError, ZeroDivisionError, np.linalg.LinAlgError) if inner_raised else ValueError):
                 sb.check()
             sb.clear_errors(NF)
         if inner_raised:
