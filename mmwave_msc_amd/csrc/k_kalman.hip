@@ -31,6 +31,12 @@ constexpr int kSpecialUnits = 64;
 // Three waves per SIMD (134 VGPRs, nothing spilled).  Rounds 1-4 capped the kernel at 128 VGPRs for a fourth wave, at the price of
 // 2 spilled VGPRs and a scratch-enabled dispatch of 8256 workgroups; same box, alternating (scripts/ab_libs.sh, NOTEBOOK round 5):
 // 4096 scenes 20.4-21.0 us capped against 20.1-20.4, 1024 scenes 11.8 against 11.1.
+// The track-wise launch is persistent: 12 one-wave workgroups per CU, each walking its shard of the lists with the launch's stride
+// (same box, alternating, K = T: one workgroup per four tracks 26.1-26.3 us, 16 per CU 24.7-25.2, 12 per CU 23.7-24.2, 8 per CU
+// 27.0-27.2; the mixed population 18.4-18.7 either way -- profiles/NOTEBOOK.md round 5).
+#ifndef MMW_PRED_RESIDENT   // (diagnostic builds: dense one-wave workgroups per CU of the persistent launch)
+#define MMW_PRED_RESIDENT 12
+#endif
 #ifndef MMW_PRED_OCC   // (diagnostic builds: another register budget)
 #define MMW_PRED_OCC 3
 #endif
@@ -43,14 +49,14 @@ __global__ __launch_bounds__(64, MMW_PRED_OCC) void k_predict(DevCfg cfg, DevSta
     double *Wj = lds + g * kPredScratch;
     int err = 0;
     if (tracks_dense(cfg, nq)) {
-        const int prev = parity ^ 1, n_dense = cfg.n_scenes * nq, unit = blockIdx.x;
+        const int prev = parity ^ 1, n_dense = (int)gridDim.x - kSpecialUnits, unit = blockIdx.x;   // (the dense units this launch runs: launch_predict)
         // (unit w < n_dense serves shard w mod shards of last frame's update lists; every unit without dense work -- the
         //  kSpecialUnits behind the dense range always, and the idle rest of every shard: after a frame in which EVERY scene
         //  spawned tracks, the first frames after a reset, that is all of them; 64 waves alone took 555 us for the 4096 scenes
         //  of the start-up -- serves the two lists below)
         // (the dependent round trips of a wave are what this launch lasts, at 12 waves per CU: the shard lengths and this group's
         //  list entry are requested together, then the scene's four words AND the record, whose address the entry holds: two)
-        const int nsh = upd_shards(n_dense);
+        const int nsh = upd_shards(cfg.n_scenes * nq);
         int tot[kUpdShards];
 #pragma unroll
         for (int i = 0; i < kUpdShards; i++) tot[i] = st.upd_count[prev * kUpdWords + i];
@@ -161,7 +167,18 @@ void launch_predict(const DevCfg &cfg, const DevState &st, const int32_t *n_pts,
 {
     if (pred_in_track(cfg) || cfg.fused) return;  // _predict_all runs at the head of k_track / inside k_scene there (mmw_kalman.hpp)
     const int nq = waves_per_scene(cfg);
-    const int grid = cfg.n_scenes * nq + (tracks_dense(cfg, nq) ? kSpecialUnits : 0);
+    int grid = cfg.n_scenes * nq;
+    if (tracks_dense(cfg, nq)) {
+        // the track-wise launch is PERSISTENT: as many one-wave workgroups as the chip holds at once (MMW_PRED_RESIDENT per CU), each
+        // walking its shard of the lists with that stride
+        static const int resident = []() {
+            int dev = 0, n_cu = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+            return n_cu * MMW_PRED_RESIDENT;
+        }();
+        if (resident >= kUpdShards && resident < grid) grid = resident;
+        grid += kSpecialUnits;
+    }
     if (cfg.dx == 9) mmw_launch(k_predict<9>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
     else mmw_launch(k_predict<6>, dim3(grid), dim3(64), 0, stream, cfg, st, n_pts, dt, nq, parity);
 }

@@ -629,9 +629,11 @@ struct UpdCursor {
     const int32_t *list;
     int tot, k, stride4, last;   // this 16-lane group's entry index, the step between its entries, the region's last index
 };
+// (`n_units` = the units the launch runs for the dense work, at least the shard count: a launch smaller than the lists walks them
+//  with that stride)
 __device__ __forceinline__ UpdCursor upd_cursor(const DevCfg &cfg, const DevState &st, int unit, int n_units, int parity, int g, int &entry)
 {
-    const int nsh = upd_shards(n_units), sh = unit % nsh, u = unit / nsh;
+    const int nsh = upd_shards(cfg.n_scenes * kalman_waves_per_scene(cfg.tr_max_tracks)), sh = unit % nsh, u = unit / nsh;
     const size_t region = upd_region(cfg.n_scenes, cfg.t_cap);
     UpdCursor C;
     C.list = st.upd_list + ((size_t)parity * kUpdShards + sh) * region;
