@@ -132,8 +132,14 @@ def test_scene_reset_after_a_reference_exception_vs_oracle(seed, layout):
                 except RuntimeError:
                     failed.append(s)
         if failed:
-            with pytest.raises(_lib.MmwError):
-                sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
+            if seed == 56:   # the read-out form: no scene's error raises, the results of the others are there, the caller reads errors()
+                assoc, labels, dbn = sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f], check=False)
+                for s in range(S):
+                    if want[s] is not None:
+                        assert np.array_equal(assoc[s, : max(int(cnt[f, s]), 0)], want[s][0]), (seed, f, s)
+            else:
+                with pytest.raises(_lib.MmwError):
+                    sb.step_host(pts[f].astype(np.float64), cnt[f], dts[f])
             mask = np.zeros(S, bool)
             mask[failed] = True
             assert np.array_equal(sb.errors() != 0, mask), (seed, f)
