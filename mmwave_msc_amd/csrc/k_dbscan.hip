@@ -1660,22 +1660,31 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
 // (scripts/wg_times_post_frames.py, NOTEBOOK round 5).  (A full scene can still trigger when a track expires in this frame's
 // maintenance; rare, and correct either way -- the order is a schedule, not a decision.)
 // hist: LDS, 2 (t_cap + 1) + 1 ints.  Loads in batches of eight per thread, all in flight at once.
+// (192: just above a ring of clutter; same box, alternating: 256 equal within the noise, 128 -- too many scenes in front -- 3-6 % slower)
+#ifndef MMW_SCHED_BIG_U   // (diagnostic builds: another ring size from which a scene leads the schedule)
+#define MMW_SCHED_BIG_U 192
+#endif
 __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevState &st, int parity, int *hist)
 {
     const int tid = threadIdx.x, nb = cfg.t_cap + 1, S = cfg.n_scenes;
     auto bin_of = [&](int key) {
-        const int t = key < 0 ? 0 : (key > cfg.t_cap ? cfg.t_cap : key);
-        // (within the first class the scenes WITHOUT tracks lead: they cluster their whole ring, the 100-250 us chains of the large queue)
-        return t == 0 ? 0 : (t < cfg.tr_max_tracks ? 0 : nb) + (nb - t);   // bins 1 .. nb - 1: most tracks first
+        const int t = (key & 0xffff) > cfg.t_cap ? cfg.t_cap : (key & 0xffff);
+        // (in front of everything: the scenes whose ring holds MORE THAN CLUTTER -- more than MMW_SCHED_BIG_U unassigned points: a cloud that
+        //  was not clustered away this frame comes back next frame, a 45-250 us chain again --, then the scenes without tracks, then the
+        //  first class by descending track count.
+        //  Ascending -- "the fewer tracks a scene has kept, the more of its points are unassigned" -- was measured: the launch then
+        //  ends on its heaviest workgroups, mixed population + 4 %)
+        if (key >> 16) return 0;
+        return t == 0 ? 1 : (t < cfg.tr_max_tracks ? 1 : 1 + nb) + (nb - t);
     };
-    for (int i = tid; i <= 2 * nb; i += 256) hist[i] = 0;
+    for (int i = tid; i <= 2 * nb + 1; i += 256) hist[i] = 0;
     __syncthreads();
     for (int base = 0; base < S; base += 256 * 8) {
         int key[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int sc = base + u * 256 + tid;
-            key[u] = sc < S ? st.hdr[sc].n_upd : -1;
+            key[u] = sc < S ? ((st.hdr[sc].n_upd < 0 ? 0 : st.hdr[sc].n_upd) & 0xffff) | (st.hdr[sc].db_u > MMW_SCHED_BIG_U ? 0x10000 : 0) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
@@ -1684,7 +1693,7 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int b = 0; b <= 2 * nb; b++) { const int c = hist[b]; hist[b] = run; run += c; }
+        for (int b = 0; b <= 2 * nb + 1; b++) { const int c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
     for (int base = 0; base < S; base += 256 * 8) {
@@ -1692,7 +1701,7 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int sc = base + u * 256 + tid;
-            key[u] = sc < S ? st.hdr[sc].n_upd : -1;
+            key[u] = sc < S ? ((st.hdr[sc].n_upd < 0 ? 0 : st.hdr[sc].n_upd) & 0xffff) | (st.hdr[sc].db_u > MMW_SCHED_BIG_U ? 0x10000 : 0) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
