@@ -143,8 +143,24 @@ def cpu_legs(pts, cnt, dts, tracks, cores, W, py_scenes_per_core, py_frames, c_s
     return out, finals
 
 
-PROF_EVERY = 4  # hipEvent-timed steps inside the timed region: one in PROF_EVERY
+# hipEvent-timed launches inside the timed region.  An event pair holds the stream for 10-20 us (a trace of the sampled steps,
+# scripts/trace_chain_start.sh: 6.6 + 4.5 + 7 us of gaps around the timed kernels), so the sample is thin: k_track -- the roofline
+# kernel -- in one step of PROF_EVERY, and in the step half way between two of those ONE of the other three kernels in rotation;
+# never two pairs in a step.  (Measured on one box, 40 steps: a pair of kernels in every 4th step cost 3.3 % of the headline --
+# 0.2040 ms per step against 0.1973 with a single sample; this scheme costs ~1 %.)
+PROF_EVERY = int(os.environ.get("MMW_BENCH_PROF_EVERY", "10"))
 OTHER_KERNELS = (5, 1, 6)  # _lib.K_PREDICT, K_DBSCAN, K_POST
+
+
+def profiled_kernels(i, n_steps):
+    """Which kernels of timed step i (of n_steps) carry a HIP-event pair: () for most steps.  A short run samples more
+    densely, so that each of the four kernels is seen at least once."""
+    period = max(2, min(PROF_EVERY, n_steps // 4))
+    if i % period == 0:
+        return (0,)   # _lib.K_TRACK
+    if i % period == period // 2:
+        return (OTHER_KERNELS[(i // period) % len(OTHER_KERNELS)],)
+    return ()
 # algorithmic bytes per track of the two Kalman kernels (DESIGN.md §5): k_predict reads the 1232-byte record
 # prefix, writes P and x (720) and the gate record (352); the update half of k_post reads the prefix and
 # writes P and x
@@ -480,11 +496,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for f in range(W, F):
-        # A HIP-event pair costs the stream ~10 us of idle time, so the live kernel durations come from a
-        # sample of the timed launches: every PROF_EVERY-th step times k_track and, in rotation, one of the
-        # other three kernels of the step
-        if (f - W) % PROF_EVERY == 0:
-            sb.profile(True, kernels=(_lib.K_TRACK, OTHER_KERNELS[((f - W) // PROF_EVERY) % len(OTHER_KERNELS)]))
+        # the live kernel durations come from a thin sample of the timed launches (profiled_kernels above)
+        pk = profiled_kernels(f - W, F - W)
+        if pk:
+            sb.profile(True, kernels=pk)
         else:
             sb.profile(False)
         step(f)
@@ -531,8 +546,9 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for f in range(W, F):
-            if (f - W) % PROF_EVERY == 0:
-                ctx.profile(True, kernels=(_lib.K_TRACK, OTHER_KERNELS[((f - W) // PROF_EVERY) % len(OTHER_KERNELS)]))
+            pk = profiled_kernels(f - W, F - W)
+            if pk:
+                ctx.profile(True, kernels=pk)
             else:
                 ctx.profile(False)
             st_(f)
@@ -650,7 +666,7 @@ def main():
 
     if rank == 0:
         total_sf = S_total * K
-        # per-kernel device time from the sampled HIP-event pairs (one step in PROF_EVERY); algorithmic bytes
+        # per-kernel device time from the sampled HIP-event pairs (profiled_kernels: a thin sample); algorithmic bytes
         # from the device counters, which cover all K steps
         n_samp = max(prof[_lib.K_TRACK][1], 1)
         step_ms = {k: prof[k][0] / max(prof[k][1], 1)
