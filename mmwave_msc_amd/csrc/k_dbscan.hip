@@ -1510,6 +1510,7 @@ __device__ __forceinline__ void q_acquire() { __builtin_amdgcn_fence(__ATOMIC_AC
 // The small queue from k_post (the step's pushes are complete): tickets are taken with one atomicAdd -- a ticket past the
 // count ends the block, and the counters are reset before their parity is used again.  (k_chain claims with a
 // compare-and-swap only when an entry is there, so a worker that gives up -- bounded wait -- never holds a ticket.)
+template <int NT = 256>
 __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevState &st, char *lds_raw, int UMc, int CL, int UM_out, int parity,
                                                   int32_t *__restrict__ labels_out, int32_t *__restrict__ db_n_out)
 {
@@ -1553,10 +1554,10 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
         // (seek_inner contexts run no k_chain; k_inner may have filled the track list after k_track queued the scene: then
         //  there is no apply_DBscan this frame -- uniform)
         if (!(cfg.seek_inner && !hdr->need_db)) {
-            if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
+            if (cloud_pairs_prove_no_core<NT>(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
                 cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
             else
-                spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
+                spawn_scene<NT, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
         }
     }
 }
@@ -1664,6 +1665,7 @@ __device__ __forceinline__ void big_wait_done(const DevState &st, int parity)
 #ifndef MMW_SCHED_BIG_U   // (diagnostic builds: another ring size from which a scene leads the schedule)
 #define MMW_SCHED_BIG_U 192
 #endif
+template <int NT = 256>
 __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevState &st, int parity, int *hist)
 {
     const int tid = threadIdx.x, nb = cfg.t_cap + 1, S = cfg.n_scenes;
@@ -1677,18 +1679,18 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
         if (key >> 16) return 0;
         return t == 0 ? 1 : (t < cfg.tr_max_tracks ? 1 : 1 + nb) + (nb - t);
     };
-    for (int i = tid; i <= 2 * nb + 1; i += 256) hist[i] = 0;
+    for (int i = tid; i <= 2 * nb + 1; i += NT) hist[i] = 0;
     __syncthreads();
-    for (int base = 0; base < S; base += 256 * 8) {
+    for (int base = 0; base < S; base += NT * 8) {
         int key[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int sc = base + u * 256 + tid;
+            const int sc = base + u * NT + tid;
             key[u] = sc < S ? ((st.hdr[sc].n_upd < 0 ? 0 : st.hdr[sc].n_upd) & 0xffff) | (st.hdr[sc].db_u > MMW_SCHED_BIG_U ? 0x10000 : 0) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
-            if (base + u * 256 + tid < S) atomicAdd(&hist[bin_of(key[u])], 1);
+            if (base + u * NT + tid < S) atomicAdd(&hist[bin_of(key[u])], 1);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1696,16 +1698,16 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
         for (int b = 0; b <= 2 * nb + 1; b++) { const int c = hist[b]; hist[b] = run; run += c; }
     }
     __syncthreads();
-    for (int base = 0; base < S; base += 256 * 8) {
+    for (int base = 0; base < S; base += NT * 8) {
         int key[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int sc = base + u * 256 + tid;
+            const int sc = base + u * NT + tid;
             key[u] = sc < S ? ((st.hdr[sc].n_upd < 0 ? 0 : st.hdr[sc].n_upd) & 0xffff) | (st.hdr[sc].db_u > MMW_SCHED_BIG_U ? 0x10000 : 0) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int sc = base + u * 256 + tid;
+            const int sc = base + u * NT + tid;
             if (sc < S) st.perm[(size_t)(parity ^ 1) * S + atomicAdd(&hist[bin_of(key[u])], 1)] = sc;
         }
     }
@@ -1729,8 +1731,8 @@ __device__ __forceinline__ void post_schedule_sort(const DevCfg &cfg, const DevS
 #ifndef MMW_POST_OCC   // (diagnostic builds: another register budget for the launch)
 #define MMW_POST_OCC 2
 #endif
-template <int DX>
-__global__ __launch_bounds__(256, MMW_POST_OCC) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
+template <int DX, int NT>
+__global__ __launch_bounds__(NT, MMW_POST_OCC) void k_post(DevCfg cfg, DevState st, const int32_t *__restrict__ n_pts, int nq, int G0, int UMc, int CL,
                                               int UMb, int CLb, int UM_out, int parity, int epoch, int32_t *__restrict__ labels_out,
                                               int32_t *__restrict__ db_n_out)
 {
@@ -1791,16 +1793,16 @@ __global__ __launch_bounds__(256, MMW_POST_OCC) void k_post(DevCfg cfg, DevState
                 SceneHdr *hdr = st.hdr + s;
                 const int U = hdr->db_u;
                 if (cfg.seek_inner && !hdr->need_db) continue;  // k_inner filled the track list: no apply_DBscan this frame (uniform)
-                if (cloud_pairs_prove_no_core(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
+                if (cloud_pairs_prove_no_core<NT>(cfg, ring_rows_of(cfg, st, hdr, s), U, P4, cnt, mm, flag))
                     cloud_finish_empty(st, hdr, s, U, UM_out, labels_out, db_n_out);
                 else
-                    spawn_scene<256, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
+                    spawn_scene<NT, true>(cfg, st, L, s, UMc, CL, UM_out, true, parity, labels_out, db_n_out);
                 __syncthreads();  // LDS is reused by the next scene
             }
         }
-        chain_worker_loop(cfg, st, lds_raw, UMc, CL, UM_out, parity, labels_out, db_n_out);
+        chain_worker_loop<NT>(cfg, st, lds_raw, UMc, CL, UM_out, parity, labels_out, db_n_out);
         if (UMb > 0 && st.q[kQBig + parity * 8 + kQCount] != 0) {  // small context: the large clouds here as well (k_track is complete: plain load)
-            big_worker_loop<256, true, false>(cfg, st, lds_raw, UMb, CLb, UM_out, parity, 0, labels_out, db_n_out);
+            big_worker_loop<NT, true, false>(cfg, st, lds_raw, UMb, CLb, UM_out, parity, 0, labels_out, db_n_out);
             if (blockIdx.x == 0 && threadIdx.x == 0) big_wait_done(st, parity);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1815,11 +1817,11 @@ __global__ __launch_bounds__(256, MMW_POST_OCC) void k_post(DevCfg cfg, DevState
         return;
     }
     if ((int)blockIdx.x == G0) {  // (not launched by the fused step: k_scene reads no schedule, every scene is resident)
-        post_schedule_sort(cfg, st, parity, reinterpret_cast<int *>(lds_raw));
+        post_schedule_sort<NT>(cfg, st, parity, reinterpret_cast<int *>(lds_raw));
         return;
     }
     const int wave = threadIdx.x >> 6;
-    const int unit = ((int)blockIdx.x - G0 - 1) * 4 + wave;
+    const int unit = ((int)blockIdx.x - G0 - 1) * (NT / 64) + wave;
     if (unit >= cfg.n_scenes * nq) return;
     double *scratch = reinterpret_cast<double *>(lds_raw) + (size_t)wave * 4 * kUpdScratch;
     if (tracks_dense(cfg, nq)) {  // four real tracks per wave, from the lists k_track built this frame
@@ -2036,9 +2038,9 @@ size_t dbscan_lds_bytes(int cls, int UM, int t_cap, int min_samples)
 }
 size_t dbscan_only_lds_bytes(int UM) { return db_lds_layout<false>(UM < kClassUM[2] ? UM : kClassUM[2], 0, false, nullptr, nullptr); }
 
-static size_t post_lds_bytes(int UM, int t_cap, int min_samples)
+static size_t post_lds_bytes(int UM, int t_cap, int min_samples, int waves = 4)
 {
-    const size_t upd = (size_t)4 * 4 * kUpdScratch * sizeof(double);
+    const size_t upd = (size_t)waves * 4 * kUpdScratch * sizeof(double);
     const size_t db = db_align16(dbscan_lds_bytes(0, UM, t_cap, min_samples)) + 4096 + (256 + 2) * 4 + 3 * 8 + 16 + 64;  // + pair-count scratch + ticket
     return upd > db ? upd : db;
 }
@@ -2076,9 +2078,14 @@ hipError_t prepare_dbscan(int UM, int t_cap, int min_samples)
     const int bum = big_um(UM, UM);
     const size_t big = big_lds_bytes(bum, big_cl(bum, t_cap, min_samples), false);
     const size_t post = post_lds_bytes(UM, t_cap, min_samples) > big ? post_lds_bytes(UM, t_cap, min_samples) : big;  // (small contexts: the large clouds in k_post)
-    hipError_t e = hipFuncSetAttribute((const void *)k_post<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post);
+    hipError_t e = hipFuncSetAttribute((const void *)k_post<9, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)k_post<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post);
+    e = hipFuncSetAttribute((const void *)k_post<6, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post);
+    if (e != hipSuccess) return e;
+    const size_t c5 = chain_lds_bytes(kBigThreads, t_cap, min_samples), post512 = (c5 > big ? c5 : big) > post ? (c5 > big ? c5 : big) : post;   // (behind the fused step: 512-thread worker blocks)
+    e = hipFuncSetAttribute((const void *)k_post<9, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post512);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void *)k_post<6, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)post512);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void *)k_dbscan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
     if (e != hipSuccess) return e;
@@ -2138,10 +2145,29 @@ void launch_post(const DevCfg &cfg, const DevState &st, const int32_t *n_pts, in
         constexpr int kSmallContextWorkers = 64;  // (32 .. 128 measured equal)
         if (G0 > kSmallContextWorkers) G0 = kSmallContextWorkers;
     }
+    if (units == 0) {
+        // Behind the fused step only the DBSCAN workers are left: 512-THREAD blocks, as k_chain's -- a BallTree chain is ~40 us on
+        // 512 threads against 45-60 on 256 (queries and the register sort network split two ways), and with the update gone nothing
+        // in the launch wants two blocks per CU.  (For the contexts whose update runs here the same was measured and lost:
+        // eight update waves that start and end together, profiles/NOTEBOOK.md round 5.)
+        // (the 512-thread build wants one exchange slot per thread: the small clouds' carve-up holds at least 512 points, as k_chain's)
+        const int umc5 = umc < kBigThreads ? kBigThreads : umc, cl5 = big_cl(umc5, cfg.t_cap, cfg.db_min_samples);
+        const size_t c5 = chain_lds_bytes(umc5, cfg.t_cap, cfg.db_min_samples);
+        if (c5 > lds) lds = c5;
+        if (umb > 0 && umb < kBigThreads) {   // ... and so does the large clouds' (a context whose rings hold 257 .. 511 points)
+            umb = kBigThreads;
+            clb = big_cl(umb, cfg.t_cap, cfg.db_min_samples);
+            const size_t b5 = big_lds_bytes(umb, clb, false);
+            if (b5 > lds) lds = b5;
+        }
+        if (cfg.dx == 9) mmw_launch(k_post<9, 512>, dim3(G0), dim3(512), lds, stream, cfg, st, n_pts, nq, G0, umc5, cl5, umb, clb, UM, parity, epoch, labels, db_n);
+        else mmw_launch(k_post<6, 512>, dim3(G0), dim3(512), lds, stream, cfg, st, n_pts, nq, G0, umc5, cl5, umb, clb, UM, parity, epoch, labels, db_n);
+        return;
+    }
     const int upd_blocks = (units + 3) / 4;
-    const dim3 grid(G0 + (units > 0 ? 1 + upd_blocks : 0));  // workers | the schedule sort | _update_all
-    if (cfg.dx == 9) mmw_launch(k_post<9>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
-    else mmw_launch(k_post<6>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
+    const dim3 grid(G0 + 1 + upd_blocks);  // workers | the schedule sort | _update_all
+    if (cfg.dx == 9) mmw_launch(k_post<9, 256>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
+    else mmw_launch(k_post<6, 256>, grid, dim3(256), lds, stream, cfg, st, n_pts, nq, G0, umc, cl, umb, clb, UM, parity, epoch, labels, db_n);
 }
 
 // The chain workers beside k_track and k_post (a second stream; see k_chain)

@@ -137,7 +137,7 @@ def test_step_kernels_compile_without_scratch():
                 assert not re.search(r"\bscratch_|buffer_(load|store)\S* .*offen", body), (name, scratch)
     for k in ("k_track", "k_scene", "k_predict", "k_post", "k_chain", "k_dbscan_big", "k_dbscan_huge", "k_inner", "k_dbscan_startup"):
         assert k in seen, (k, sorted(seen))
-    assert len(seen["k_track"]) == 24 and len(seen["k_scene"]) == 12 and len(seen["k_post"]) == 2 and len(seen["k_predict"]) == 2
+    assert len(seen["k_track"]) == 24 and len(seen["k_scene"]) == 12 and len(seen["k_post"]) == 4 and len(seen["k_predict"]) == 2   # (k_post: two motion models x 256- and 512-thread blocks)
     # the benchmarked instantiations keep the occupancy their launch geometry is sized for
     for name, vgprs, occ in seen["k_track"]:
         if re.search(r"k_trackILi[12]ELb0ELb0ELb[01]E", name):
