@@ -53,10 +53,13 @@ def close64(a, b, tol=F64_TOL):
 def assert_tracks_match(got, want, ctx="", tol=F64_TOL, exact=False):
     assert len(got) == len(want), f"{ctx}: track count {len(got)} != {len(want)}"
     for name in INT_FIELDS:
-        assert np.array_equal(got[name], want[name]), f"{ctx}: int field {name} differs"
+        assert np.array_equal(got[name], want[name]), f"{ctx}: int field {name} differs: got {np.asarray(got[name]).tolist()} want {np.asarray(want[name]).tolist()}"
     for name in F64_FIELDS:
         if exact:
-            assert np.array_equal(got[name], want[name]), f"{ctx}: field {name} not bit-equal"
+            if not np.array_equal(got[name], want[name]):
+                g, w = np.asarray(got[name], dtype=np.float64), np.asarray(want[name], dtype=np.float64)
+                bad = np.argwhere(~((g == w) | (np.isnan(g) & np.isnan(w))))
+                raise AssertionError(f"{ctx}: field {name} not bit-equal at {bad[:6].tolist()} ({len(bad)} entries): got {g[tuple(bad[0])]!r} want {w[tuple(bad[0])]!r}")
         else:
             assert close64(got[name], want[name], tol), (
                 f"{ctx}: field {name} differs by {np.abs(np.asarray(got[name]) - np.asarray(want[name])).max():.3e}")
