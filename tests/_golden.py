@@ -53,7 +53,12 @@ def close64(a, b, tol=F64_TOL):
 def assert_tracks_match(got, want, ctx="", tol=F64_TOL, exact=False):
     assert len(got) == len(want), f"{ctx}: track count {len(got)} != {len(want)}"
     for name in INT_FIELDS:
-        assert np.array_equal(got[name], want[name]), f"{ctx}: int field {name} differs: got {np.asarray(got[name]).tolist()} want {np.asarray(want[name]).tolist()}"
+        if not np.array_equal(got[name], want[name]):
+            # (which tracks, and what else differs on them: one field of one track, a track's whole state, or the order of the list)
+            rows = sorted({int(i) for i in np.argwhere(np.asarray(got[name]) != np.asarray(want[name]))[:, 0]})
+            others = [n for n in INT_FIELDS + F64_FIELDS if n != name and not np.array_equal(np.asarray(got[n])[rows], np.asarray(want[n])[rows], equal_nan=n in F64_FIELDS)]
+            raise AssertionError(f"{ctx}: int field {name} differs on tracks {rows} of {len(want)}: got {np.asarray(got[name]).tolist()} want "
+                                 f"{np.asarray(want[name]).tolist()}; on those tracks these fields differ too: {others}")
     for name in F64_FIELDS:
         if exact:
             if not np.array_equal(got[name], want[name]):
