@@ -160,3 +160,25 @@ def test_bench_under_an_external_launcher_uses_the_given_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     js = [json.loads(ln) for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
     assert len(js) == 1 and js[0]["n_ranks_seen"] == 2 and js[0]["scenes_rank0"] == 32 and js[0]["gather_ok"]
+
+
+def test_bench_times_every_kernel_and_never_two_in_a_step():
+    """bench.profiled_kernels: the thin HIP-event sample of the timed region (an event pair holds the stream for 10-20 us: two
+    pairs in every 4th step cost 3.3 % of the headline, profiles/NOTEBOOK.md round 5).  Whatever the number of timed steps the
+    driver asks for: never two pairs in one step, k_track -- the roofline kernel -- most often, each of the other three kernels
+    of a step at least once, and from the default 40 steps on at most one step in five carries a pair."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for K in (8, 12, 20, 40, 80, 150, 1000):
+        seen = {}
+        for i in range(K):
+            pk = bench.profiled_kernels(i, K)
+            assert len(pk) <= 1, (K, i, pk)
+            for k in pk:
+                seen[k] = seen.get(k, 0) + 1
+        assert set(seen) == {0, *bench.OTHER_KERNELS}, (K, seen)          # K_TRACK + K_PREDICT, K_DBSCAN, K_POST
+        assert seen[0] >= max(seen[k] for k in bench.OTHER_KERNELS), (K, seen)
+        if K >= 40:   # (a short run samples more densely so that every kernel is seen; from the default 40 steps on: one step in five at most)
+            assert sum(seen.values()) <= K // 5, (K, seen)
