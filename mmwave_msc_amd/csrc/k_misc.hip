@@ -442,6 +442,22 @@ __global__ void k_reset(DevCfg cfg, DevState st, const int32_t *__restrict__ fla
     for (size_t e = g; e < tot; e += (size_t)gridDim.x * blockDim.x) st.order[e] = (int32_t)(e % cfg.t_cap);
 }
 
+#ifdef MMW_DIAG_POISON
+__global__ __launch_bounds__(1024) void k_poison_lds()
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(lds_raw);
+    for (int i = threadIdx.x; i < 160 * 1024 / 8; i += blockDim.x) w[i] = 0x7ff8dead7fffbeefULL;   // a NaN as fp64, huge as int32 / int64
+    __syncthreads();
+}
+void launch_poison(hipStream_t stream)
+{
+    static bool prepared = false;
+    if (!prepared) { (void)hipFuncSetAttribute((const void *)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); prepared = true; }
+    hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(1024), 160 * 1024, stream);   // (one workgroup per CU at a time: four rounds over 256 CUs)
+}
+#endif
+
 void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st)
 {
     static_assert(MMW_MAX_PTS_LIMIT <= 4 * 256, "k_normalize (and k_track / k_scene) take at most four rows per thread: a larger limit needs a round loop");

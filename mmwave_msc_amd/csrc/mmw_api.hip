@@ -391,10 +391,16 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
         if (d.fused) { d.dense_min_units = 0x7fffffff; d.side_worker = 0; }
     }
 
+#ifdef MMW_DIAG_POISON   // (diagnostic build, mmw_launch.hpp: what mmw_create does not initialise reads as NaN / huge, not as whatever was there)
+#define MMW_POISON_FRESH(ptr, bytes) (void)hipMemset((void *)(ptr), 0xFF, (bytes))
+#else
+#define MMW_POISON_FRESH(ptr, bytes) ((void)0)
+#endif
 #define ALLOC(ptr, bytes)                                                                                   \
     do {                                                                                                    \
         hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                                \
         if (e_ != hipSuccess) { int rc = fail(nullptr, MMW_E_HIP, "hipMalloc(%zu) -> %s", (size_t)(bytes), hipGetErrorString(e_)); mmw_destroy(c); return rc; } \
+        MMW_POISON_FRESH(ptr, bytes);                                                                       \
     } while (0)
     const size_t S = (size_t)n_scenes;
     ALLOC(c->st.hdr, S * sizeof(SceneHdr));
