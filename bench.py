@@ -687,6 +687,7 @@ def main():
         # command and scripts/make_traffic_json.py records the source hash of the build they ran on.  The number is quoted
         # only when that hash is the running library's (mmw_version()); for any other build the line says null.
         traffic, traffic_src = None, "null: no PMC passes of this build (profiles/traffic.json absent or from other sources)"
+        issue = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             try:
@@ -705,6 +706,19 @@ def main():
                 elif tj.get("src_hash") != lib_hash:
                     traffic_src = (f"null: profiles/traffic.json was collected on src:{tj.get('src_hash')}, this library is src:{lib_hash} "
                                    f"(run scripts/gpu_round.sh pmc + scripts/make_traffic_json.py on this build)")
+                # the third roof: vector-instruction ISSUE.  SQ_INSTS_VALU per launch (its own --pmc pass on this build, scripts/pmc_sq.sh)
+                # over this run's timed duration, against the rate at which the chip issues fp64 vector instructions by wall clock
+                # (scripts/ubench/ubench_f64: 2.05 ns per wave instruction and SIMD) -- for kernels that are neither bandwidth- nor
+                # flop-bound this is the roof that says how much is left (an upper bound: a third of the instructions are 32-bit)
+                vi, ceil = tj.get("valu_insts_per_launch", {}).get(key), tj.get("fp64_issue_ceiling")
+                if tj.get("src_hash") == lib_hash and tj.get("population", "mixed") == args.population and isinstance(vi, dict) and ceil:
+                    peak_gips = ceil["simds"] / ceil["ns_per_wave_instruction_and_simd"]   # G wave-instructions / s
+                    issue = {"bound": "valu_issue_fp64", "unit": "G wave-instructions/s", "peak": round(peak_gips, 1), "kernels": {}}
+                    for kid, nm in ((_lib.K_TRACK, "k_track"), (_lib.K_POST, "k_post"), (_lib.K_PREDICT, "k_predict")):
+                        if nm in vi and step_ms[kid] > 0:
+                            a = vi[nm] / (step_ms[kid] * 1e-3) / 1e9
+                            issue["kernels"][nm] = {"valu_insts_per_launch": vi[nm], "achieved": round(a, 1), "frac": round(a / peak_gips, 4)}
+                    issue["source"] = tj["valu_insts_per_launch"].get("source", "") + "; ceiling: " + ceil.get("source", "")
             except Exception:
                 traffic = None
         # B_trk = 64N + 4N + 4U + 2*T*1200 + 64*U_new per scene-frame, with the run's own means
@@ -748,6 +762,7 @@ def main():
             "roofline_survey_bytes": {"bound": "hbm", "bytes_per_scene_frame": round(b_trk, 1),
                                       "achieved": round(b_trk * S / (el / K) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(b_trk * S / (el / K) / 1e9 / HBM_PEAK_GBS, 6)},
+            "roofline_issue": issue,
             # the other roof SURVEY.md §8(d) names: fp64 vector arithmetic of k_track / of the whole step
             "roofline_valu": {"bound": "valu_fp64", "kernel": "k_track", "flop_per_launch": round(flop_track, 1),
                               "achieved": round(flop_track / (step_ms[_lib.K_TRACK] * 1e-3) / 1e12, 3) if step_ms[_lib.K_TRACK] > 0 else None,

@@ -35,4 +35,10 @@ res = {"4096x512x8": table(big), "512x512x8": table(small),
                 "entry) but, alone on the chip, find nothing to claim and leave after their idle polls -- the DBSCAN bytes they move in the benchmarked "
                 "schedule are k_post's / k_dbscan_big's here; the step's total does not depend on who moves them, and k_track, the roofline kernel, "
                 "runs the same code with or without their company."}
+# (optional third argument: a JSON file {"4096x512x8": {"k_track": N, ...}} of SQ_INSTS_VALU per launch from scripts/pmc_sq.sh sq1 on the
+#  same build -- bench.py's roofline_issue; the measured fp64 issue ceiling of the chip travels with it)
+if len(sys.argv) > 3:
+    res["valu_insts_per_launch"] = json.load(open(sys.argv[3]))
+    res["fp64_issue_ceiling"] = {"ns_per_wave_instruction_and_simd": 2.05, "simds": 1024,
+                                 "source": "scripts/ubench/ubench_f64 (profiles/r05a_ubench_f64.txt): independent v_fma_f64 chains, 8 waves per SIMD, wall clock"}
 print(json.dumps(res, indent=1))
