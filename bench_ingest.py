@@ -92,7 +92,7 @@ class HostFeed:
         else:
             k = f & 1
             if self.form == "tlv":
-                sb.normalize_tlv_dev(self.buf[b].data_ptr(), self.tlv_off.data_ptr(), self.uart_cfg, self.norm[k].data_ptr(), self.n_out[k].data_ptr())
+                sb.normalize_tlv_dev(self.buf[b].data_ptr(), self.buf[b].numel() * self.buf[b].element_size(), self.tlv_off.data_ptr(), self.uart_cfg, self.norm[k].data_ptr(), self.n_out[k].data_ptr())
             else:
                 sb.normalize_dev(self.buf[b].data_ptr(), self.d_cnt[f].data_ptr(), self.norm[k].data_ptr(), self.n_out[k].data_ptr(), f32=True)
             sb.step_dev(self.norm[k].data_ptr(), self.n_out[k].data_ptr(), self.d_dt[f].data_ptr(), a.data_ptr(), l.data_ptr(), n.data_ptr())

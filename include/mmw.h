@@ -184,7 +184,12 @@ int mmw_get_errors(mmw_ctx *ctx, int32_t *err_bits);
 /* Clears the given error bits of the scenes whose flag is non-zero (host array of n_scenes words; NULL = every scene) and
  * nothing else: for errors that leave the scene's state valid -- a caller that catches the reference's ValueError
  * (MMW_E_NONFINITE) and carries on sees the same state the reference is in, and the error comes back on the next frame if
- * it still applies. */
+ * it still applies.  ONE flavour of MMW_E_NONFINITE does NOT leave the reference's state: with mmw_config.seek_inner, a
+ * non-finite doppler / peakVal of an ASSIGNED point reaches the inner apply_DBscan (Tracking.py:440), whose ValueError leaves
+ * the reference's track() in the middle of _associate_points_to_tracks -- no further track associated, no _maintain_tracks, no
+ * _update_all, no add_frame --, while here only that track's inner clustering is skipped and the frame completes (db_n is then
+ * NOT MMW_DB_RAISED: the frame's own call did not raise).  Like MMW_E_CAPACITY such a scene differs from the reference from
+ * then on: reset it (mmw_reset_scenes), do not clear the bit and carry on. */
 #define MMW_ERRBIT_SINGULAR 1
 #define MMW_ERRBIT_DIVZERO 2
 #define MMW_ERRBIT_CAPACITY 4
@@ -221,6 +226,10 @@ int mmw_synchronize(mmw_ctx *ctx);                                   /* sync */
  * communicator's stream, a torch kernel reading mmw_features' rows.  hip_stream: a raw hipStream_t; NULL =
  * the legacy default stream (what torch reports as current_stream().cuda_stream == 0), MMW_STREAM_LEGACY the same. */
 int mmw_stream_wait(mmw_ctx *ctx, void *hip_stream);
+/* The other direction: whatever the context queues on ITS stream after this call starts only when everything queued on
+ * `hip_stream` so far has finished.  For device buffers the context is about to REWRITE while a consumer on another stream may
+ * still be reading them (the track table of the previous all-gather: write-after-read). */
+int mmw_wait_stream(mmw_ctx *ctx, void *hip_stream);
 int mmw_get_dims(const mmw_ctx *ctx, int32_t *n_scenes, int32_t *max_pts, int32_t *track_cap, int32_t *ring, int32_t *ring_rows);
 
 /* Thin device-memory helpers so a ctypes host needs no HIP binding. */
@@ -449,10 +458,15 @@ int mmw_parse_uart(const uint8_t *buf, size_t len, const mmw_uart_cfg *cfg, doub
  * buffer; tlv_offset[S] (dev) = byte offset into `packets` of each scene's TLV body (2-byte aligned), < 0 = no detected-points
  * TLV this frame (n_out = 0: mmw_step skips the scene's frame, offline_main.py:56); cfg (host) as for mmw_parse_uart;
  * pts[S][max_pts][8] / n_out[S] (dev) as mmw_normalize writes them -- bit-equal to mmw_parse_uart + mmw_normalize on the same
- * bytes.  12 bytes per object cross PCIe instead of 20 (fp32 raw rows) or 40 (fp64).  Objects beyond max_pts are not read. */
+ * bytes.  12 bytes per object cross PCIe instead of 20 (fp32 raw rows) or 40 (fp64).  packets_bytes = the size of `packets`:
+ * nothing outside it is read.  A body that does not lie inside it on a 2-byte boundary with every object it announces, or that
+ * announces more than max_pts objects (mmw_parse_uart returns MMW_E_ARG for those bytes), gives n_out = MMW_BAD_FRAME: the
+ * mmw_step that follows raises the scene's bad-count bit (MMW_E_ARG), the other scenes are unaffected. */
+#define MMW_BAD_FRAME (-3)
 int mmw_find_tlv(const uint8_t *buf, size_t len, int64_t *body_offset, int32_t *n_obj, uint32_t *frame_number, size_t *packet_start,
                  size_t *packet_len);
-int mmw_normalize_tlv(mmw_ctx *ctx, const uint8_t *packets, const int64_t *tlv_offset, const mmw_uart_cfg *cfg, double *pts, int32_t *n_out);
+int mmw_normalize_tlv(mmw_ctx *ctx, const uint8_t *packets, size_t packets_bytes, const int64_t *tlv_offset, const mmw_uart_cfg *cfg, double *pts,
+                      int32_t *n_out);
 
 /* Work counters accumulated by the kernels since the last reset (sync):
  * [0] k_track algorithmic bytes  [1] k_dbscan algorithmic bytes  [2] scene-frames stepped

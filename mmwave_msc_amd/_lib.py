@@ -25,6 +25,7 @@ ERRBIT_SINGULAR, ERRBIT_DIVZERO, ERRBIT_CAPACITY, ERRBIT_BADCOUNT, ERRBIT_NONFIN
 K_TRACK, K_DBSCAN, K_FEATURES, K_NORMALIZE, K_TABLE, K_PREDICT, K_POST = range(7)
 
 EMPTY_FRAME = -1   # MMW_EMPTY_FRAME (include/mmw.h)
+BAD_FRAME = -3     # MMW_BAD_FRAME: n_out of mmw_normalize_tlv for a TLV body it refused to decode
 
 EXPORTS = [
     "mmw_config_default", "mmw_create", "mmw_destroy", "mmw_last_error", "mmw_reset", "mmw_pop_frame", "mmw_set_stream",
@@ -36,7 +37,7 @@ EXPORTS = [
     "mmw_parse_uart", "mmw_features_async", "mmw_features_wait", "mmw_set_keypoints_uid", "mmw_get_inner",
     "mmw_set_batch_size", "mmw_set_batch_frame", "mmw_mars_conv_split", "mmw_mars_dense1_split", "mmw_diag_queue", "mmw_set_chain_side_stream", "mmw_side_workers", "mmw_step_kind", "mmw_streams_concurrent", "mmw_reset_scenes", "mmw_get_errors",
     "mmw_kalman_layout", "mmw_step_f32", "mmw_normalize_f32", "mmw_frame_host", "mmw_mars_head_small", "mmw_mars_range_fixup",
-    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors", "mmw_stream_wait", "mmw_find_tlv", "mmw_normalize_tlv",
+    "mmw_attach_posture", "mmw_frame_posture_host", "mmw_clear_errors", "mmw_stream_wait", "mmw_wait_stream", "mmw_find_tlv", "mmw_normalize_tlv",
 ]
 
 
@@ -209,6 +210,7 @@ def load():
         "mmw_pop_frame": (C.c_int, [vp, vp]),
         "mmw_synchronize": (C.c_int, [vp]),
         "mmw_stream_wait": (C.c_int, [vp, vp]),
+        "mmw_wait_stream": (C.c_int, [vp, vp]),
         "mmw_get_dims": (C.c_int, [vp, i32p, i32p, i32p, i32p, i32p]),
         "mmw_dev_alloc": (C.c_int, [vp, C.c_size_t, vpp]),
         "mmw_dev_free": (C.c_int, [vp, vp]),
@@ -262,7 +264,7 @@ def load():
         "mmw_mars_head_small": (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, i32, i32, i32]),
         "mmw_parse_uart": (C.c_int, [vp, C.c_size_t, vp, vp, vp, i32, vp, vp, vp, vp]),
         "mmw_find_tlv": (C.c_int, [vp, C.c_size_t, vp, vp, vp, vp, vp]),
-        "mmw_normalize_tlv": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+        "mmw_normalize_tlv": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp, vp]),
         "mmw_format_frames": (C.c_int, [vp, vp, vp, vp, vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)

@@ -119,6 +119,14 @@ class SceneBatch:
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         self._chk(self.L.mmw_stream_wait(self.h, int(s.cuda_stream)))
 
+    def wait_stream(self, stream=None):
+        """mmw_wait_stream, the other direction: what this context queues from now on starts only when everything queued on
+        `stream` (default torch's current one) so far has finished -- before the context REWRITES a device buffer a consumer on
+        that stream may still be reading (the track table of the previous all-gather)."""
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._chk(self.L.mmw_wait_stream(self.h, int(s.cuda_stream)))
+
     def set_chain_side_stream(self, on: bool):
         """Small-cloud DBSCAN workers beside the association kernel (second stream) on / off, from the next step on."""
         self._chk(self.L.mmw_set_chain_side_stream(self.h, 1 if on else 0))
@@ -217,12 +225,13 @@ class SceneBatch:
         fn = self.L.mmw_normalize_f32 if f32 else self.L.mmw_normalize
         self._chk(fn(self.h, raw_ptr, n_raw_ptr, pts_ptr, n_out_ptr))
 
-    def normalize_tlv_dev(self, packets_ptr, tlv_offset_ptr, uart_cfg, pts_ptr, n_out_ptr):
+    def normalize_tlv_dev(self, packets_ptr, packets_bytes, tlv_offset_ptr, uart_cfg, pts_ptr, n_out_ptr):
         """mmw_normalize_tlv: the radar's own wire format (detected-points TLV bodies, 12 B per object) decoded as ReadIWR14xx.read
         does (ReadDataIWR1443.py:153-171) and normalised (Utils.normalize_data) in one kernel: packets (device bytes),
         tlv_offset[S] (device int64: byte offset of each scene's TLV body, < 0 = none), uart_cfg (`_lib.MmwUartCfg`, host)
-        -> pts[S][max_pts][8] fp64, n_out[S] (device)."""
-        self._chk(self.L.mmw_normalize_tlv(self.h, packets_ptr, tlv_offset_ptr, C.byref(uart_cfg), pts_ptr, n_out_ptr))
+        -> pts[S][max_pts][8] fp64, n_out[S] (device).  Nothing outside packets[0 .. packets_bytes) is read; a body that does not
+        fit, or announces more than max_pts objects, gives n_out = _lib.BAD_FRAME (the next step raises the scene's bad count)."""
+        self._chk(self.L.mmw_normalize_tlv(self.h, packets_ptr, int(packets_bytes), tlv_offset_ptr, C.byref(uart_cfg), pts_ptr, n_out_ptr))
 
     def step_host(self, pts: np.ndarray, n: np.ndarray, dt: np.ndarray, raise_nonfinite: bool = True, check: bool = True):
         """Host convenience (H2D + step + D2H).  Returns (assoc[S,NP], labels[S,UM], db_n[S]).  raise_nonfinite=False: a scene
@@ -289,8 +298,9 @@ class SceneBatch:
                 out["labels"].ctypes.data if want_labels else None, out["db_n"].ctypes.data, out["n_tracks"].ctypes.data)
         if posture:   # ... and estimate_posture with the attached model behind the step (mmw_frame_posture_host)
             rows = C.c_int32(0)
-            self._chk(self.L.mmw_frame_posture_host(*args, C.byref(rows)))
-            out["posture_rows"] = int(rows.value)
+            rc = self.L.mmw_frame_posture_host(*args, C.byref(rows))
+            out["posture_rows"] = int(rows.value)   # (written before the first scene error is reported: a caller that catches the
+            self._chk(rc)                           #  reference's ValueError must still see that estimate_posture ran on the device)
         else:
             self._chk(self.L.mmw_frame_host(*args))
         return out

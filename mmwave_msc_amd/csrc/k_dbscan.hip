@@ -842,6 +842,12 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
     DSTAMP(2);
     // ---- BallTree.query_radius(X, eps) for every point (_binary_tree.pxi.tp:1903-1980) ----
     const int lbits = n_levels - 1;
+    // NearestNeighbors._fit with algorithm="auto" (sklearn/neighbors/_base.py:622-633): DBSCAN leaves n_neighbors at its default
+    // of 5, and `n_neighbors >= n_samples // 2` answers clouds of 1 .. 11 points by BRUTE FORCE -- the exact pairwise metric
+    // `<= eps` (_base.py:1054-1081, 1221-1250), no tree: the root (the only node of so small a cloud) is a TEST leaf for every
+    // query, never PRUNE, never taken whole.  (Reachable with DB_MIN_SAMPLES_MIN <= 11; the no-core-point screens bound a
+    // superset of either neighbourhood.)
+    const bool brute = (U >> 1) <= kSkNeighbors;  // uniform
     // The leaf tests -- "is metric(p, q) <= eps" for every point q of a leaf some query of the wave reached: nine tenths of
     // this phase, 14 fp64 operations each -- go through an fp32 SCREEN first: the same formula on the fp32 copies, two
     // candidates per packed instruction, decides every pair whose fp32 value is further than E from eps; the few in between
@@ -916,7 +922,8 @@ __device__ __forceinline__ int dbscan_core(const DevCfg &cfg, const DbLds &L, co
                     const double rad = __longlong_as_double((long long)L.nrad[node]);
                     const double t = d - rad;
                     const double lb = t > 0 ? t : 0, ub = d + rad;
-                    if (lb > eps) state = 0;
+                    if (brute) state = 2;   // (one node: level == lbits == 0)
+                    else if (lb > eps) state = 0;
                     else if (ub <= eps) state = 1;
                     else if (level == lbits) state = 2;
                     else state = 3;

@@ -100,23 +100,30 @@ __global__ __launch_bounds__(256) void k_normalize(DevCfg cfg, const RT *__restr
 // indices above numDopplerBins / 2 - 1 get 65535 subtracted in int16, doppler = idx * dopplerResolutionMps, x, y, z / 2^Q) and
 // normalised in the same registers.  packets: the bytes as they arrived (any 2-byte alignment of a body); tlv_offset[s] = byte
 // offset of scene s's TLV BODY, < 0 = no detected-points TLV this frame (n_out = 0: the scene's frame is skipped).  The host only
-// finds magic words (mmw_find_tlv).  numObj beyond max_pts is clamped (mmw_find_tlv reports the count: the caller checks).
+// finds magic words (mmw_find_tlv).  Nothing outside packets[0 .. packets_bytes) is read: a body that does not lie inside it on a
+// 2-byte boundary with all the objects it announces, or that announces more than max_pts objects (mmw_parse_uart: MMW_E_ARG),
+// gives n_out = MMW_BAD_FRAME -- the scene's ERR_BADCOUNT in the mmw_step that follows.
 template <int R>
-__global__ __launch_bounds__(256) void k_normalize_tlv(DevCfg cfg, const uint8_t *__restrict__ packets, const long long *__restrict__ tlv_offset,
-                                                       double half_bins, double doppler_res, double *__restrict__ out,
-                                                       int32_t *__restrict__ n_out)
+__global__ __launch_bounds__(256) void k_normalize_tlv(DevCfg cfg, const uint8_t *__restrict__ packets, long long packets_bytes,
+                                                       const long long *__restrict__ tlv_offset, double half_bins, double doppler_res,
+                                                       double *__restrict__ out, int32_t *__restrict__ n_out)
 {
     __shared__ int wcnt[R * 4];
     const int s = blockIdx.x, tid = threadIdx.x;
     const long long off = tlv_offset[s];
     int n = 0;
+    bool bad = false;
     double q = 1.0;
     const unsigned short *body = nullptr;
     if (off >= 0) {   // uniform
-        body = reinterpret_cast<const unsigned short *>(packets + off);
-        const int num = body[0], qfmt = body[1];
-        n = min(num, cfg.max_pts);
-        q = ldexp(1.0, qfmt);
+        bad = (off & 1) != 0 || off + 4 > packets_bytes;
+        if (!bad) {
+            body = reinterpret_cast<const unsigned short *>(packets + off);
+            const int num = body[0], qfmt = body[1];
+            bad = num > cfg.max_pts || off + 4 + 12LL * num > packets_bytes;
+            n = bad ? 0 : num;
+            q = ldexp(1.0, qfmt);
+        }
     }
     double v[R][5];
 #pragma unroll
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256) void k_normalize_tlv(DevCfg cfg, const uint8_t
         v[r][4] = (double)(short)w[2];
     }
     normalize_rows<R>(cfg, s, n, v, out, n_out, wcnt);
+    if (bad && tid == 0) n_out[s] = -3;   // MMW_BAD_FRAME (the same thread wrote the 0 above)
 }
 
 // ---------------------------------------------------------------------------
@@ -467,11 +475,11 @@ void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_
     else { if (r <= 1) MMW_NORM(double, 1); else if (r == 2) MMW_NORM(double, 2); else MMW_NORM(double, 4); }
 #undef MMW_NORM
 }
-void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, const long long *tlv_offset, double half_bins, double doppler_res, double *out,
-                          int32_t *n_out, hipStream_t st)
+void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, long long packets_bytes, const long long *tlv_offset, double half_bins,
+                          double doppler_res, double *out, int32_t *n_out, hipStream_t st)
 {
     const int r = (cfg.max_pts + 255) / 256;
-#define MMW_NORM_TLV(R) mmw_launch(k_normalize_tlv<R>, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, packets, tlv_offset, half_bins, doppler_res, out, n_out)
+#define MMW_NORM_TLV(R) mmw_launch(k_normalize_tlv<R>, dim3(cfg.n_scenes), dim3(256), 0, st, cfg, packets, packets_bytes, tlv_offset, half_bins, doppler_res, out, n_out)
     if (r <= 1) MMW_NORM_TLV(1); else if (r == 2) MMW_NORM_TLV(2); else MMW_NORM_TLV(4);
 #undef MMW_NORM_TLV
 }

@@ -43,8 +43,8 @@ void launch_dbscan_huge(const DevCfg &cfg, const DevState &st, int UM, int u_bou
 void launch_dbscan_only(const DevCfg &cfg, const DevState &st, int UM, const double *pts, const int32_t *n, int max_n, double eps, int min_samples,
                         int32_t *labels, int32_t *ncl, hipStream_t stream);
 void launch_normalize(const DevCfg &cfg, const void *raw, bool f32, const int32_t *n_raw, double *out, int32_t *n_out, hipStream_t st);
-void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, const long long *tlv_offset, double half_bins, double doppler_res, double *out,
-                          int32_t *n_out, hipStream_t st);
+void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, long long packets_bytes, const long long *tlv_offset, double half_bins,
+                          double doppler_res, double *out, int32_t *n_out, hipStream_t st);
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st);
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
                      hipStream_t st, const int32_t *n_in = nullptr, int32_t *total_out = nullptr);
@@ -101,6 +101,7 @@ struct mmw_ctx {
     int32_t *h_rows = nullptr;        // pinned [kTickets]: eligible-track totals of the outstanding mmw_features_async calls
     hipEvent_t feat_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t handoff_ev = nullptr;     // mmw_stream_wait: recorded on the context's stream, waited for by the caller's
+    hipEvent_t handback_ev = nullptr;    // mmw_wait_stream: recorded on the caller's stream, waited for by the context's
     int32_t feat_cap[4] = {0, 0, 0, 0};
     float *d_posture = nullptr;
     unsigned long long *d_stats = nullptr;
@@ -309,6 +310,10 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (n_scenes < 1 || max_pts < 1 || max_pts > MMW_MAX_PTS_LIMIT) return fail(nullptr, MMW_E_ARG, "mmw_create: n_scenes=%d max_pts=%d out of range (max_pts <= %d)", n_scenes, max_pts, MMW_MAX_PTS_LIMIT);
     if (cfg->fb_frames_batch < 0 || cfg->fb_frames_batch + 1 > MMW_RING_MAX) return fail(nullptr, MMW_E_ARG, "FB_FRAMES_BATCH must be in [0,%d]", MMW_RING_MAX - 1);
     if (cfg->dim_x != 9 && cfg->dim_x != 6) return fail(nullptr, MMW_E_ARG, "dim_x must be 9 (CONST_ACC_MODEL) or 6 (CONST_VEL_MODEL)");
+    // sklearn's parameter validation (DBSCAN._parameter_constraints, cluster/_dbscan.py:330-342: eps in (0, inf), min_samples an
+    // integer >= 1): with anything else EVERY apply_DBscan call of the reference raises InvalidParameterError -- refused here
+    if (!(cfg->db_eps > 0.0) || cfg->db_min_samples < 1 || (cfg->seek_inner && !(cfg->db_inner_eps > 0.0)))
+        return fail(nullptr, MMW_E_ARG, "DB_EPS%s must be > 0 and DB_MIN_SAMPLES_MIN >= 1 (sklearn's DBSCAN refuses anything else)", cfg->seek_inner ? " / DB_INNER_EPS" : "");
     const int ring = cfg->fb_frames_batch + 1;
     // (apply_DBscan has no size limit, Utils.py:250-291; here a cloud is at most the ring: MMW_RING_MAX frames of MMW_MAX_PTS_LIMIT
     //  points.  Up to 1920 points its BallTree lives in the LDS; larger ones -- only contexts with ring * max_pts > 1920 can
@@ -497,6 +502,7 @@ int mmw_destroy(mmw_ctx *c)
     for (void *p : pinned) if (p) hipHostFree(p);
     for (int k = 0; k < kTickets; k++) if (c->feat_ev[k]) hipEventDestroy(c->feat_ev[k]);
     if (c->handoff_ev) hipEventDestroy(c->handoff_ev);
+    if (c->handback_ev) hipEventDestroy(c->handback_ev);
     if (c->h_rows) hipHostFree(c->h_rows);
     if (c->side_stream) hipStreamDestroy(c->side_stream);
     if (c->side_gate) hipEventDestroy(c->side_gate);
@@ -658,6 +664,18 @@ int mmw_stream_wait(mmw_ctx *c, void *hip_stream)
     return MMW_OK;
 }
 
+int mmw_wait_stream(mmw_ctx *c, void *hip_stream)
+{
+    if (!c) return MMW_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t other = hip_stream == MMW_STREAM_LEGACY ? hipStreamLegacy : (hipStream_t)hip_stream;
+    if (other == c->stream) return MMW_OK;
+    if (!c->handback_ev) HIPCHK(c, hipEventCreateWithFlags(&c->handback_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->handback_ev, other));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->handback_ev, 0));
+    return MMW_OK;
+}
+
 int mmw_get_dims(const mmw_ctx *c, int32_t *n_scenes, int32_t *max_pts, int32_t *track_cap, int32_t *ring, int32_t *ring_rows)
 {
     if (!c) return MMW_E_ARG;
@@ -715,7 +733,8 @@ static int normalize_impl(mmw_ctx *c, const void *raw, bool f32, const int32_t *
 int mmw_normalize(mmw_ctx *c, const double *raw, const int32_t *n_raw, double *pts, int32_t *n_out) { return normalize_impl(c, raw, false, n_raw, pts, n_out); }
 int mmw_normalize_f32(mmw_ctx *c, const float *raw, const int32_t *n_raw, double *pts, int32_t *n_out) { return normalize_impl(c, raw, true, n_raw, pts, n_out); }
 
-int mmw_normalize_tlv(mmw_ctx *c, const uint8_t *packets, const int64_t *tlv_offset, const mmw_uart_cfg *cfg, double *pts, int32_t *n_out)
+int mmw_normalize_tlv(mmw_ctx *c, const uint8_t *packets, size_t packets_bytes, const int64_t *tlv_offset, const mmw_uart_cfg *cfg, double *pts,
+                      int32_t *n_out)
 {
     if (!c || !packets || !tlv_offset || !cfg || !pts || !n_out) return fail(c, MMW_E_ARG, "mmw_normalize_tlv: null pointer");
     if (((uintptr_t)pts & 15) != 0 || ((uintptr_t)packets & 1) != 0) return fail(c, MMW_E_ARG, "mmw_normalize_tlv: pts must be 16-byte aligned, packets 2-byte aligned");
@@ -723,8 +742,8 @@ int mmw_normalize_tlv(mmw_ctx *c, const uint8_t *packets, const int64_t *tlv_off
     EventPair ep;
     prof_arm(c, MMW_K_NORMALIZE, ep);
     static_assert(sizeof(long long) == sizeof(int64_t), "tlv offsets");
-    launch_normalize_tlv(c->dc, packets, reinterpret_cast<const long long *>(tlv_offset), cfg->num_doppler_bins / 2.0 - 1, cfg->doppler_resolution_mps, pts,
-                         n_out, c->stream);
+    launch_normalize_tlv(c->dc, packets, (long long)packets_bytes, reinterpret_cast<const long long *>(tlv_offset), cfg->num_doppler_bins / 2.0 - 1,
+                         cfg->doppler_resolution_mps, pts, n_out, c->stream);
     prof_armed_done(c, ep);
     HIPCHK(c, hipGetLastError());
     return MMW_OK;
@@ -746,7 +765,6 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
     if (((uintptr_t)pts & 15) != 0) return fail(c, MMW_E_ARG, "mmw_step: pts must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
     EventPair ep;
-    c->epoch++;
     // a cloud is the unassigned part of the ring's frames: in the first steps after a reset it cannot be larger than the
     // frames pushed so far, and the large-cloud launches are carved (LDS per workgroup -> workgroups per CU) for that bound
     if (c->ring_frames_bound < c->dc.ring) c->ring_frames_bound++;
@@ -774,6 +792,12 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
             HIPCHK(c, hipEventRecord(c->side_gate, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_gate, 0));
         }
+    }
+    // the step number of the queue protocol counts COMMITTED steps: a step that left above (probe, gate event) has launched no
+    // k_post, so no stop epoch was raised for it -- counting it would leave q[kQStop] one behind for good, and every later k_chain
+    // would poll to its idle limit without ever claiming
+    c->epoch++;
+    if (c->dc.side_worker) {
         launch_chain(c->dc, c->st, c->UM, u_bound, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
     }
     // TrackBuffer.track (Tracking.py:683-703) = four launches on one stream:
@@ -960,6 +984,7 @@ int mmw_dbscan(mmw_ctx *c, const double *pts, const int32_t *n, int32_t max_n, d
 {
     if (!c || !pts || !n || !labels) return fail(c, MMW_E_ARG, "mmw_dbscan: null pointer");
     if (max_n < 1 || max_n > c->UM) return fail(c, MMW_E_ARG, "mmw_dbscan: max_n=%d must be in [1, ring*max_pts=%d]", max_n, c->UM);
+    if (!(eps > 0.0) || min_samples < 1) return fail(c, MMW_E_ARG, "mmw_dbscan: eps must be > 0 and min_samples >= 1 (sklearn's DBSCAN refuses anything else)");
     HIPCHK(c, hipSetDevice(c->device));
     launch_dbscan_only(c->dc, c->st, c->UM, pts, n, max_n, eps, min_samples, labels, n_clusters, c->stream);
     HIPCHK(c, hipGetLastError());

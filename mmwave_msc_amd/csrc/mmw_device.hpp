@@ -14,6 +14,8 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kGateChunk = 16;      // tracks whose gate matrices sit in LDS at once
 constexpr int kGateRec = 44;        // doubles per gate record: Ci[36] | log|det| | predicted position hx[6] | pad
 constexpr int kLeafSize = 30;       // sklearn BallTree default leaf_size (DBSCAN passes it through)
+constexpr int kSkNeighbors = 5;     // NearestNeighbors' default n_neighbors, left alone by DBSCAN.fit (sklearn/cluster/_dbscan.py:410-418):
+                                    // clouds of n // 2 <= 5 points are answered by brute force, not by the tree (neighbors/_base.py:622-633)
 constexpr int kMaxLeaves = 32;      // n <= 1920 -> <= 63 nodes -> <= 32 leaves
 constexpr int kBigCloudMax = 30 * 64;  // = 1920: the largest cloud whose BallTree carve-up fits the LDS; larger ones (work list 2) run on slabs in global memory
 constexpr int kMaxNodes = 63;

@@ -127,17 +127,22 @@ class ShardedTracker:
         if self.pipe is not None:
             self.pipe.drain()
 
-    def gather_table(self, slots: int, force_collective: bool = False) -> torch.Tensor:
+    def gather_table(self, slots: int, force_collective: bool = False, reuse_out: bool = False) -> torch.Tensor:
         """Every rank's track summaries (`slots` per scene, scene ids global) all-gathered, ordered by global scene id.
-        The table is written on the CONTEXT's stream (k_table); the collective runs on torch's current stream: the hand-over is an
-        event (`mmw_stream_wait`), whatever stream either side is on -- no host wait, no reliance on the caller having bound the
-        context to torch's stream.  Row counts are exchanged once per table shape and cached, the collective's buffers reused."""
+        The table is written on the CONTEXT's stream (k_table); the collective runs on torch's current stream.  Both directions
+        of the hand-over are events, whatever stream either side is on -- no host wait, no reliance on the caller having bound
+        the context to torch's stream: the collective waits for k_table (`mmw_stream_wait`), and the NEXT call's k_table waits
+        for the previous collective (`mmw_wait_stream`: it rewrites the table -- and this call the pad / output buffers -- the
+        collective read).  Row counts are exchanged once per table shape and cached, the collective's buffers reused; the
+        result is a fresh tensor unless `reuse_out` (then it is the cached output buffer, valid until the next call)."""
         slots = int(slots)
         if hasattr(self.sb, "track_table_dev") and getattr(self.sb, "h", None) is not None:
             dev = torch.device("cuda", self.sb.device)
             if self._table is None or self._table.shape[0] != self.S * slots:
                 self._table = torch.zeros((self.S * slots, SUMMARY_WORDS), dtype=torch.int32, device=dev)
                 self._gather = {}
+            if hasattr(self.sb, "wait_stream"):
+                self.sb.wait_stream(torch.cuda.current_stream(dev))   # (write-after-read: the previous gather still reads _table)
             self.sb.track_table_dev(self._table.data_ptr(), slots, scene_base=self.lo)
             if self.world > 1 and dist.get_backend() != "nccl":   # (gloo: host tensors; the table must have been written first)
                 self.sb.synchronize()
@@ -148,7 +153,7 @@ class ShardedTracker:
         else:
             local = summaries_to_tensor(self.sb.track_table_host(slots, scene_base=self.lo))
         if self.world == 1 and not force_collective:
-            return local
+            return local.clone() if (local is self._table and not reuse_out) else local
         g = self._gather.get(slots) if isinstance(getattr(self, "_gather", None), dict) else None
         if g is None or g["device"] != local.device:
             counts = exchange_row_counts(local.shape[0], local.device)
@@ -159,7 +164,10 @@ class ShardedTracker:
             if not isinstance(getattr(self, "_gather", None), dict):
                 self._gather = {}
             self._gather[slots] = g
-        return all_gather_tables(local, counts=g["counts"], out=g["out"], pad=g["pad"], force_collective=force_collective)
+        res = all_gather_tables(local, counts=g["counts"], out=g["out"], pad=g["pad"], force_collective=force_collective)
+        if not reuse_out and res.data_ptr() == g["out"].data_ptr():
+            res = res.clone()     # (a table kept from one call must not change under the caller at the next)
+        return res
 
     def close(self):
         if self.pipe is not None:

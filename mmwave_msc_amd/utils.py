@@ -132,10 +132,20 @@ def altered_EuclideanDist(p1, p2):
 
 def dbscan_labels(pointcloud, eps=None, min_samples=None) -> np.ndarray:
     """sklearn-compatible labels of the reference's DBSCAN call (Utils.py:272-278)."""
-    pc = np.asarray(pointcloud, dtype=np.float64).reshape(-1, 8)
+    pc = np.asarray(pointcloud, dtype=np.float64)
+    eps = const.DB_EPS if eps is None else eps
+    min_samples = const.DB_MIN_SAMPLES_MIN if min_samples is None else min_samples
+    # sklearn's own refusals, as ValueError (InvalidParameterError is one): parameters first (_validate_params), then the array
+    if not (float(eps) > 0.0):
+        raise ValueError(f"The 'eps' parameter of DBSCAN must be a float in the range (0.0, inf). Got {eps!r} instead.")
+    if int(min_samples) != min_samples or min_samples < 1:
+        raise ValueError(f"The 'min_samples' parameter of DBSCAN must be an int in the range [1, inf). Got {min_samples!r} instead.")
+    if pc.ndim != 2:
+        raise ValueError(f"Expected 2D array, got {pc.ndim}D array instead")
+    if pc.shape[0] == 0:
+        raise ValueError(f"Found array with 0 sample(s) (shape={pc.shape}) while a minimum of 1 is required by DBSCAN.")
+    pc = pc.reshape(-1, 8)
     n = pc.shape[0]
-    if n == 0:
-        return np.zeros(0, dtype=np.int32)
     sb = _util_ctx()
     if n > sb.UM:
         sb = _util_ctx(fb_frames_batch=3)   # capacity only: the largest cloud a context can hold (4 frames of 1024 points)
@@ -143,9 +153,7 @@ def dbscan_labels(pointcloud, eps=None, min_samples=None) -> np.ndarray:
         raise ValueError(f"apply_DBscan on {n} points: the GPU BallTree emulation holds at most {sb.UM}")
     pts = np.zeros((1, n, 8))
     pts[0] = pc
-    labels, _ = sb.dbscan_host(pts, np.array([n], np.int32),
-                               eps=const.DB_EPS if eps is None else eps,
-                               min_samples=const.DB_MIN_SAMPLES_MIN if min_samples is None else min_samples)
+    labels, _ = sb.dbscan_host(pts, np.array([n], np.int32), eps=float(eps), min_samples=int(min_samples))
     return labels[0, :n].copy()
 
 

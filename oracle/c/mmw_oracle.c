@@ -655,6 +655,17 @@ int orc_dbscan_neighbors(const orc_config *cfg, const double *pts, int n, double
     int n_levels, ok = 0;
     keyidx_t *scratch;
     if (n <= 0) return 0;
+    /* NearestNeighbors._fit, algorithm="auto" (sklearn/neighbors/_base.py:622-633): DBSCAN builds its NearestNeighbors with the
+     * default n_neighbors = 5, and `self.n_neighbors >= n_samples // 2` sends clouds of 1 .. 11 points to "brute" -- the exact
+     * pairwise matrix of the callable, `d <= radius` (radius_neighbors' "brute" arm, _base.py:1221-1250 -> pairwise_distances_chunked ->
+     * metrics/pairwise.py:_pairwise_callable -> _radius_neighbors_reduce_func, _base.py:1054-1081): no BallTree, hence no PRUNE / take-all shortcut.  (The other arms of
+     * that test never hold here: 8 columns <= 15, the metric is not "precomputed".) */
+    if (n / 2 <= ORC_SK_N_NEIGHBORS) {
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++)
+                adj[(size_t)i * n + j] = alt_dist(cfg, pts + (size_t)i * 8, pts + (size_t)j * 8) <= eps;
+        return 0;
+    }
     /* BinaryTree.__init__ _binary_tree.pxi.tp:876-878, leaf_size = 30 */
     {
         double q = (double)(n - 1) / 30.0;

@@ -276,6 +276,88 @@ def gen_dbscan_huge():
     print(f"  dbscan_huge: sizes {sizes}, clusters {[int(data[f'labels_{n}_35'].max()) + 1 for n in sizes]} / {[int(data[f'labels_{n}_8'].max()) + 1 for n in sizes]}")
 
 
+SMALL_SIZES = list(range(1, 14))
+SMALL_MIN_SAMPLES = list(range(1, 7)) + [8, 10]
+SMALL_CLOUDS = 40
+
+
+def small_cloud(seed, n):
+    """One cloud of `n` points around a random centre whose pairwise metric straddles DB_EPS: a third of the clouds tight
+    (most pairs inside eps), a third at the threshold, a third loose; every fifth cloud repeats one of its points (duplicate
+    rows: metric 0); every other cloud of three or more points is a SHELL (below).  All 8 columns filled, fp32-representable."""
+    rng = np.random.default_rng(31000 + seed)
+    sig = (0.18, 0.30, 0.45)[seed % 3]
+    x = np.zeros((n, 8))
+    cx, cy = rng.uniform(-2, 2), rng.uniform(1.5, 6)
+    if seed % 2 == 1 and n >= 3:
+        # a shell around the centre, squared metric radius 0.3 .. 0.5 eps: "metric(p, centroid) + radius <= eps" holds for most
+        # points (the tree would hand each of them the whole cloud) while points on opposite sides are up to 4 radii apart
+        u = rng.standard_normal((n, 3))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        r = np.sqrt(rng.uniform(0.3, 0.5, (n, 1)) * 0.3 / (1 - 0.03 * cy))
+        x[:, 0], x[:, 1], x[:, 2] = cx + r[:, 0] * u[:, 0], cy + r[:, 0] * u[:, 1], 0.9 + r[:, 0] * u[:, 2] / np.sqrt(0.4)
+    else:
+        x[:, 0] = cx + sig * rng.standard_normal(n)
+        x[:, 1] = cy + sig * rng.standard_normal(n)
+        x[:, 2] = rng.uniform(0.05, 1.8, n)
+    x[:, 3:6] = 0.3 * rng.standard_normal((n, 3))
+    x[:, 6] = 0.3 * rng.standard_normal(n)
+    x[:, 7] = rng.gamma(1.0, 30.0, n)
+    if n > 1 and seed % 5 == 4:
+        x[int(rng.integers(1, n))] = x[0]
+    return x.astype(np.float32)
+
+
+def gen_dbscan_small():
+    """apply_DBscan on clouds of 1 .. 13 points with DB_MIN_SAMPLES_MIN 1 .. 6, 8, 10.  DBSCAN.fit builds its NearestNeighbors with the
+    default n_neighbors = 5 (sklearn/cluster/_dbscan.py:410-418), and NearestNeighbors._fit answers `n_neighbors >= n_samples // 2`
+    -- 1 .. 11 points -- by BRUTE FORCE (neighbors/_base.py:622-633); the BallTree and its prune / take-all shortcuts start at
+    12 points.  `tree_differs` records, per (size, min_samples), how many of the clouds the BallTree rule would have labelled
+    differently (DBSCAN(algorithm="ball_tree") on the same cloud): the file FAILS an implementation that runs the tree's
+    shortcuts below 12 points.  Plus one named case: the 3-point cloud of the round-5 review (fuzz case 12002 of
+    tests/_fuzz.py, scene 1, frame 3; its own eps / weights / min_samples)."""
+    const, utils, _ = load_reference()
+    from sklearn.cluster import DBSCAN
+    data = {}
+    differs = np.zeros((len(SMALL_SIZES), len(SMALL_MIN_SAMPLES)), np.int32)
+    for a, n in enumerate(SMALL_SIZES):
+        pts = np.stack([small_cloud(100 * n + c, n) for c in range(SMALL_CLOUDS)])
+        data[f"pts_{n}"] = pts
+        for b, ms in enumerate(SMALL_MIN_SAMPLES):
+            labs = np.zeros((SMALL_CLOUDS, n), np.int8)
+            for c in range(SMALL_CLOUDS):
+                x = pts[c].astype(np.float64)
+                labs[c] = DBSCAN(eps=const.DB_EPS, min_samples=ms, metric=utils.altered_EuclideanDist).fit_predict(x)
+                cl = utils.apply_DBscan(x, min_samples=ms)
+                assert [len(k) for k in cl] == [int((labs[c] == k).sum()) for k in range(labs[c].max() + 1)]
+                tree = DBSCAN(eps=const.DB_EPS, min_samples=ms, metric=utils.altered_EuclideanDist, algorithm="ball_tree").fit_predict(x)
+                differs[a, b] += int(not np.array_equal(tree, labs[c]))
+            data[f"labels_{n}_{ms}"] = labs
+    # the named case
+    from tests._fuzz import draw_case, plant_nonfinite, scene_inputs
+    case = draw_case(12002, max_pts=260, max_scenes=2, frames=12)
+    fp, fc, _ = scene_inputs(case)
+    plant_nonfinite(case, fp, fc, rate=0.3)
+    named = fp[3, 1, [0, 1, 3]].astype(np.float32)
+    kw = case["cfg"]
+    saved = (const.DB_Z_WEIGHT, const.DB_RANGE_WEIGHT)
+    const.DB_Z_WEIGHT, const.DB_RANGE_WEIGHT = kw["db_z_weight"], kw["db_range_weight"]
+    try:
+        lab = DBSCAN(eps=kw["db_eps"], min_samples=kw["db_min_samples"], metric=utils.altered_EuclideanDist).fit_predict(named.astype(np.float64))
+        tree = DBSCAN(eps=kw["db_eps"], min_samples=kw["db_min_samples"], metric=utils.altered_EuclideanDist,
+                      algorithm="ball_tree").fit_predict(named.astype(np.float64))
+    finally:
+        const.DB_Z_WEIGHT, const.DB_RANGE_WEIGHT = saved
+    assert list(lab) == [-1, -1, -1] and list(tree) == [0, 0, 0], (lab, tree)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, "dbscan_small.npz"), sizes=np.array(SMALL_SIZES), min_samples=np.array(SMALL_MIN_SAMPLES),
+                        tree_differs=differs, named_pts=named, named_labels=lab.astype(np.int8),
+                        named_cfg=json.dumps({k: kw[k] for k in ("db_eps", "db_z_weight", "db_range_weight", "db_min_samples")}),
+                        db_eps=const.DB_EPS, db_z_weight=const.DB_Z_WEIGHT, db_range_weight=const.DB_RANGE_WEIGHT, meta=_meta(), **data)
+    print("  dbscan_small: clouds the BallTree rule would label differently, of", SMALL_CLOUDS, "per (size, min_samples):")
+    for a, n in enumerate(SMALL_SIZES):
+        print(f"    n={n:2d}: {list(map(int, differs[a]))}")
+
+
 def gen_offline():
     """OfflineManager + offline_main dt logic (Utils.py:53-177, offline_main.py:40-62).
     offline_main.py itself cannot be imported (PyQt5/keras); its loop is 12 lines and
@@ -680,6 +762,8 @@ def main():
         gen_dbscan()
     if not args.only or args.only == "dbscan_huge":
         gen_dbscan_huge()
+    if not args.only or args.only == "dbscan_small":
+        gen_dbscan_small()
     if not args.only or args.only == "offline":
         gen_offline()
     if not args.only or args.only == "formatters":

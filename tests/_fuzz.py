@@ -41,7 +41,18 @@ def reference_overrides(cfg_kw: dict) -> dict:
     return out
 
 
-def draw_case(seed: int, max_pts: int = 1024, max_scenes: int = 8, frames: int = 12) -> dict:
+ARMS = ("wide", "small", "threshold")
+# apply_DBscan's input sizes at which scikit-learn changes what it does: 11 | 12 brute force -> BallTree
+# (NearestNeighbors: n_neighbors 5 >= n // 2), 60 | 61, 120 | 121, 240 | 241 one more tree level (leaf_size 30)
+SK_THRESHOLDS = (11, 12, 60, 61, 120, 121, 240, 241)
+
+
+def draw_case(seed: int, max_pts: int = 1024, max_scenes: int = 8, frames: int = 12, arm: str = "wide") -> dict:
+    """arm "wide": the whole configuration surface (the draws of a seed never change: recorded seeds stay what they were).
+    arm "small": N <= 16 points per frame, DB_MIN_SAMPLES_MIN 1 .. 4, ring 1 .. 2 -- clouds sklearn answers by brute force, or
+    right behind that switch, with cores in them.  arm "threshold": the cloud sizes of SK_THRESHOLDS (+- 1), reached by one
+    frame (ring 1) or by the sum of ring frames, with a min_samples small enough for clusters."""
+    assert arm in ARMS, arm
     rng = np.random.default_rng(770000 + int(seed))
     seek_inner = seed % 8 == 5
     # points per frame: small, medium and large clouds; exact multiples of 64 only by accident
@@ -51,10 +62,22 @@ def draw_case(seed: int, max_pts: int = 1024, max_scenes: int = 8, frames: int =
     n = max(1, min(n, lim))
     ring = int(rng.integers(2, 4)) if seek_inner else int(rng.integers(1, 5))
     tr_max = int(rng.integers(1, 13))
+    if arm != "wide":
+        arng = np.random.default_rng(771000 + int(seed))
+        if arm == "small":
+            n, ring = int(arng.integers(1, 17)), (int(arng.integers(2, 4)) if seek_inner else int(arng.integers(1, 3)))
+        else:
+            ring = int(arng.integers(2, 4)) if seek_inner else int(arng.integers(1, 4))
+            u = int(arng.choice([t for t in SK_THRESHOLDS if t <= min(lim, max_pts) * ring])) + int(arng.integers(-1, 2))
+            n = max(1, min(lim, -(-u // ring) if arng.random() < 0.5 else u))
     # every cluster apply_DBscan finds becomes a track (Tracking.py:576-589): keep (TR_MAX_TRACKS - 1) + U / min_samples below
     # the 63 tracks a scene's list may hold in every layout
     ms_floor = -(-ring * n // (62 - tr_max)) + 1
     min_samples = int(max(ms_floor, rng.integers(3, 41) if n >= 120 else rng.integers(2, max(4, n // 3 + 1))))   # (small clouds can cluster too)
+    if arm == "small":
+        min_samples = int(max(-(-ring * n // (62 - tr_max)), arng.integers(1, 5)))      # (min_samples 1: every point a core point)
+    elif arm == "threshold":
+        min_samples = int(max(ms_floor, arng.integers(2, 7) if n <= 16 else arng.integers(3, 13)))
     cfg = dict(
         fb_frames_batch=ring - 1, db_min_samples=min_samples, tr_max_tracks=tr_max,
         kf_enable_est=int(rng.integers(0, 2)), dim_x=int(rng.choice([9, 6])),
@@ -70,7 +93,7 @@ def draw_case(seed: int, max_pts: int = 1024, max_scenes: int = 8, frames: int =
     if seek_inner:
         cfg.update(seek_inner=1, fb_frames_batch_static=int(rng.integers(1, ring + 1)), db_points_thres=int(rng.integers(20, 60)),
                    db_spread_thres=float(np.round(rng.uniform(0.4, 1.0), 2)), db_inner_eps=float(np.round(rng.uniform(0.05, 0.2), 3)))
-    return dict(seed=int(seed), S=int(rng.integers(1, max_scenes + 1)), N=n, F=int(frames), cfg=cfg, seek_inner=seek_inner)
+    return dict(seed=int(seed), S=int(rng.integers(1, max_scenes + 1)), N=n, F=int(frames), cfg=cfg, seek_inner=seek_inner, arm=arm)
 
 
 def scene_inputs(case: dict):

@@ -510,6 +510,20 @@ def test_trackbuffer_raises_the_references_valueerror_on_nonfinite_rows():
         with pytest.raises(ValueError) as ei:
             utils.dbscan_labels(pts)
         assert "NaN" in str(ei.value)
+    # ... and sklearn's other refusals: parameters outside DBSCAN's constraints, no samples, a 1-D array (np.array([]) is what
+    # BatchedData.clear() leaves in effective_data, Tracking.py:57-58)
+    ok = z["pts_61"].astype(np.float64)
+    for args, word in (((ok, 0.0, 5), "eps"), ((ok, float("nan"), 5), "eps"), ((ok, 0.3, 0), "min_samples"),
+                       ((np.zeros((0, 8)), 0.3, 5), "0 sample"), ((np.array([]), 0.3, 5), "2D array")):
+        with pytest.raises(ValueError) as ei:
+            utils.apply_DBscan(*args)
+        assert word in str(ei.value), (word, str(ei.value))
+    # twelve points: the first cloud size sklearn hands to the BallTree; eleven: brute force (both golden: dbscan_small.npz)
+    zs = np.load(os.path.join(GOLDEN, "dbscan_small.npz"))
+    for n in (3, 8, 11, 12, 13):
+        for c in range(0, 40, 7):
+            for ms in (2, 5, 8):
+                assert np.array_equal(utils.dbscan_labels(zs[f"pts_{n}"][c], min_samples=ms), zs[f"labels_{n}_{ms}"][c]), (n, c, ms)
     # normalize_data: one non-finite coordinate turns all three into NaN (the reference's full 4 x 4 products: 0 * inf) and the
     # scene filter drops the row; a non-finite doppler leaves three NaN velocities on a kept row -- against the oracle's
     # restatement, which tests/test_reference_fuzz.py pins on the live reference with the same rows

@@ -23,9 +23,32 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_CASES))
 def test_random_configuration_vs_oracle(seed, layout):
+    run_case(draw_case(seed), layout)
+
+
+import json as _json
+import os as _os
+with open(_os.path.join(_os.path.dirname(__file__), "fuzz_window.json")) as _fh:
+    _WINDOW = _json.load(_fh)
+# the arms aimed at scikit-learn's size switches (tests/_fuzz.py: "small" = clouds answered by brute force, n // 2 <= 5, and right
+# behind; "threshold" = 11 | 12, 60 | 61, 120 | 121, 240 | 241 points), on the seed window of the ROUND (tests/fuzz_window.json:
+# the live-reference fuzz runs the same seeds against oracle/c in the build container)
+ARM_SEED0 = int(_os.environ.get("MMW_FUZZ_ARM_SEED0", _WINDOW["base"]))
+N_ARM = int(_os.environ.get("MMW_FUZZ_ARM_CASES", "32"))
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("arm", ["small", "threshold"])
+@pytest.mark.parametrize("seed", range(ARM_SEED0, ARM_SEED0 + N_ARM))
+def test_random_small_and_threshold_clouds_vs_oracle(seed, arm, layout):
+    seen = run_case(draw_case(seed, arm=arm), layout)
+    assert seen is not None
+
+
+def run_case(case, layout):
     from mmwave_msc_amd import _lib
     from oracle import c_oracle as co
-    case = draw_case(seed)
+    seed = case["seed"]
     kw, S, N, F = case["cfg"], case["S"], case["N"], case["F"]
     pts, cnt, dts = scene_inputs(case)                       # [F,S,N,8] float32, [F,S] (0 = skipped, -1 = empty cloud), [F,S]
     sb = make_checked(S, N, layout, **kw)
@@ -103,6 +126,7 @@ def test_random_configuration_vs_oracle(seed, layout):
                 assert np.array_equal(sb.track_ring_frame(s, t, k), scenes[s].track_ring_frame(t, k)[: sb.ring_rows]), (seed, s, t, k)
     sb.close()
     case["seen"] = seen
+    return seen
 
 
 @pytest.mark.parametrize("layout", ["track_wise", "per_scene", "one_workgroup"])
@@ -165,7 +189,6 @@ def test_scene_reset_after_a_reference_exception_vs_oracle(seed, layout):
     sb.close()
 
 
-import os as _os
 N_NONFINITE = int(_os.environ.get("MMW_FUZZ_NF_CASES", "24"))      # (a one-off wider window: MMW_FUZZ_NF_CASES=512, as MMW_FUZZ_CASES)
 NF_SEED0 = int(_os.environ.get("MMW_FUZZ_NF_SEED0", "5000"))
 

@@ -428,6 +428,82 @@ def test_dbscan_golden():
     sb.close()
 
 
+def test_dbscan_of_at_most_13_points_golden():
+    """tests/golden/dbscan_small.npz (sklearn through the reference's metric: 1 .. 13 points, DB_MIN_SAMPLES_MIN 1 .. 10, clouds on
+    which the BallTree's take-all rule and the brute force sklearn really runs below 12 points DISAGREE -- `tree_differs`) through
+    mmw_dbscan, and the round-5 review's 3-point cloud with its own constants."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "dbscan_small.npz"))
+    sizes, mss = [int(v) for v in z["sizes"]], [int(v) for v in z["min_samples"]]
+    per = len(z["pts_1"])
+    S = len(sizes) * per
+    sb = _mk(S, 16, fb_frames_batch=0, db_eps=float(z["db_eps"]), db_z_weight=float(z["db_z_weight"]), db_range_weight=float(z["db_range_weight"]))
+    pts = np.zeros((S, 13, 8))
+    n = np.zeros(S, np.int32)
+    for a, sz in enumerate(sizes):
+        pts[a * per: (a + 1) * per, :sz] = z[f"pts_{sz}"]
+        n[a * per: (a + 1) * per] = sz
+    for ms in mss:
+        labels, ncl = sb.dbscan_host(pts, n, min_samples=ms)
+        for a, sz in enumerate(sizes):
+            want = z[f"labels_{sz}_{ms}"]
+            got = labels[a * per: (a + 1) * per, :sz]
+            assert np.array_equal(got, want), (sz, ms, np.flatnonzero((got != want).any(axis=1)))
+            assert np.array_equal(ncl[a * per: (a + 1) * per], want.max(axis=1) + 1)
+    sb.close()
+    kw = json.loads(str(z["named_cfg"]))
+    ms = kw.pop("db_min_samples")
+    sb = _mk(1, 16, fb_frames_batch=0, **kw)
+    labels, ncl = sb.dbscan_host(z["named_pts"][None].astype(np.float64), np.array([3], np.int32), min_samples=ms)
+    assert list(labels[0, :3]) == [-1, -1, -1] and ncl[0] == 0
+    sb.close()
+
+
+@pytest.mark.parametrize("ms", [1, 2, 3, 4, 5, 6, 8, 10])
+def test_dbscan_of_at_most_13_points_through_the_step(ms):
+    """The same clouds as FRAMES: a scene per cloud, ring of one frame, no tracks yet -- TrackBuffer.track hands apply_DBscan
+    exactly the cloud (Tracking.py:689-697) --, in whichever kernels the layout runs the start-up and the small-cloud DBSCAN in
+    (k_dbscan_startup / k_post's workers / k_chain / k_scene's hand-over).  Frame 0 against the golden labels; two more
+    frames (the clouds shifted by 13 scenes: new tracks gate, the rest clusters again) against the oracle."""
+    from oracle import c_oracle as co
+    z = np.load(os.path.join(GOLDEN, "dbscan_small.npz"))
+    sizes = [int(v) for v in z["sizes"]]
+    per = min(len(z["pts_1"]), 512 // len(sizes))    # (<= 512 scenes: the one-workgroup step takes no more)
+    S = len(sizes) * per
+    kw = dict(fb_frames_batch=0, db_min_samples=ms, tr_max_tracks=12, db_eps=float(z["db_eps"]), db_z_weight=float(z["db_z_weight"]),
+              db_range_weight=float(z["db_range_weight"]))
+    sb = _mk(S, 16, **kw)
+    cfg = co.default_config(**kw)
+    scenes = [co.OracleScene(cfg, 16) for _ in range(S)]
+    pts = np.zeros((S, 16, 8))
+    n = np.zeros(S, np.int32)
+    for a, sz in enumerate(sizes):
+        pts[a * per: (a + 1) * per, :sz] = z[f"pts_{sz}"][:per]
+        n[a * per: (a + 1) * per] = sz
+    dts = np.full(S, 0.1)
+    n_small = 0
+    for f in range(3):
+        P, C = np.roll(pts, 13 * f, axis=0), np.roll(n, 13 * f)
+        assoc, labels, dbn = sb.step_host(P, C, dts)
+        ntr = sb.num_tracks()
+        trk = sb.tracks(cap=16)
+        for s in range(S):
+            oa, ol = scenes[s].track(P[s, : C[s]], 0.1)
+            assert np.array_equal(assoc[s, : C[s]], oa), (f, s)
+            assert (ol is None) == (dbn[s] < 0), (f, s)
+            if ol is not None:
+                assert dbn[s] == len(ol) and np.array_equal(labels[s, : dbn[s]], ol), (f, s, ms, len(ol))
+                n_small += int(len(ol) // 2 <= 5)
+            if f == 0:
+                sz = sizes[s // per]
+                assert np.array_equal(labels[s, :sz], z[f"labels_{sz}_{ms}"][s % per]), (s, sz, ms)
+            assert ntr[s] == scenes[s].n_tracks, (f, s)
+            assert_tracks_match(trk[s, : ntr[s]], scenes[s].tracks(), ctx=f"f{f} s{s}", exact=True)
+    sb.check()
+    sb.close()
+    assert n_small > S
+
+
 def test_dbscan_pairs_at_the_threshold_vs_oracle():
     """query_radius decides most leaf tests from an fp32 value of the metric and only the pairs within its error bound of eps in
     fp64 (k_dbscan.hip, leaf_screen).  Clouds built so that MANY pairs sit within 1e-7 .. 1e-3 of eps (lattices at the
@@ -532,7 +608,18 @@ def test_error_paths_are_loud():
     with pytest.raises(_lib.MmwError) as ei:
         sb.step_dev(buf.ptr + 8, nb.ptr, db.ptr)
     assert ei.value.code == _lib.E_ARG
+    # what sklearn's DBSCAN refuses on every call (InvalidParameterError: eps <= 0 or NaN, min_samples < 1) is refused at creation
+    labels_of = lambda **k: sb.dbscan_host(np.zeros((1, 8, 8)), np.array([4], np.int32), **k)   # noqa: E731
+    for bad in (dict(eps=0.0), dict(eps=-0.3), dict(eps=float("nan")), dict(min_samples=0)):
+        with pytest.raises(_lib.MmwError) as ei:
+            labels_of(**bad)
+        assert ei.value.code == _lib.E_ARG, bad
+    assert list(labels_of(min_samples=1)[0][0, :4]) == [0, 0, 0, 0]     # (min_samples = 1: every point a core point, four equal rows one cluster)
     sb.close()
+    for bad in (dict(db_eps=0.0), dict(db_min_samples=0), dict(db_eps=float("nan")), dict(seek_inner=1, db_inner_eps=0.0)):
+        with pytest.raises(_lib.MmwError) as ei:
+            SceneBatch(_lib.default_config(**bad), 1, 64)
+        assert ei.value.code == _lib.E_ARG, bad
 
 
 def test_capacity_overflow_is_per_scene_and_recoverable():

@@ -144,7 +144,7 @@ def test_device_tlv_decode_and_normalize_equals_host_parse_then_normalize(N):
         b_of = sb_dev.buf("tlv_off", S * 8).upload(offs)
         b_out = sb_dev.buf("tlv_pts", S * N * 64)
         b_no = sb_dev.buf("tlv_n", S * 4)
-        sb_dev.normalize_tlv_dev(b_pk.ptr, b_of.ptr, ucfg, b_out.ptr, b_no.ptr)
+        sb_dev.normalize_tlv_dev(b_pk.ptr, len(blob), b_of.ptr, ucfg, b_out.ptr, b_no.ptr)
         got_n = b_no.download((S,), np.int32)
         got_pts = b_out.download((S, N, 8), np.float64)
         assert np.array_equal(got_n, want_n), (frame, got_n, want_n)
@@ -190,3 +190,45 @@ def test_find_tlv_agrees_with_the_recorded_uart_session():
         assert frame == fn == int(g[f"frame{i}"]), (i, frame, fn)
         complete += int(plen > 0)
     assert complete >= 3
+
+
+def test_device_tlv_decode_refuses_bodies_outside_the_buffer_or_the_context():
+    """mmw_normalize_tlv reads nothing outside packets[0 .. packets_bytes): an offset that is odd or beyond the buffer, a body
+    whose announced objects run past its end, and a body that announces more than max_pts objects (mmw_parse_uart: MMW_E_ARG for
+    those bytes) all give n_out = MMW_BAD_FRAME for THAT scene -- the mmw_step that follows raises its bad-count bit -- while the
+    scenes beside it decode as usual."""
+    import struct
+    from mmwave_msc_amd import _lib, radar
+    from mmwave_msc_amd.batch import SceneBatch
+    N, S = 64, 6
+    cfgp = {"rangeIdxToMeters": 0.0436, "dopplerResolutionMps": 0.1252, "numDopplerBins": 32.0}
+    ucfg = radar.uart_cfg(cfgp)
+    rng = np.random.default_rng(3)
+
+    def body(n_announced, n_present, q=9):
+        o = rng.integers(-200, 200, size=(n_present, 6)).astype("<i2")
+        o[:, 4] = np.abs(o[:, 4]) + 300      # y > 0: the scene filter keeps rows
+        return struct.pack("<HH", n_announced, q) + o.tobytes()
+
+    good = body(20, 20)
+    blob = good + body(N + 1, N + 1) + good + body(30, 30)      # scene 1 announces max_pts + 1 objects; the last body gets truncated below
+    o1, o2, o3 = len(good), len(good) + 4 + 12 * (N + 1), 2 * len(good) + 4 + 12 * (N + 1)
+    nbytes = len(blob) - 12 * 5                                   # scene 3: five of its thirty objects lie outside the buffer
+    offs = np.array([0, o1, o2, o3, o2 + 1, nbytes - 2], np.int64)   # scene 4: odd offset; scene 5: the 4-byte head does not fit
+    sb = SceneBatch(_lib.default_config(), S, N)
+    b_pk = sb.buf("tlv_bytes", len(blob) + 16).upload(np.frombuffer(blob, dtype=np.uint8))
+    b_of = sb.buf("tlv_off", S * 8).upload(offs)
+    b_out = sb.buf("tlv_pts", S * N * 64)
+    b_no = sb.buf("tlv_n", S * 4)
+    sb.normalize_tlv_dev(b_pk.ptr, nbytes, b_of.ptr, ucfg, b_out.ptr, b_no.ptr)
+    got = b_no.download((S,), np.int32)
+    assert got[0] > 0 and got[2] == got[0], got
+    assert list(got[[1, 3, 4, 5]]) == [_lib.BAD_FRAME] * 4, got
+    b_dt = sb.buf("tlv_dt", S * 8).upload(np.full(S, 0.1))
+    sb.step_dev(b_out.ptr, b_no.ptr, b_dt.ptr)
+    with pytest.raises(_lib.MmwError) as ei:
+        sb.check()
+    assert ei.value.code == _lib.E_ARG
+    err = sb.errors()
+    assert [bool(e & 8) for e in err] == [False, True, False, True, True, True], err
+    sb.close()

@@ -86,6 +86,34 @@ def test_dbscan_matches_sklearn_golden():
         assert np.array_equal(sizes, z[f"sizes_{n}"])
 
 
+def test_dbscan_of_at_most_13_points_matches_sklearn_golden():
+    """Clouds of 1 .. 13 points, DB_MIN_SAMPLES_MIN 1 .. 10: sklearn answers n // 2 <= 5 by BRUTE FORCE (NearestNeighbors'
+    default n_neighbors = 5 >= n_samples // 2, sklearn/neighbors/_base.py:622-633), the BallTree starts at 12 points.  The
+    file would fail an implementation that ran the tree's take-all / prune shortcuts on the small clouds (what oracle/c and the
+    kernels did up to round 5): `tree_differs` -- recorded from DBSCAN(algorithm="ball_tree") -- says how many clouds per
+    (size, min_samples) that rule labels differently, and the test insists the file has teeth."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "dbscan_small.npz"))
+    cfg = co.default_config(db_eps=float(z["db_eps"]), db_z_weight=float(z["db_z_weight"]), db_range_weight=float(z["db_range_weight"]))
+    sizes, mss = [int(v) for v in z["sizes"]], [int(v) for v in z["min_samples"]]
+    assert sizes == list(range(1, 14))
+    for n in sizes:
+        pts = z[f"pts_{n}"].astype(np.float64)
+        for ms in mss:
+            want = z[f"labels_{n}_{ms}"]
+            for c in range(len(pts)):
+                assert np.array_equal(co.dbscan(cfg, pts[c], min_samples=ms), want[c]), f"n={n} min_samples={ms} cloud {c}"
+    td = z["tree_differs"]
+    per = len(z["pts_3"])
+    for n in range(2, 12):     # every brute-force size has a min_samples at which >= 10 % of its clouds tell the two rules apart
+        assert td[sizes.index(n)].max() >= per // 10, (n, td[sizes.index(n)])
+    assert td[sizes.index(12):].sum() == 0   # (12 points up: the tree IS the reference)
+    kw = json.loads(str(z["named_cfg"]))
+    ms = kw.pop("db_min_samples")
+    got = co.dbscan(co.default_config(**kw), z["named_pts"].astype(np.float64), min_samples=ms)
+    assert np.array_equal(got, z["named_labels"]) and list(got) == [-1, -1, -1]   # the round-5 review's 3-point cloud: no track
+
+
 def test_dbscan_of_more_than_1920_points_matches_sklearn_golden():
     """64 .. 128 BallTree leaves (Utils.py:250-291 has no size limit): the oracle the GPU's global-memory path is checked
     against, pinned on sklearn's labels for the reference's own metric."""
