@@ -1537,7 +1537,7 @@ __device__ __forceinline__ void chain_worker_loop(const DevCfg &cfg, const DevSt
         if (threadIdx.x == 0) {
             if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
             int s = -1, h = -1;
-            h = atomicAdd(&q[kQHead], 1);
+            h = atomicAdd(&q[kQHead], 1) & kQIdxMask;   // (tickets; the tag of the step in the upper bits: mmw_device.hpp)
             if (h >= q_load(&q[kQCount])) h = -1;
             if (h >= 0) {
                 int32_t *e = ring + h;
@@ -1600,15 +1600,15 @@ __device__ __forceinline__ void big_worker_loop(const DevCfg &cfg, const DevStat
             if (have) { __threadfence(); atomicAdd(&q[kQDone], 1); }
             int s = -1, h = -1;
             if (AFTER_TRACK) {
-                if (q_load(&q[kQHead]) < q_load(&q[kQCount])) {  // (an empty queue costs two loads, no atomic)
-                    h = atomicAdd(&q[kQHead], 1);
+                if ((q_load(&q[kQHead]) & kQIdxMask) < q_load(&q[kQCount])) {  // (an empty queue costs two loads, no atomic)
+                    h = atomicAdd(&q[kQHead], 1) & kQIdxMask;
                     if (h >= q_load(&q[kQCount])) h = -1;
                 }
             } else {
                 for (int spins = 0; spins < kSpinLimit; spins++) {
                     const int hh = q_load(&q[kQHead]), c = q_load(&q[kQCount]);
-                    if (hh < c) {
-                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh; break; }
+                    if ((hh & ~kQIdxMask) == q_tag(epoch) && (hh & kQIdxMask) < c) {
+                        if (atomicCAS(&q[kQHead], hh, hh + 1) == hh) { h = hh & kQIdxMask; break; }
                         continue;
                     }
                     if (q_load(&st.q[kQStop]) - epoch >= 0) break;  // k_post of this step has begun and the queue is empty: done
@@ -1771,8 +1771,8 @@ __global__ __launch_bounds__(NT, MMW_POST_OCC) void k_post(DevCfg cfg, DevState 
             //  heads would part ways in front of the worker loop's barriers)
             int *leave = reinterpret_cast<int *>(lds_raw);
             if (threadIdx.x == 0) {
-                const int c3 = st.db_count[parity * 4 + 3], c0 = q_load(&st.q[parity * 8 + kQCount]), h0 = q_load(&st.q[parity * 8 + kQHead]);
-                const int cb = UMb > 0 ? q_load(&st.q[kQBig + parity * 8 + kQCount]) - q_load(&st.q[kQBig + parity * 8 + kQHead]) : 0;
+                const int c3 = st.db_count[parity * 4 + 3], c0 = q_load(&st.q[parity * 8 + kQCount]), h0 = q_load(&st.q[parity * 8 + kQHead]) & kQIdxMask;
+                const int cb = UMb > 0 ? q_load(&st.q[kQBig + parity * 8 + kQCount]) - (q_load(&st.q[kQBig + parity * 8 + kQHead]) & kQIdxMask) : 0;
                 *leave = (c3 == 0 && h0 >= c0 && cb <= 0) ? 1 : 0;
             }
             __syncthreads();
@@ -1874,14 +1874,17 @@ __global__ __launch_bounds__(kBigThreads) void k_chain(DevCfg cfg, DevState st, 
                 if (stop - epoch >= 1) break;
                 if (stop - (epoch - 1) < 0) { __builtin_amdgcn_s_sleep(8); continue; }
 #endif
+                // (a claim is a compare-and-swap on TAG + index: the head word was tagged with our step's number when the queue was reset
+                //  for us; a worker that read `stop` above and was then held up for two steps fails here instead of taking a later
+                //  step's cloud into ITS step's output buffers -- what the stop check alone let happen under six processes)
                 const int hb = q_load(&qb[kQHead]), cb = cfg.big_live ? q_load(&qb[kQCount]) : 0;  // (start-up frames: pushed without a release, not ours)
-                if (hb < cb) {
-                    if (atomicCAS(&qb[kQHead], hb, hb + 1) == hb) { h = hb; kind = 2; break; }
+                if ((hb & ~kQIdxMask) == q_tag(epoch) && (hb & kQIdxMask) < cb) {
+                    if (atomicCAS(&qb[kQHead], hb, hb + 1) == hb) { h = hb & kQIdxMask; kind = 2; break; }
                     continue;
                 }
                 const int hs = q_load(&qs[kQHead]), cs = q_load(&qs[kQCount]);
-                if (hs < cs) {
-                    if (atomicCAS(&qs[kQHead], hs, hs + 1) == hs) { h = hs; kind = 1; break; }
+                if ((hs & ~kQIdxMask) == q_tag(epoch) && (hs & kQIdxMask) < cs) {
+                    if (atomicCAS(&qs[kQHead], hs, hs + 1) == hs) { h = hs & kQIdxMask; kind = 1; break; }
                     continue;
                 }
                 if (stop - epoch >= 0) break;  // k_post of this step had begun before the queues were looked at, and both are empty: done

@@ -6,6 +6,7 @@
 //   k_pop_frame   BatchedData.pop_frame on the global ring         (Tracking.py:66-71)
 //   k_export      flatten effective_tracks for read-back
 //   k_table       fixed-size track summaries for the RCCL all-gather
+#include <cstddef>
 #include "mmw_device.hpp"
 #include "mmw_math.hpp"
 #include "mmw_launch.hpp"
@@ -364,7 +365,12 @@ __global__ void k_export(DevCfg cfg, DevState st, mmw_track_record *__restrict__
     if (s >= cfg.n_scenes) return;
     mmw_track_record *o = out + (size_t)s * cap + j;
     const SceneHdr *hdr = st.hdr + s;
-    if (j >= hdr->n_tracks) return;  // caller zero-fills
+    if (j >= hdr->n_tracks) {   // a list position beyond the scene's tracks: zeros, written HERE (no memset in front of the launch)
+        unsigned long long *z = reinterpret_cast<unsigned long long *>(o);
+        static_assert(sizeof(mmw_track_record) % 8 == 0, "zero fill by 8-byte words");
+        for (size_t e = 0; e < sizeof(mmw_track_record) / 8; e++) z[e] = 0ULL;
+        return;
+    }
     const TrackRec *rec = st.trk + (size_t)s * cfg.t_cap + st.order[(size_t)s * cfg.t_cap + j];
     for (int e = 0; e < 9; e++) o->x[e] = e < cfg.dx ? rec->x[e] : 0.0;
     for (int e = 0; e < 81; e++) o->P[e] = (e / 9 < cfg.dx && e % 9 < cfg.dx) ? rec->P[e] : 0.0;
@@ -383,6 +389,10 @@ __global__ void k_export(DevCfg cfg, DevState st, mmw_track_record *__restrict__
     o->uid = rec->uid;
     for (int k = 0; k < MMW_RING_MAX; k++) o->ring_n[k] = k < rec->ring_len ? rec->ring_n[k] : 0;
     for (int e = 0; e < MMW_NKP; e++) o->keypoints[e] = rec->kp[e];
+    // (the record's trailing padding: the buffer is not cleared in front of the launch, and a caller may compare records as bytes)
+    constexpr size_t kUsed = offsetof(mmw_track_record, keypoints) + sizeof(float) * MMW_NKP;
+    static_assert(sizeof(mmw_track_record) - kUsed == 4 || sizeof(mmw_track_record) == kUsed, "trailing padding of mmw_track_record");
+    if (sizeof(mmw_track_record) > kUsed) reinterpret_cast<int32_t *>(o)[kUsed / 4] = 0;
 }
 
 __global__ void k_table(DevCfg cfg, DevState st, mmw_track_summary *__restrict__ out, int slots, int scene_base)

@@ -266,8 +266,8 @@ __global__ __launch_bounds__(NT, PPT >= 4 ? NT / 256 : NT / 128) void k_scene(De
     const int n = n_raw < 0 ? 0 : n_raw;  // MMW_EMPTY_FRAME: track() on an empty cloud
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths and queue counters (k_post's workers)
-    if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;
-    if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = 0;
+    if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = tid - 4 == kQHead ? q_tag(cfg.epoch + 1) : 0;  // ... and its queue counters (kQCount, kQHead -- tagged with the step it will serve --, kQDone)
+    if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = tid - 8 == kQHead ? q_tag(cfg.epoch + 1) : 0;  // ... and those of the large clouds' queue
     if (s == 0 && tid < kUpdWords) st.upd_count[(parity ^ 1) * kUpdWords + tid] = 0;
     if (s == 0 && tid == NT - 1) st.spc_count[parity ^ 1] = 0;
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
@@ -341,14 +341,19 @@ __global__ __launch_bounds__(NT, PPT >= 4 ? NT / 256 : NT / 128) void k_scene(De
         // One track's record (C^-1, log det, predicted position: 43 doubles) is the same for every point: read through the
         // scalar cache (constant address space, uniform address -> s_load) it enters the fp64 VALU ops as their SGPR operand.
         // y' C^-1 y as k-ordered FUSED chains, the arithmetic definition the oracle shares (k_track.hip).
+#ifdef MMW_DIAG_VGATE   // (diagnostic build, scripts/dual_run.py: the records by VECTOR loads -- volatile global -- instead of through the scalar cache)
+        typedef const volatile double *gate_ptr;
+#else
         typedef const double __attribute__((address_space(4))) *gate_ptr;
-        typedef const int __attribute__((address_space(4))) *line_ptr;
+#endif
         const int su = __builtin_amdgcn_readfirstlane(s), Tu = __builtin_amdgcn_readfirstlane(T);
         gate_ptr gb = (gate_ptr)(st.gate_buf + (size_t)su * cfg.t_cap * kGateRec);
         // (the constant address space promises the compiler memory that does not change: the pointer is made opaque HERE,
         //  behind the invalidate, so that no load through it can be moved above this statement)
         asm volatile("; mmw: gate pointer opaque from here" : "+s"(gb) : : "memory");
+#ifndef MMW_DIAG_VGATE
         {   // warm the scalar cache: one dword of every 64-byte line of the records, all requests in flight together
+            typedef const int __attribute__((address_space(4))) *line_ptr;
             const unsigned long long a0 = (unsigned long long)gb & ~63ULL;
             const int lines = (int)((((unsigned long long)gb + (unsigned long long)Tu * kGateRec * 8 + 63ULL) & ~63ULL) - a0) >> 6;
             line_ptr w = (line_ptr)a0;
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(NT, PPT >= 4 ? NT / 256 : NT / 128) void k_scene(De
             }
             asm volatile("" : : "s"(acc));
         }
+#endif
         PROBE(4);
         for (int j = 0; j < Tu; j++) {
             gate_ptr G = gb + j * kGateRec;

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     const int n = n_raw < 0 ? 0 : n_raw;  // MMW_EMPTY_FRAME: track() on an empty cloud
     if (tid == 0 && db_n_out) db_n_out[s] = -1;
     if (s == 0 && tid < 4) st.db_count[(parity ^ 1) * 4 + tid] = 0;  // next step's work-list lengths
-    if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = 0;  // ... and its queue counters (kQCount, kQHead, kQDone)
-    if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = 0;  // ... and those of the large clouds' queue
+    if (s == 0 && tid >= 4 && tid < 7) st.q[(parity ^ 1) * 8 + (tid - 4)] = tid - 4 == kQHead ? q_tag(cfg.epoch + 1) : 0;  // ... and its queue counters (kQCount, kQHead -- tagged with the step it will serve --, kQDone)
+    if (s == 0 && tid >= 8 && tid < 11) st.q[kQBig + (parity ^ 1) * 8 + (tid - 8)] = tid - 8 == kQHead ? q_tag(cfg.epoch + 1) : 0;  // ... and those of the large clouds' queue
     if (s == 0 && tid < kUpdWords) st.upd_count[(parity ^ 1) * kUpdWords + tid] = 0;       // ... and the lengths of its update lists
     if (s == 0 && tid == kThreads - 1) st.spc_count[parity ^ 1] = 0;
     if (!frame_reaches_track(n_raw, NP)) {  // offline_main.py:56: empty frames never reach track()
@@ -323,7 +323,11 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
     // the arithmetic definition the oracle shares (oracle/c/mmw_oracle.c, _calc_dist_fun); with the operands in SGPRs the
     // phase is bound by fp64 issue, and the fused form is 49 instead of 84 instructions per (point, track).
     {
+#ifdef MMW_DIAG_VGATE   // (diagnostic build, scripts/dual_run.py: the records by VECTOR loads -- volatile global -- instead of through the scalar cache)
+        typedef const volatile double *gate_ptr;
+#else
         typedef const double __attribute__((address_space(4))) *gate_ptr;
+#endif
         const int su = __builtin_amdgcn_readfirstlane(s), Tu = __builtin_amdgcn_readfirstlane(T);
         gate_ptr gb = (gate_ptr)(st.gate_buf + (size_t)su * cfg.t_cap * kGateRec);
         if constexpr (PRED) {
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
             // change, so the pointer itself is made opaque HERE, behind the invalidate: no load through it can be moved above
             // this statement.
             asm volatile("; mmw: gate pointer opaque from here" : "+s"(gb) : : "memory");
+#ifndef MMW_DIAG_VGATE
             // Warm the scalar cache: one dword of every 64-byte line of the scene's gate records, all requests in flight
             // together.  The loop below then takes its records (six s_loads per track, waited for as a batch) from the
             // scalar cache instead of paying an L2 round trip per track -- with two or three workgroups per CU nothing hides
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(kThreads, (PRED ? 2 : (PPT == 2 ? 5 : (PPT == 1 ? 4
                 for (int u = 0; u < 16; u++) acc |= t[u];
             }
             asm volatile("" : : "s"(acc));
+#endif
         }
         PROBE(32);
         for (int j = 0; j < Tu; j++) {

@@ -397,10 +397,18 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     }
 
 #ifdef MMW_DIAG_POISON   // (diagnostic build, mmw_launch.hpp: what mmw_create does not initialise reads as NaN / huge, not as whatever was there)
-#define MMW_POISON_FRESH(ptr, bytes) (void)hipMemset((void *)(ptr), 0xFF, (bytes))
+#define MMW_POISON_FRESH(ptr, bytes) (void)hipMemsetAsync((void *)(ptr), 0xFF, (bytes), c->own_stream)
 #else
 #define MMW_POISON_FRESH(ptr, bytes) ((void)0)
 #endif
+    // The context's stream FIRST: everything that initialises device memory below is queued on it and waited for before this
+    // function returns.  (Up to round 5 the zero fills were plain hipMemset calls -- work on the NULL stream, asynchronous to the
+    // host for device memory -- while the context's stream is non-blocking, i.e. not ordered with the null stream: with six
+    // processes on the GPU a fill could still be pending when mmw_create returned, and landed on the track records / queue words
+    // AFTER the first steps had written them, or on memory mmw_destroy had already freed.  scripts/dual_run.py caught it: about
+    // one fresh context in 10^4 under that load; profiles/NOTEBOOK.md round 6.)
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
+    c->stream = c->own_stream;
 #define ALLOC(ptr, bytes)                                                                                   \
     do {                                                                                                    \
         hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                                \
@@ -438,21 +446,27 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     c->st.db_list = c->d_db_list;
     c->st.db_count = c->d_db_count;
     c->st.q = c->d_q;
-    if (hipMemcpy(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(c->d_stats, 0, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_db_count, 0, 8 * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->d_q, 0, kQWords * sizeof(int32_t)) != hipSuccess || hipMemset(c->d_db_list, 0, 4 * S * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->st.upd_count, 0, 2 * (size_t)kUpdWords * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->st.upd_list, 0, 2 * (size_t)kUpdShards * upd_region((int)S, cap) * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->st.spc_count, 0, 2 * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(c->st.trk, 0, S * cap * sizeof(TrackRec)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipStreamCreate failed"); }
+#ifdef MMW_MUTANT_NULL_STREAM_INIT
+    // (diagnostic build `make DIAG=nullinit DIAGFLAGS=-DMMW_MUTANT_NULL_STREAM_INIT`, never the product: the round-5 initialisation,
+    //  which scripts/dual_run.py must catch under load)
+#define MMW_FILL0(ptr, bytes) hipMemset((ptr), 0, (bytes))
+#else
+#define MMW_FILL0(ptr, bytes) hipMemsetAsync((ptr), 0, (bytes), c->own_stream)
+#endif
+    if (hipMemcpyAsync(c->d_posture, cfg->default_posture, MMW_NKP * sizeof(float), hipMemcpyHostToDevice, c->own_stream) != hipSuccess ||
+        MMW_FILL0(c->d_stats, (size_t)kStatSlots * kStatWords * sizeof(unsigned long long)) != hipSuccess ||
+        MMW_FILL0(c->d_db_count, 8 * sizeof(int32_t)) != hipSuccess ||
+        MMW_FILL0(c->d_q, kQWords * sizeof(int32_t)) != hipSuccess || MMW_FILL0(c->d_db_list, 4 * S * sizeof(int32_t)) != hipSuccess ||
+        MMW_FILL0(c->st.upd_count, 2 * (size_t)kUpdWords * sizeof(int32_t)) != hipSuccess ||
+        MMW_FILL0(c->st.upd_list, 2 * (size_t)kUpdShards * upd_region((int)S, cap) * sizeof(int32_t)) != hipSuccess ||
+        MMW_FILL0(c->st.spc_count, 2 * sizeof(int32_t)) != hipSuccess ||
+        MMW_FILL0(c->st.trk, S * cap * sizeof(TrackRec)) != hipSuccess ||
+        hipStreamSynchronize(c->own_stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }   // (cfg->default_posture is the caller's)
     if (hipHostMalloc((void **)&c->h_rows, kTickets * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipHostMalloc failed"); }
     for (int k = 0; k < kTickets; k++) {
         c->h_rows[k] = 0;
         if (hipEventCreateWithFlags(&c->feat_ev[k], hipEventDisableTiming) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipEventCreate failed"); }
     }
-    c->stream = c->own_stream;
     c->side_wanted = d.side_worker;
     c->side_trusted = (d.side_worker && cfg->chain_side_stream == 2) ? 1 : 0;   // 2: taken on trust (counter collection serialises kernels: the probe would say no)
     c->gate_side = (d.side_worker && cfg->chain_side_stream == 3) ? 1 : 0;
@@ -465,7 +479,7 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     if (d.seek_inner) {
         if (inner_lds_demand(d) > 160 * 1024) { mmw_destroy(c); return fail(nullptr, MMW_E_ARG, "seek_inner: LDS demand too large (%zu B)", inner_lds_demand(d)); }
         if (prepare_inner(d) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "hipFuncSetAttribute(k_inner) failed"); }
-        if (hipMemset(c->st.inner_buf, 0, S * (size_t)(kInnerHdr + c->st.inner_cap) * sizeof(int32_t)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
+        if (MMW_FILL0(c->st.inner_buf, S * (size_t)(kInnerHdr + c->st.inner_cap) * sizeof(int32_t)) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "device init failed"); }
     }
     hipError_t e1 = prepare_track(d), e2 = prepare_dbscan(c->UM, cap, cfg->db_min_samples);
     if (e1 == hipSuccess && scene_lds_bytes(d) <= 160 * 1024) e1 = prepare_scene(d);
@@ -478,9 +492,19 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
             return fail(nullptr, MMW_E_HIP, "hipMalloc(%zu B of BallTree slabs) failed", c->st.huge_stride * (size_t)dbscan_huge_workers(n_scenes));
         }
     }
+#undef MMW_FILL0
     launch_reset(d, c->st, nullptr, c->stream);
+    // every fill above and the reset kernel have finished before the caller sees the context
     if (hipStreamSynchronize(c->stream) != hipSuccess) { mmw_destroy(c); return fail(nullptr, MMW_E_HIP, "reset kernel failed: %s", hipGetErrorString(hipGetLastError())); }
     *out = c;
+    return MMW_OK;
+}
+
+// Read-back into the caller's (pageable) memory of what the context's stream has written: wait for the stream, then a blocking copy.
+static int d2h_after_kernels(mmw_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return MMW_OK;
 }
 
@@ -601,8 +625,7 @@ int mmw_set_batch_frame(mmw_ctx *c, int32_t scene, const double *rows, int32_t n
     if (!c || scene < 0 || scene >= c->dc.n_scenes || n < 0 || n > c->dc.max_pts || (n > 0 && !rows)) return fail(c, MMW_E_ARG, "mmw_set_batch_frame: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     SceneHdr h;
-    HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, &h, c->st.hdr + scene, sizeof(h)); if (rc_) return rc_; }
     h.g_len = 1;
     if (c->ring_frames_bound < 1) c->ring_frames_bound = 1;
     for (int k = 0; k < MMW_RING_MAX; k++) h.g_n[k] = 0;
@@ -713,8 +736,7 @@ int mmw_memcpy_d2h(mmw_ctx *c, void *dst, const void *src, size_t bytes)
 {
     if (!c) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, dst, src, bytes); if (rc_) return rc_; }
     return MMW_OK;
 }
 
@@ -797,6 +819,7 @@ static int step_impl(mmw_ctx *c, const void *pts, bool f32, const int32_t *n_pts
     // k_post, so no stop epoch was raised for it -- counting it would leave q[kQStop] one behind for good, and every later k_chain
     // would poll to its idle limit without ever claiming
     c->epoch++;
+    c->dc.epoch = c->epoch;   // (k_track / k_scene tag the claim words of the NEXT step's queues with it: mmw_device.hpp, q_tag)
     if (c->dc.side_worker) {
         launch_chain(c->dc, c->st, c->UM, u_bound, c->step_parity, c->epoch, db_labels, db_n, c->side_stream);
     }
@@ -1057,8 +1080,7 @@ static int read_headers(mmw_ctx *c, std::vector<SceneHdr> &h)
 {
     HIPCHK(c, hipSetDevice(c->device));
     h.resize(c->dc.n_scenes);
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->st.hdr, h.size() * sizeof(SceneHdr), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, h.data(), c->st.hdr, h.size() * sizeof(SceneHdr)); if (rc_) return rc_; }
     return MMW_OK;
 }
 
@@ -1090,8 +1112,7 @@ int mmw_check(mmw_ctx *c)
     int rc = read_headers(c, h);
     if (rc) return rc;
     int32_t q[kQWords];
-    HIPCHK(c, hipMemcpyAsync(q, c->d_q, sizeof(q), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, q, c->d_q, sizeof(q)); if (rc_) return rc_; }
     return first_scene_error(c, h.data(), h.size(), q);
 }
 
@@ -1129,12 +1150,9 @@ int mmw_get_tracks(mmw_ctx *c, mmw_track_record *out, int32_t cap)
         HIPCHK(c, hipMalloc((void **)&c->d_export, bytes));
         c->export_cap = cap;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_export, 0, bytes, c->stream));
-    launch_export(c->dc, c->st, c->d_export, cap, c->stream);
+    launch_export(c->dc, c->st, c->d_export, cap, c->stream);   // (writes every record, the empty ones as zeros: no memset in front)
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out, c->d_export, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MMW_OK;
+    return d2h_after_kernels(c, out, c->d_export, bytes);
 }
 
 int mmw_get_track_ring_frame(mmw_ctx *c, int32_t scene, int32_t track, int32_t k, double *out, int32_t *n_rows)
@@ -1142,20 +1160,16 @@ int mmw_get_track_ring_frame(mmw_ctx *c, int32_t scene, int32_t track, int32_t k
     if (!c || !out || !n_rows || scene < 0 || scene >= c->dc.n_scenes) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     SceneHdr h;
-    HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, &h, c->st.hdr + scene, sizeof(h)); if (rc_) return rc_; }
     if (track < 0 || track >= h.n_tracks) return fail(c, MMW_E_ARG, "track %d out of range (%d tracks)", track, h.n_tracks);
     int32_t slot = 0;
-    HIPCHK(c, hipMemcpyAsync(&slot, c->st.order + (size_t)scene * c->dc.t_cap + track, sizeof(slot), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, &slot, c->st.order + (size_t)scene * c->dc.t_cap + track, sizeof(slot)); if (rc_) return rc_; }
     TrackRec rec;
-    HIPCHK(c, hipMemcpyAsync(&rec, c->st.trk + (size_t)scene * c->dc.t_cap + slot, sizeof(rec), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, &rec, c->st.trk + (size_t)scene * c->dc.t_cap + slot, sizeof(rec)); if (rc_) return rc_; }
     if (k < 0 || k >= rec.ring_len) return fail(c, MMW_E_ARG, "frame %d out of range (ring_len %d)", k, rec.ring_len);
     const int keep = rec.ring_n[k] < c->dc.ring_rows ? rec.ring_n[k] : c->dc.ring_rows;
     const double *src = c->st.trk_ring + ((((size_t)scene * c->dc.t_cap + slot) * c->dc.ring + rec.ring_slot[k]) * c->dc.ring_rows) * 8;
-    HIPCHK(c, hipMemcpyAsync(out, src, (size_t)keep * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, out, src, (size_t)keep * 8 * sizeof(double)); if (rc_) return rc_; }
     *n_rows = keep;
     return MMW_OK;
 }
@@ -1165,12 +1179,10 @@ int mmw_get_batch_ring_frame(mmw_ctx *c, int32_t scene, int32_t k, double *out, 
     if (!c || !out || !n_rows || scene < 0 || scene >= c->dc.n_scenes) return MMW_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     SceneHdr h;
-    HIPCHK(c, hipMemcpyAsync(&h, c->st.hdr + scene, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, &h, c->st.hdr + scene, sizeof(h)); if (rc_) return rc_; }
     if (k < 0 || k >= h.g_len) return fail(c, MMW_E_ARG, "frame %d out of range (ring_len %d)", k, h.g_len);
     const double *src = c->st.g_ring + ((size_t)scene * c->dc.ring + h.g_slot[k]) * (size_t)c->dc.max_pts * 8;
-    HIPCHK(c, hipMemcpyAsync(out, src, (size_t)h.g_n[k] * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, out, src, (size_t)h.g_n[k] * 8 * sizeof(double)); if (rc_) return rc_; }
     *n_rows = h.g_n[k];
     return MMW_OK;
 }
@@ -1182,8 +1194,7 @@ int mmw_get_inner(mmw_ctx *c, int32_t *n_calls, int32_t *rows, int32_t *labels, 
     HIPCHK(c, hipSetDevice(c->device));
     const size_t S = c->dc.n_scenes, W = kInnerHdr + c->st.inner_cap;
     std::vector<int32_t> h(S * W);
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->st.inner_buf, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, h.data(), c->st.inner_buf, h.size() * sizeof(int32_t)); if (rc_) return rc_; }
     for (size_t s = 0; s < S; s++) {
         const int32_t *b = h.data() + s * W;
         n_calls[s] = b[0];
@@ -1287,8 +1298,7 @@ static int read_stats(mmw_ctx *c, uint64_t *out, int words)
 {
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint64_t> h((size_t)kStatSlots * kStatWords);
-    HIPCHK(c, hipMemcpyAsync(h.data(), c->d_stats, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, h.data(), c->d_stats, h.size() * sizeof(uint64_t)); if (rc_) return rc_; }
     for (int w = 0; w < words; w++) {
         uint64_t sum = 0;
         for (int k = 0; k < kStatSlots; k++) sum += h[(size_t)k * kStatWords + w];
@@ -1392,8 +1402,7 @@ int mmw_stats_get_ext(mmw_ctx *c, uint64_t *out)
 int mmw_diag_probes(mmw_ctx *c, uint64_t *out /*[256 + 8192]*/)
 {
     if (!c || !out) return MMW_E_ARG;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_stats + (size_t)kStatSlots * kStatWords, (256 + 8192) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { const int rc_ = d2h_after_kernels(c, out, c->d_stats + (size_t)kStatSlots * kStatWords, (256 + 8192) * sizeof(uint64_t)); if (rc_) return rc_; }
     return MMW_OK;
 }
 #endif

@@ -42,6 +42,7 @@ struct DevCfg {
     int32_t db_points_thres, fb_frames_batch_static;
     int32_t big_live;        // this step's large clouds may be claimed WHILE k_track runs (side workers on, start-up frames over): they are pushed with a release; otherwise plainly, for the kernels behind k_track
     int32_t fused;           // the step is k_scene (one workgroup runs a scene's whole track(): k_scene.hip) + the worker blocks of k_post: contexts whose scenes are all resident at once
+    int32_t epoch;           // number of this step (mmw_api.hip: counts committed steps of the context): tags the claim words of the DBSCAN queues
     int32_t var_ring, side_worker;   // side_worker: k_chain runs beside k_track on a second stream (mmw_api.hip); var_ring: a global ring size was changed (mmw_set_batch_size): k_track reads ring sizes from the headers
     double db_spread_thres, db_inner_eps;
     double db_z_weight, db_range_weight, db_eps;
@@ -164,6 +165,14 @@ constexpr int kUpdMaxScenes = 1 << 19;
 // per CU); measured 0.0777 -> 0.0705 ms at 768 scenes, 0.0937 -> 0.1128 at 1024.
 constexpr int kSmallContextScenes = 768;
 constexpr int kQCount = 0, kQHead = 1, kQDone = 2, kQStop = 3, kQTimeout = 4;
+// The head (claim) word of a queue carries the number of the step the queue serves in its upper bits (q_tag), written when the
+// queue is reset a step ahead: a claim is a compare-and-swap on tag + index, so a side-stream worker of ANOTHER step -- one that
+// checked the stop epoch, was held up (six processes time-sharing the GPU: milliseconds), and looks at the queue of its parity two
+// steps later -- cannot take an entry that is not its step's (it did: scripts/dual_run.py, profiles/NOTEBOOK.md round 6; the
+// cloud was clustered correctly but its labels / db_n went to the OLD step's output buffers).  Consumers on the context's own
+// stream run inside their step and mask the tag.
+constexpr int kQTagShift = 20, kQIdxMask = (1 << kQTagShift) - 1;   // (n_scenes < 2^19 entries per step)
+__host__ __device__ inline int q_tag(int epoch) { return (epoch & 0x7ff) << kQTagShift; }
 constexpr int kQBig = 16;   // q[kQBig + 8p + kQCount/kQHead/kQDone]: the queue of the clouds of more than 256 points
 constexpr int kQWords = 32;
 constexpr int kEarlyU = 0;     // clouds of at least this many points go to the early queue (k_track.hip); a threshold above the clutter level (180) measured slower

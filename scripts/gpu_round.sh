@@ -7,7 +7,7 @@ STAGES="${@:-tests smoke bench}"
 for st in $STAGES; do
   case $st in
     tests)
-      timeout 1500 python -m pytest tests -x -q -m gpu --durations=5 2>&1 | tail -25 | tee gpurun_out/pytest_gpu.txt ;;
+      timeout 1500 python -m pytest tests -q -m gpu --durations=5 2>&1 | tail -25 | tee gpurun_out/pytest_gpu.txt ;;
     smoke)
       timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.txt ;;
     bench)

@@ -93,13 +93,14 @@ def _device_isa(names):
 
 
 def _kernel_report(rep):
-    """[(mangled name, scratch bytes per lane, spilled VGPRs, VGPRs, waves per SIMD)] from -Rpass-analysis=kernel-resource-usage."""
+    """[(mangled name, scratch bytes per lane, spilled VGPRs, VGPRs, waves per SIMD, spilled SGPRs)] from -Rpass-analysis=kernel-resource-usage."""
     import re
     out = []
     for blk in re.split(r"remark: Function Name: ", rep)[1:]:
         name = blk.split()[0]
         f = lambda pat: int(re.search(pat, blk).group(1))
-        out.append((name, f(r"ScratchSize \[bytes/lane\]: (\d+)"), f(r"VGPRs Spill: (\d+)"), f(r" VGPRs: (\d+)"), f(r"Occupancy \[waves/SIMD\]: (\d+)")))
+        out.append((name, f(r"ScratchSize \[bytes/lane\]: (\d+)"), f(r"VGPRs Spill: (\d+)"), f(r" VGPRs: (\d+)"), f(r"Occupancy \[waves/SIMD\]: (\d+)"),
+                    f(r"SGPRs Spill: (\d+)")))
     return out
 
 
@@ -107,6 +108,8 @@ def _kernel_report(rep):
 # clusters its whole first frame) takes two 512-thread workgroups per CU, i.e. 128 registers per lane, for a BallTree chain that wants
 # ~180 -- measured 3.0 ms per 4096 clouds that way against 4.0 ms unspilled at one workgroup per CU (k_dbscan.hip: launch_dbscan_big).
 _MAY_SPILL = {"k_dbscan_startup": 52}
+_SGPR_SPILL_CEILING = {"k_track": 56, "k_scene": 141, "k_predict": 12, "k_inner": 250, "k_chain": 306, "k_dbscan_big": 271, "k_dbscan_startup": 240,
+                       "k_dbscan_only": 83, "k_dbscan_huge": 257, "k_dbscan_only_huge": 181, "k_post": 567}
 
 
 def test_step_kernels_compile_without_scratch():
@@ -124,9 +127,13 @@ def test_step_kernels_compile_without_scratch():
         rep, asm = isa[f]
         kernels = _kernel_report(rep)
         assert kernels, rep[-2000:]
-        for name, scratch, vspill, vgprs, occ in kernels:
+        for name, scratch, vspill, vgprs, occ, sspill in kernels:
             short = re.search(r"\d+(k_[a-z_]+?)(I|E)", name).group(1)
             seen.setdefault(short, []).append((name, vgprs, occ))
+            # spilled SGPRs: every one is a v_writelane / v_readlane pair with its wait states inside a latency chain (the round-5
+            # review counted 505 in k_post, 300 in k_chain that nothing guarded).  A ratchet: the ceilings are the numbers of the
+            # build this test was written on (k_chain: + 3 for the tagged claim words of round 6, a correctness fix); lower them when a kernel improves, never raise them without a measurement.
+            assert sspill <= _SGPR_SPILL_CEILING[short], (name, sspill, _SGPR_SPILL_CEILING[short])
             if short in _MAY_SPILL:
                 assert vspill <= _MAY_SPILL[short], (name, vspill)
                 continue
