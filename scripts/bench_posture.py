@@ -11,7 +11,8 @@ from mmwave_msc_amd.batch import SceneBatch
 from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
 
 S, N, T, F = int(os.environ.get("S", 4096)), 512, 8, 8
-pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=1)
+POP = os.environ.get("POP", "full")   # the e2e leg of bench.py runs SURVEY 8(d)'s K = T population (31.7 k samples); POP=mixed: 1 + s mod 8 targets (18.3 k)
+pts, cnt, dts = bench.generate(np.arange(S), F, N, T, workers=1, population=POP)
 dev = torch.device("cuda:0")
 sb = SceneBatch(_lib.default_config(tr_max_tracks=T), S, N)
 side = torch.cuda.Stream(); torch.cuda.set_stream(side); sb.follow_torch_stream(side)  # one stream for torch and the context
@@ -32,4 +33,4 @@ torch.cuda.synchronize()
 t0 = time.perf_counter(); K = 10
 for _ in range(K): n = it()
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / K
-print(f"posture leg: {n} samples, {el*1e3:.3f} ms/iter, {n/el:.0f} samples/s, CNN {n*25.187328e6/el/1e12:.2f} TFLOP/s of 157.3 fp32-MFMA peak")
+print(f"posture leg ({POP} population): {n} samples, {el*1e3:.3f} ms/iter, {n/el:.0f} samples/s, CNN {n*25.187328e6/el/1e12:.2f} TFLOP/s of 157.3 fp32-MFMA peak")
