@@ -159,7 +159,10 @@ def test_multi_scene_vs_oracle():
     for t in range(scenes[s].n_tracks):
         rec = scenes[s].tracks()[t]
         for k in range(rec["ring_len"]):
-            assert np.array_equal(sb.track_ring_frame(s, t, k), scenes[s].track_ring_frame(t, k))
+            # (the rows both sides store: the oracle keeps ring_rows = 64 of a frame, a context that forms the cluster statistics per
+            #  track -- mmw_config.split_stats -- keeps every row)
+            want = scenes[s].track_ring_frame(t, k)
+            assert np.array_equal(sb.track_ring_frame(s, t, k)[: len(want)], want[: sb.ring_rows])
     sb.close()
 
 
