@@ -261,6 +261,7 @@ def main():
     ap.add_argument("--rerun", type=int, default=10, help="repeat runs of a mismatching case")
     ap.add_argument("--max-scenes", type=int, default=8)
     ap.add_argument("--sync-every-step", action="store_true")
+    ap.add_argument("--no-ras", action="store_true", help="skip the amd-smi / rocm-smi snapshots (the 15-second pytest form)")
     ap.add_argument("--tag", default="r06")
     ap.add_argument("--worker", type=int, default=None)
     args = ap.parse_args()
@@ -268,7 +269,7 @@ def main():
         worker(args, args.worker)
         return 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    ras0 = ras_snapshot()
+    ras0 = {} if args.no_ras else ras_snapshot()
     t0 = time.time()
     base = [sys.executable, os.path.abspath(__file__), "--seconds", str(args.seconds), "--seed0", str(args.seed0), "--seed-end", str(args.seed_end), "--reps", str(args.reps),
             "--rerun", str(args.rerun), "--max-scenes", str(args.max_scenes), "--tag", args.tag] + (["--sync-every-step"] if args.sync_every_step else [])
@@ -294,7 +295,7 @@ def main():
                 reruns=sum(w["reruns"] for w in workers), rerun_mismatches=sum(w["rerun_mismatches"] for w in workers),
                 error_cases=sum(w["error_cases"] for w in workers), create_failed=sum(w["create_failed"] for w in workers),
                 workers_reporting=len(workers), layouts={}, mismatch_records=mismatches[:40], other_output=noise[:20],
-                ras_before=ras0, ras_after=ras_snapshot())
+                ras_before=ras0, ras_after={} if args.no_ras else ras_snapshot())
     for w in workers:
         for k, v in w["layouts"].items():
             summ["layouts"][k] = summ["layouts"].get(k, 0) + v
