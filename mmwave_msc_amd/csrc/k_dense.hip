@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
+#include <type_traits>
 
 namespace mmw {
 
@@ -58,6 +59,17 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0,
                                      0);
 }
+// The same request as ONE asm statement (m0 = the wave's destination, uniform base + 32-bit lane offset).  Why not the builtin: with an
+// LDS-DMA instruction in flight the compiler's wait counting gives up on the LDS counter -- every wait for a fragment becomes
+// `s_waitcnt lgkmcnt(0)`, i.e. for ALL requested fragments, also those asked for on purpose a phase ahead (k_mars_dense1_w192p).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_asm(const void *ubase, unsigned voff, void *lds_wave_base)
+{
+    const unsigned m = (unsigned)(unsigned long long)((__attribute__((address_space(3))) void *)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(ubase), "s"(m) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 }  // namespace dense
 
 using namespace dense;
@@ -300,6 +312,181 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
     }
 }
 
+// ---- the same tile, software-pipelined over its four (half step, row block) phases -- experiment.  In the kernel above a wave asks
+//      for a phase's fragments and then waits for them with nothing queued on the matrix pipe (both waves of a SIMD are in the same
+//      phase: they drain it together, four times per K-step, and once more behind the barrier).  Here the activation fragments of
+//      phase p + 1 are requested BEFORE the nine MFMAs of phase p (two fragment buffers), the weight fragments of the next half step
+//      replace this one's as each feature block's last MFMAs have been issued, and the barrier of a K-step sits in front of its LAST
+//      phase, whose operands are in registers: barrier skew and the first reads of the next tile hide behind those MFMAs.
+//      Same ring (three A tiles, two W tiles), same request lead, same order of additions per accumulator: bit-identical. ----
+__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
+                                                                   long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
+                                                                   int tiles_n)
+{
+    using namespace dense192;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const long long m0 = (long long)tm * 256;
+    const int n0 = tn * BN2;
+    // this wave's pieces of a tile (1 KB = 8 rows x 128 B each): A pieces wave * 4 + i, W pieces wave * 3 + i.  A piece's source is a
+    // uniform base + i * 8 rows + one of TWO per-lane offsets (the swizzle of rows 8 p + r depends on p's parity only): four VGPRs
+    // instead of seven 64-bit pointers -- the fragment double buffer needs the registers
+    const int rr = lane >> 3, c0 = (lane & 7) ^ (rr >> 1);
+    const int ldA = (int)lda, ldW = (int)ldw;
+    const unsigned vA0 = (unsigned)((rr * ldA + c0 * 8) * 2), vA1 = (unsigned)((rr * ldA + (c0 ^ 4) * 8) * 2);
+    const unsigned vW0 = (unsigned)((rr * ldW + (c0 ^ ((wave & 1) * 4)) * 8) * 2), vW1 = (unsigned)((rr * ldW + (c0 ^ ((~wave & 1) * 4)) * 8) * 2);   // (W piece wave * 3 + i: parity (wave + i) & 1)
+    const char *const uA = reinterpret_cast<const char *>(a2 + (m0 + wave * 32) * lda), *const uW = reinterpret_cast<const char *>(w2 + (long long)(n0 + wave * 24) * ldw);
+    char *const dA = lds + wave * 4 * 1024, *const dW = lds + 3 * kA + wave * 3 * 1024;
+    auto pieceA = [&](int i, int kt, int slot) { glds16_asm(uA + ((long long)i * 16 * ldA + (long long)kt * (4 * BK)), (i & 1) ? vA1 : vA0, dA + slot * kA + i * 1024); };
+    auto pieceW = [&](int i, int kt, int slot) { glds16_asm(uW + ((long long)i * 16 * ldW + (long long)kt * (4 * BK)), (i & 1) ? vW1 : vW0, dW + slot * kW + i * 1024); };
+    const int offA0 = unit_off(wm * 64 + (lane & 31), lane >> 5), offW0 = unit_off(wn * 96 + (lane & 31), lane >> 5);
+    df16 am[2][3], ac[2][3];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
+    dh8 wh[3], wl[3], ab[2][2];   // weight fragments of the half step in hand; activation fragments [buffer][hi, lo']
+    auto LA = [&](int buf, const char *ba, int kk, int x) {
+        ab[buf][0] = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32)) + x * 4096));
+        ab[buf][1] = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32) ^ 64) + x * 4096));
+    };
+    auto LW = [&](const char *bw, int kk, int y) {
+        wh[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32)) + y * 4096));
+        wl[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32) ^ 64) + y * 4096));
+    };
+    // (corr first and last, main between them: the second corr product does not follow the first back to back)
+#define MMW_MF(buf, x, y)                                                                               \
+    do {                                                                                                \
+        ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[buf][0], wl[y], ac[x][y], 0, 0, 0);       \
+        am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[buf][0], wh[y], am[x][y], 0, 0, 0);       \
+        ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[buf][1], wh[y], ac[x][y], 0, 0, 0);       \
+    } while (0)
+    const int KT = K / BK;
+    // requests in the order the counted waits rely on: ... W(kt), A(kt + 1) | W(kt + 1), A(kt + 2) | ...
+    pieceW(0, 0, 0); pieceW(1, 0, 0); pieceW(2, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) pieceA(i, 0, 0);
+    if (KT > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) pieceA(i, 1, 1);
+        pieceW(0, 1, 1); pieceW(1, 1, 1); pieceW(2, 1, 1);
+    }
+    if (KT > 2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) pieceA(i, 2, 2);
+    }
+    if (KT > 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if (KT > 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int sa = 0, sw = 0;   // ring slots of the tile in hand
+    {   // tile 0: everything but its last phase, fragments requested one phase ahead
+        const char *ba = lds, *bw = lds + 3 * kA;
+        LA(0, ba, 0, 0);
+#pragma unroll
+        for (int y = 0; y < 3; y++) LW(bw, 0, y);
+        __builtin_amdgcn_sched_barrier(0);
+        LA(1, ba, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 0; y < 3; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
+        LA(0, ba, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 0; y < 3; y++) { MMW_MF(1, 1, y); __builtin_amdgcn_sched_barrier(0); LW(bw, 1, y); __builtin_amdgcn_sched_barrier(0); }
+        LA(1, ba, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 0; y < 3; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
+    }
+    // One barrier-to-barrier stretch: the last phase of tile j, then -- if there is a tile j + 1 -- its first three.  MORE1..3 = "tiles
+    // j + 1, j + 2, j + 3 exist" as COMPILE-TIME flags (the steady state is straight-line code; the last three stretches are
+    // instantiated separately): at a join of two paths the compiler's wait counting falls back to lgkmcnt(0).
+    auto stretch = [&](auto M1, auto M2, auto M3, int j) {
+        constexpr bool more1 = decltype(M1)::value, more2 = decltype(M2)::value, more3 = decltype(M3)::value;
+        // here: every read of tile j has been requested (its last phase's operands are in, or on their way to, registers)
+        const int sa1 = sa + 1 == 3 ? 0 : sa + 1, sw1 = sw ^ 1;   // slots of tile j + 1; tile j's own become those of A(j + 3), W(j + 2)
+        const char *ba = lds + sa1 * kA, *bw = lds + 3 * kA + sw1 * kW;
+        if constexpr (more1) {
+            if constexpr (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // W(j + 1) and everything before it; A(j + 2) stays in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's reads of tile j have arrived, its buffers may be refilled (the
+                                                  // builtin, not asm: the compiler's own wait counting must see it)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_s_setprio(1);
+        // ---- last phase of tile j (registers only) | first reads of tile j + 1 | requests W(j + 2), then A(j + 3) ----
+        if constexpr (more1) LA(0, ba, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int y = 0; y < 3; y++) {
+            MMW_MF(1, 1, y);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (more1) LW(bw, 0, y);
+            if constexpr (more2) pieceW(y, j + 2, sw);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (more1) {
+            // ---- tile j + 1, phases (0, 0), (0, 1), (1, 0) ----
+            LA(1, ba, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int y = 0; y < 3; y++) {
+                MMW_MF(0, 0, y);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more3) pieceA(y, j + 3, sa);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            LA(0, ba, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int y = 0; y < 3; y++) {
+                MMW_MF(1, 1, y);
+                __builtin_amdgcn_sched_barrier(0);
+                LW(bw, 1, y);
+                if constexpr (more3) { if (y == 0) pieceA(3, j + 3, sa); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            LA(1, ba, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int y = 0; y < 3; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
+            sa = sa1; sw = sw1;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int j = 0;
+    for (; j + 3 < KT; j++) stretch(T{}, T{}, T{}, j);
+    if (j + 2 < KT) { stretch(T{}, T{}, F{}, j); j++; }
+    if (j + 1 < KT) { stretch(T{}, F{}, F{}, j); j++; }
+    stretch(F{}, F{}, F{}, j);
+#undef MMW_MF
+#pragma unroll
+    for (int y = 0; y < 3; y++) {
+        const int col = n0 + wn * 96 + y * 32 + (lane & 31);
+        const float bv = bias[col];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (am[x][y][r] + ac[x][y][r] * kInvSplit) + bv;
+                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);
+            }
+        }
+    }
+}
+
 // rows_padded: a multiple of 256; K a multiple of 32; N a multiple of 128.
 // The tile list is cut where its last wave of workgroups would fill less than half the chip: bands of 256 rows that make whole
 // waves go to the 256-row instantiation, the rest -- as twice as many 128-row tiles -- to the other (18 304 rows x 1536: 864
@@ -318,6 +505,7 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
         if (hipFuncSetAttribute((const void *)k_mars_dense1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256)) != hipSuccess) return;
         if (hipFuncSetAttribute((const void *)k_mars_dense1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(128)) != hipSuccess) return;
         if (hipFuncSetAttribute((const void *)k_mars_dense1_w192, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1_w192p, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) P.n_cu = prop.multiProcessorCount;
         P.ok = true;
@@ -342,8 +530,13 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
             bm2 = (int)(((total2 / n_cu) * n_cu) / tn2);
             if (2LL * (bands - bm2) * tiles_n > n_cu) bm2 = bands;   // (... unless the rest is more than one wave of 128 x 128 half tiles)
         }
+#ifdef MMW_DIAG_DENSE_OLD
         if (bm2 > 0)
             hipLaunchKernelGGL(k_mars_dense1_w192, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
+#else
+        if (bm2 > 0)
+            hipLaunchKernelGGL(k_mars_dense1_w192p, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
+#endif
         if (bm2 < bands)
             hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * (bands - bm2) * tiles_n), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias, out, K,
                                N, (long long)bm2 * BM, tiles_n);

@@ -500,11 +500,14 @@ int mmw_create(const mmw_config *cfg, int32_t n_scenes, int32_t max_pts, int32_t
     return MMW_OK;
 }
 
-// Read-back into the caller's (pageable) memory of what the context's stream has written: wait for the stream, then a blocking copy.
+// Read-back into the caller's (pageable) memory of what the context's stream has written: the stream is waited for first, then the
+// copy runs on it alone and is waited for.  (On the context's stream, not as a blocking hipMemcpy: that one runs on the legacy default
+// stream and would also wait for whatever another runtime -- torch -- has queued there.)
 static int d2h_after_kernels(mmw_ctx *c, void *dst, const void *src, size_t bytes)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MMW_OK;
 }
 
