@@ -61,7 +61,7 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base)
 }
 // The same request as ONE asm statement (m0 = the wave's destination, uniform base + 32-bit lane offset).  Why not the builtin: with an
 // LDS-DMA instruction in flight the compiler's wait counting gives up on the LDS counter -- every wait for a fragment becomes
-// `s_waitcnt lgkmcnt(0)`, i.e. for ALL requested fragments, also those asked for on purpose a phase ahead (k_mars_dense1_w192p).
+// `s_waitcnt lgkmcnt(0)`, i.e. for ALL requested fragments, also those asked for on purpose a phase ahead (k_mars_dense1_w192).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16_asm(const void *ubase, unsigned voff, void *lds_wave_base)
@@ -196,130 +196,31 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
 
 // ---- 256 x 192 tiles, for feature counts that are a multiple of 192 (define_CNN_3D: 1536): fewer bytes from L2 per
 //      multiply-add (56 KB per K-step for 1.5 x the work of the 48 KB of a 256 x 128 tile) and a third fewer workgroups.  Two
-//      accumulator sets of a 64 x 96 wave tile are 192 of the 256 registers a lane has at two waves per SIMD (fragment
-//      addresses derived from one register per operand: 255 VGPRs, no scratch -- a spilled build's scratch traffic counts in
-//      vmcnt and breaks the counted waits: 1.04 ms); the LDS holds a ring of three A tiles (two in flight) and of two W
-//      tiles (one in flight: the weights are L2-resident) = 144 KB.  Same K order per output element: bit-identical results.
-//      Measured 0.924-0.931 against 0.997-1.001 ms on one box (18 304 x 6144 x 1536), with the wave index scalar (ring slots,
-//      tile origins and DMA destinations in SGPRs). ----
+//      accumulator sets of a 64 x 96 wave tile are 192 of the 256 registers a lane has at two waves per SIMD; the LDS holds a
+//      ring of three A tiles (two in flight) and of two W tiles (one in flight) = 144 KB.  Same K order per output element as
+//      the kernel above: bit-identical results.
+//      SOFTWARE-PIPELINED over the four (half step, row block) phases of a K-step (round 6; before: every phase asked for its
+//      fragments and then waited for them with nothing queued on the matrix pipe -- both waves of a SIMD are in the same phase,
+//      they drained it together four times per K-step and once more behind the barrier: 64 % MFMA-busy).  Now
+//        * the activation fragments of phase p + 1 are requested BEFORE the nine MFMAs of phase p (two fragment buffers), the weight
+//          fragments of the next half step replace this one's as each feature block's last MFMAs have been issued;
+//        * the barrier of a K-step sits in front of its LAST phase, whose operands are in registers: barrier skew and the first
+//          reads of the next tile hide behind those MFMAs (a build without the barrier is not faster);
+//        * the LDS-DMA requests are asm (glds16_asm), so the compiler's fragment waits are counted (lgkmcnt(6) / (4) / (2) ...);
+//        * a piece's source is a uniform base + one of two per-lane offsets (4 VGPRs instead of seven pointers: 250 VGPRs, no scratch
+//          -- a spilled build's reloads are `s_waitcnt vmcnt(0)` in the middle of the counted waits).
+//      Measured (31 744 x 6144 x 1536, same box, alternating; profiles/r06e_*): 1.476 -> 1.322 ms, 64 -> 80 % MFMA-busy.  What is
+//      left, by timing-only builds (MMW_DIAG_DENSE_NODMA / _NOLDS / _NOBAR: garbage results): MFMAs alone 0.79 ms, + barrier and
+//      DMA 0.92, + fragment reads instead 1.02, everything 1.33 -- and GRBM_GUI_ACTIVE says the chip runs this kernel at 1.6 GHz
+//      (the MFMA-only build at ~2.3): with all three units busy the clock, not a unit, is what gives.  Every request an L2 hit
+//      (operands from a 1 MB footprint) was worth 5 %, weights requested two K-steps ahead instead of one 2.5 %, a wave that only
+//      touches lines six steps ahead -5 % (slower): the fabric's latency is covered. ----
 namespace dense192 {
 constexpr int BN2 = 192;
 constexpr int kA = 256 * kRowBytes, kW = BN2 * kRowBytes;   // 32 KB, 24 KB
 constexpr int kLds = 3 * kA + 2 * kW;                        // 144 KB
 }
 __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
-                                                                  long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
-                                                                  int tiles_n)
-{
-    using namespace dense192;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: ring slots and tile origins stay out of the VGPRs)
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long long m0 = (long long)tm * 256;
-    const int n0 = tn * BN2;
-    const _Float16 *srcA[4], *srcW[3];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int u = (wave * 4 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
-        srcA[i] = a2 + (m0 + row) * lda + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int u = (wave * 3 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
-        srcW[i] = w2 + (long long)(n0 + row) * ldw + c * 8;
-    }
-    auto issueA = [&](int kt) {
-        char *b = lds + (kt % 3) * kA;
-#pragma unroll
-        for (int i = 0; i < 4; i++) glds16(srcA[i] + kt * (2 * BK), b + (wave * 4 + i) * 1024);
-    };
-    auto issueW = [&](int kt) {
-        char *b = lds + 3 * kA + (kt & 1) * kW;
-#pragma unroll
-        for (int i = 0; i < 3; i++) glds16(srcW[i] + kt * (2 * BK), b + (wave * 3 + i) * 1024);
-    };
-    // fragment addresses: one register per operand -- tile x / y is 32 rows = 4096 bytes further, the second half step (kk = 1)
-    // flips bit 5 of the offset (unit c ^ 2), lo' bit 6
-    const int offA0 = unit_off(wm * 64 + (lane & 31), lane >> 5), offW0 = unit_off(wn * 96 + (lane & 31), lane >> 5);
-    df16 am[2][3], ac[2][3];
-#pragma unroll
-    for (int x = 0; x < 2; x++)
-#pragma unroll
-        for (int y = 0; y < 3; y++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
-    const int KT = K / BK;
-    // issue order per step: W(kt + 1), then A(kt + 2) -- so that "everything but the last A tile" is what step kt + 1 waits for
-    issueW(0);
-    issueA(0);
-    if (KT > 1) issueA(1);
-    for (int kt = 0; kt < KT; kt++) {
-        const bool moreW = kt + 1 < KT, moreA = kt + 2 < KT;
-        if (moreW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the four pieces of A(kt + 1)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // The seven DMA pieces of this step (W(kt + 1), then A(kt + 2): the order the counted wait relies on) are issued BETWEEN
-        // the MFMA groups of the first half step, one per three MFMAs, not in a block behind the barrier (measured: 0.5 % over
-        // the block; peeling the last two steps off so that no branch sits between the MFMAs: nothing, at 256 VGPRs)
-        char *dw = lds + 3 * kA + ((kt + 1) & 1) * kW + wave * 3 * 1024, *da = lds + ((kt + 2) % 3) * kA + wave * 4 * 1024;
-        const int kw1 = __builtin_amdgcn_readfirstlane((kt + 1) * (2 * BK)), ka2 = __builtin_amdgcn_readfirstlane((kt + 2) * (2 * BK));
-        const char *ba = lds + (kt % 3) * kA, *bw = lds + 3 * kA + (kt & 1) * kW;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            dh8 wh[3], wl[3];
-#pragma unroll
-            for (int y = 0; y < 3; y++) {
-                wh[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32)) + y * 4096));
-                wl[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32) ^ 64) + y * 4096));
-            }
-#pragma unroll
-            for (int x = 0; x < 2; x++) {
-                const dh8 ah = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32)) + x * 4096));
-                const dh8 al = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32) ^ 64) + x * 4096));
-#pragma unroll
-                for (int y = 0; y < 3; y++) {
-                    am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[y], am[x][y], 0, 0, 0);
-                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[y], ac[x][y], 0, 0, 0);
-                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[y], ac[x][y], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kk == 0 && x == 0) { if (moreW) glds16(srcW[y] + kw1, dw + y * 1024); }
-                    else if (kk == 0 && x == 1) { if (moreA) glds16(srcA[y] + ka2, da + y * 1024); }
-                    else if (kk == 1 && x == 0 && y == 0) { if (moreA) glds16(srcA[3] + ka2, da + 3 * 1024); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    }
-#pragma unroll
-    for (int y = 0; y < 3; y++) {
-        const int col = n0 + wn * 96 + y * 32 + (lane & 31);
-        const float bv = bias[col];
-#pragma unroll
-        for (int x = 0; x < 2; x++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const long long row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (am[x][y][r] + ac[x][y][r] * kInvSplit) + bv;
-                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);
-            }
-        }
-    }
-}
-
-// ---- the same tile, software-pipelined over its four (half step, row block) phases -- experiment.  In the kernel above a wave asks
-//      for a phase's fragments and then waits for them with nothing queued on the matrix pipe (both waves of a SIMD are in the same
-//      phase: they drain it together, four times per K-step, and once more behind the barrier).  Here the activation fragments of
-//      phase p + 1 are requested BEFORE the nine MFMAs of phase p (two fragment buffers), the weight fragments of the next half step
-//      replace this one's as each feature block's last MFMAs have been issued, and the barrier of a K-step sits in front of its LAST
-//      phase, whose operands are in registers: barrier skew and the first reads of the next tile hide behind those MFMAs.
-//      Same ring (three A tiles, two W tiles), same request lead, same order of additions per accumulator: bit-identical. ----
-__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
                                                                    long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
                                                                    int tiles_n)
 {
@@ -341,6 +242,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float1
     const unsigned vW0 = (unsigned)((rr * ldW + (c0 ^ ((wave & 1) * 4)) * 8) * 2), vW1 = (unsigned)((rr * ldW + (c0 ^ ((~wave & 1) * 4)) * 8) * 2);   // (W piece wave * 3 + i: parity (wave + i) & 1)
     const char *const uA = reinterpret_cast<const char *>(a2 + (m0 + wave * 32) * lda), *const uW = reinterpret_cast<const char *>(w2 + (long long)(n0 + wave * 24) * ldw);
     char *const dA = lds + wave * 4 * 1024, *const dW = lds + 3 * kA + wave * 3 * 1024;
+#ifdef MMW_DIAG_DENSE_NODMA   // (timing-only builds, scripts/ab_dense.sh: no requests / MMW_DIAG_DENSE_NOLDS: no fragment reads / _NOBAR: no barrier)
+#define glds16_asm(a, b, c) ((void)0)
+#endif
     auto pieceA = [&](int i, int kt, int slot) { glds16_asm(uA + ((long long)i * 16 * ldA + (long long)kt * (4 * BK)), (i & 1) ? vA1 : vA0, dA + slot * kA + i * 1024); };
     auto pieceW = [&](int i, int kt, int slot) { glds16_asm(uW + ((long long)i * 16 * ldW + (long long)kt * (4 * BK)), (i & 1) ? vW1 : vW0, dW + slot * kW + i * 1024); };
     const int offA0 = unit_off(wm * 64 + (lane & 31), lane >> 5), offW0 = unit_off(wn * 96 + (lane & 31), lane >> 5);
@@ -352,6 +256,12 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float1
 #pragma unroll
             for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
     dh8 wh[3], wl[3], ab[2][2];   // weight fragments of the half step in hand; activation fragments [buffer][hi, lo']
+#ifdef MMW_DIAG_DENSE_NOLDS
+    for (int y = 0; y < 3; y++) { wh[y] = dh8{1, 1, 1, 1, 1, 1, 1, 1}; wl[y] = wh[y]; }
+    ab[0][0] = ab[0][1] = ab[1][0] = ab[1][1] = wh[0];
+    auto LA = [&](int, const char *, int, int) {};
+    auto LW = [&](const char *, int, int) {};
+#else
     auto LA = [&](int buf, const char *ba, int kk, int x) {
         ab[buf][0] = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32)) + x * 4096));
         ab[buf][1] = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32) ^ 64) + x * 4096));
@@ -360,6 +270,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float1
         wh[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32)) + y * 4096));
         wl[y] = *reinterpret_cast<const dh8 *>(bw + ((offW0 ^ (kk * 32) ^ 64) + y * 4096));
     };
+#endif
     // (corr first and last, main between them: the second corr product does not follow the first back to back)
 #define MMW_MF(buf, x, y)                                                                               \
     do {                                                                                                \
@@ -419,7 +330,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float1
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's reads of tile j have arrived, its buffers may be refilled (the
                                                   // builtin, not asm: the compiler's own wait counting must see it)
+#ifndef MMW_DIAG_DENSE_NOBAR
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
         }
         __builtin_amdgcn_s_setprio(1);
@@ -471,6 +384,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192p(const _Float1
     if (j + 1 < KT) { stretch(T{}, F{}, F{}, j); j++; }
     stretch(F{}, F{}, F{}, j);
 #undef MMW_MF
+#ifdef MMW_DIAG_DENSE_NODMA
+#undef glds16_asm
+#endif
 #pragma unroll
     for (int y = 0; y < 3; y++) {
         const int col = n0 + wn * 96 + y * 32 + (lane & 31);
@@ -505,7 +421,6 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
         if (hipFuncSetAttribute((const void *)k_mars_dense1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256)) != hipSuccess) return;
         if (hipFuncSetAttribute((const void *)k_mars_dense1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(128)) != hipSuccess) return;
         if (hipFuncSetAttribute((const void *)k_mars_dense1_w192, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return;
-        if (hipFuncSetAttribute((const void *)k_mars_dense1_w192p, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) P.n_cu = prop.multiProcessorCount;
         P.ok = true;
@@ -530,13 +445,8 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
             bm2 = (int)(((total2 / n_cu) * n_cu) / tn2);
             if (2LL * (bands - bm2) * tiles_n > n_cu) bm2 = bands;   // (... unless the rest is more than one wave of 128 x 128 half tiles)
         }
-#ifdef MMW_DIAG_DENSE_OLD
         if (bm2 > 0)
             hipLaunchKernelGGL(k_mars_dense1_w192, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
-#else
-        if (bm2 > 0)
-            hipLaunchKernelGGL(k_mars_dense1_w192p, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
-#endif
         if (bm2 < bands)
             hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * (bands - bm2) * tiles_n), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias, out, K,
                                N, (long long)bm2 * BM, tiles_n);
