@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
 #pragma unroll
             for (int i = 0; i < C::kStage / 16 / 64; i++) z[i * 64 + lane] = uint4{0, 0, 0, 0};
         }
+#ifndef MMW_DIAG_CONV_NOINPUT
 #pragma unroll
         for (int q = 0; q < PPL; q++) {
             h8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,10 +346,12 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
 #pragma unroll
                 for (int c = 0; c < 5; c++) xin[q][c] = feat[(size_t)(b + stride) * C::kPos * 5 + (q * 64 + lane) * 5 + c];
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         CSTAMP(1);  // input staging
         // ---- conv1: the four 16-position tiles of a plane at a time (they share the weight fragments); D[oc][pos] ----
+#ifndef MMW_DIAG_CONV_NOCONV1
 #pragma unroll
         for (int d = 0; d < NZ; d++) {
             int pc[4];
@@ -399,17 +402,31 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 for (int u = 0; u < 4; u++) { nxh[u] = xh[u]; nxl[u] = xl[u]; }
                 if (nxt >= 0) load_step(nxt, nwh, nwl, nxh, nxl);
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef MMW_DIAG_CONV_NOMFMA1
+                asm volatile("" ::"v"(wh), "v"(wl), "v"(xh[0]), "v"(xh[1]), "v"(xh[2]), "v"(xh[3]), "v"(xl[0]), "v"(xl[1]), "v"(xl[2]), "v"(xl[3]));
+#else
 #pragma unroll
                 for (int u = 0; u < 4; u++) am[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[u], am[u], 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < 4; u++) ac[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[u], ac[u], 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < 4; u++) ac[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[u], ac[u], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 wh = nwh; wl = nwl;
 #pragma unroll
                 for (int u = 0; u < 4; u++) { xh[u] = nxh[u]; xl[u] = nxl[u]; }
             }
+#ifdef MMW_DIAG_CONV_NOEPI1
+            {
+                float keep = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) keep += am[u][r] + ac[u][r];
+                if (keep == 12345.678f) out[lane] = (_Float16)keep;
+            }
+#else
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 h4 hi, lo;
@@ -426,20 +443,81 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 reinterpret_cast<h4 *>(Hhi + (g >> 1) * CE + pc[u])[g & 1] = hi;
                 reinterpret_cast<h4 *>(Hlo + (g >> 1) * CE + pc[u])[g & 1] = lo;
             }
+#endif
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         CSTAMP(2);  // conv1
         // ---- conv2: the two 32-position tiles of a plane at a time (the plane is uniform: taps that read a plane outside
-        //      the volume are skipped at compile time); D[oc][pos] ----
+        //      the volume are skipped at compile time); D[oc][pos].
+        //      The EPILOGUE of plane d - 1 (bias, relu, split, staging tile, stores: VALU work, a quarter of the kernel when it ran
+        //      between the planes with the matrix pipe idle -- one wave per SIMD, nobody else to fill it) is cut into sixteen chunks
+        //      and issued BETWEEN the taps of plane d, behind each tap's six MFMAs: two accumulator sets, the registers were
+        //      there.  Only the last plane's epilogue runs alone (its staging tile lies over X8, which the next sample's
+        //      input wants). ----
         _Float16 *o = out + (size_t)b * ld_out;
         const h8 *Hh = Hhi + h2 * CE, *Hl = Hlo + h2 * CE;   // this lane's channel plane
+        f32x16 acc[2][4];                                     // [set = plane & 1][am0, ac0, am1, ac1]
+        // chunk k of the epilogue of plane dp (accumulators S), sixteen of them: 0..3 = tile 0's four channel groups (bias, relu, split)
+        // -> staging tile [column r][oc]; 4..7 = tile 0's four output stores, each fed by ONE 16-byte read of the staging tile that is
+        // requested in FRONT of the tap's MFMAs (epi_pre) and stored behind them (epi_post): no wait for the LDS; 8..11, 12..15 = tile 1
+        uint4 q4 = uint4{0, 0, 0, 0};
+        const int st_half = (lane >> 2) & 1, st_chunk = lane & 3;   // a store instruction writes whole 128-byte lines: for each of its two rows, four positions x [hi 64 B | lo' 64 B]
+        auto epi_pre = [&](int k) {
+            if ((k & 7) < 4) return;
+            if ((k & 7) == 4) {   // the tile's four groups are staged
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int j = (k & 7) - 4, ps = j >> 1, i = j & 1;
+            q4 = reinterpret_cast<const uint4 *>(stage)[st_half * 128 + ps * 64 + (lane >> 5) * 32 + (i * 4 + ((lane & 31) >> 3)) * 4 + st_chunk];
+        };
+        auto epi_post = [&](const f32x16 (&S)[4], int dp, int k) {
+            const int u = k >> 3, kk = k & 7;
+            if (kk < 4) {   // bias, relu, split; four consecutive channels per register group
+                const int qg = kk;
+                h4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float m = S[2 * u][qg * 4 + r], c = S[2 * u + 1][qg * 4 + r];
+                    float v = (m + c * (1.0f / kSplitScale)) + bias2[qg * 4 + r];
+                    v = v > 0.f ? v : 0.f;
+                    _Float16 a, l2;
+                    split16(v, a, l2, amax);
+                    hi[r] = a; lo[r] = l2;
+                }
+                const int oc0 = 8 * qg + 4 * (lane >> 5);
+                *reinterpret_cast<h4 *>(stage + col2 * 32 + oc0) = hi;
+                *reinterpret_cast<h4 *>(stage + 1024 + col2 * 32 + oc0) = lo;
+            } else {
+                // columns 8k .. 8k+7 of the tile are row (2u + (k >> 1) + 4 (k & 1)) of the plane: eight positions x 32 channels
+                // of the output; a position is one run of the interleaved layout [hi 32 | lo' 32] (k_dense.hip), 16 bytes per
+                // lane and pass, two rows per pass
+                const int j = kk - 4, ps = j >> 1, i = j & 1;
+                const int kq = ps * 2 + (lane >> 5);
+                const int row = 2 * u + (kq >> 1) + 4 * (kq & 1);
+                const int p = i * 4 + ((lane & 31) >> 3);
+                const size_t e = (size_t)(dp * 64 + row * 8 + p) * 64 + st_half * 32 + st_chunk * 8;   // halves
+#ifdef MMW_DIAG_CONV_NOSTORE
+                if (q4.x == 0x12345678u) *reinterpret_cast<uint4 *>(o + e) = q4;
+#else
+                *reinterpret_cast<uint4 *>(o + e) = q4;
+#endif
+                if (kk == 7) {   // the staging tile may be written again
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        };
 #pragma unroll
         for (int d = 0; d < NZ; d++) {
             const int pc0 = d * 100 + cell2, pc1 = pc0 + 20;
-            f32x16 am0, ac0, am1, ac1;
+            f32x16(&A)[4] = acc[d & 1];
 #pragma unroll
-            for (int r = 0; r < 16; r++) { am0[r] = 0.f; ac0[r] = 0.f; am1[r] = 0.f; ac1[r] = 0.f; }
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) A[q][r] = 0.f;
             // Software-pipelined over the plane's valid taps: the operands of tap k+1 are requested BEFORE the six MFMAs
             // of tap k are issued.
             h8 xh0, xl0, xh1, xl1, wlo;
@@ -451,6 +529,7 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 xh0 = Hh[i0]; xl0 = Hl[i0]; xh1 = Hh[i1]; xl1 = Hl[i1];
                 wlo = W2lo[t0 * 64 + lane];
             }
+            int kth = 0;   // (compile time: the loop is unrolled) how many valid taps of this plane have been issued
 #pragma unroll
             for (int tap = 0; tap < C::kTaps; tap++) {
                 if ((unsigned)(d + C::tap_kd(tap) - 1) >= (unsigned)NZ) continue;  // compile-time (d and tap are unrolled)
@@ -458,6 +537,9 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
 #pragma unroll
                 for (int tt = C::kTaps - 1; tt > tap; tt--) if ((unsigned)(d + C::tap_kd(tt) - 1) < (unsigned)NZ) nxt = tt;
                 h8 nh0 = xh0, nl0 = xl0, nh1 = xh1, nl1 = xl1, nw = wlo;
+#ifndef MMW_DIAG_CONV_NOEPI2
+                if (d > 0 && kth < 16) epi_pre(kth);   // (a store chunk's read of the staging tile: in front of the MFMAs)
+#endif
                 if (nxt >= 0) {
                     const int i0 = pc0 + C::tap_off(nxt), i1 = pc1 + C::tap_off(nxt);
                     nh0 = Hh[i0]; nl0 = Hl[i0]; nh1 = Hh[i1]; nl1 = Hl[i1];
@@ -465,59 +547,53 @@ __global__ __launch_bounds__(256, 1) void k_mars_conv16(const float *__restrict_
                 }
                 // (the scheduler must not pull tap k + 1's MFMAs up to their operands' loads: it would wait for the LDS there)
                 __builtin_amdgcn_sched_barrier(0);
-                am0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh0, am0, 0, 0, 0);
-                am1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh1, am1, 0, 0, 0);
-                ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl0, ac0, 0, 0, 0);
-                ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl1, ac1, 0, 0, 0);
-                ac0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh0, ac0, 0, 0, 0);
-                ac1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh1, ac1, 0, 0, 0);
+#ifdef MMW_DIAG_CONV_NOMFMA2
+                asm volatile("" ::"v"(xh0), "v"(xl0), "v"(xh1), "v"(xl1), "v"(wlo), "v"(w2hi[tap]));
+#else
+                A[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh0, A[0], 0, 0, 0);
+                A[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xh1, A[2], 0, 0, 0);
+                A[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl0, A[1], 0, 0, 0);
+                A[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2hi[tap], xl1, A[3], 0, 0, 0);
+                A[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh0, A[1], 0, 0, 0);
+                A[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh1, A[3], 0, 0, 0);
+#endif
+#ifndef MMW_DIAG_CONV_NOEPI2
+                if (d > 0 && kth < 16) {
+                    // ... and a chunk of the previous plane's epilogue BETWEEN them: a wave issues in order, so VALU work placed behind the
+                    // six MFMAs would start when the last of them does; the scheduler is told to deal it out, eight to an MFMA
+                    if ((kth & 7) >= 4) __builtin_amdgcn_sched_barrier(0);   // (a store chunk -- one store, which waits for its LDS read -- stays behind the MFMAs)
+                    epi_post(acc[(d - 1) & 1], d - 1, kth);
+                    if ((kth & 7) < 4) {
+#pragma unroll
+                        for (int g = 0; g < 6; g++) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                        }
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+                kth++;
                 xh0 = nh0; xl0 = nl0; xh1 = nh1; xl1 = nl1; wlo = nw;
             }
-            CSTAMP(3);  // conv2 MFMA loop
-            // epilogue: bias, relu, split; four consecutive channels per register group -> staging tile [column r][oc]
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-#pragma unroll
-                for (int qg = 0; qg < 4; qg++) {
-                    h4 hi, lo;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float m = u ? am1[qg * 4 + r] : am0[qg * 4 + r], c = u ? ac1[qg * 4 + r] : ac0[qg * 4 + r];
-                        float v = (m + c * (1.0f / kSplitScale)) + bias2[qg * 4 + r];
-                        v = v > 0.f ? v : 0.f;
-                        _Float16 a, l2;
-                        split16(v, a, l2, amax);
-                        hi[r] = a; lo[r] = l2;
-                    }
-                    const int oc0 = 8 * qg + 4 * (lane >> 5);
-                    *reinterpret_cast<h4 *>(stage + col2 * 32 + oc0) = hi;
-                    *reinterpret_cast<h4 *>(stage + 1024 + col2 * 32 + oc0) = lo;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // columns 8k .. 8k+7 of the tile are row (2u + (k >> 1) + 4 (k & 1)) of the plane: eight positions x 32 channels
-                // of the output; a position is one run of the interleaved layout [hi 32 | lo' 32] (k_dense.hip), 16 bytes per
-                // lane and pass, two rows per pass
-                const uint4 *sv = reinterpret_cast<const uint4 *>(stage);
-#pragma unroll
-                for (int ps = 0; ps < 2; ps++) {
-                    const int k = ps * 2 + (lane >> 5);
-                    const int row = 2 * u + (k >> 1) + 4 * (k & 1);
-                    // a store instruction writes whole 128-byte lines: for each of its two rows, four positions x [hi 64 B | lo' 64 B]
-                    const int half = (lane >> 2) & 1, chunk = lane & 3;
-#pragma unroll
-                    for (int i = 0; i < 2; i++) {
-                        const int p = i * 4 + ((lane & 31) >> 3);
-                        const size_t e = (size_t)(d * 64 + row * 8 + p) * 64 + half * 32 + chunk * 8;   // halves
-                        *reinterpret_cast<uint4 *>(o + e) = sv[half * 128 + ps * 64 + (lane >> 5) * 32 + p * 4 + chunk];
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            CSTAMP(4);  // conv2 epilogue + stores
+            CSTAMP(3);  // conv2 MFMA loop (+ the previous plane's epilogue)
         }
+#ifdef MMW_DIAG_CONV_NOEPI2
+        {
+            float keep = 0.f;
+#pragma unroll
+            for (int st = 0; st < 2; st++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) keep += acc[st][q][r];
+            if (keep == 12345.678f) o[lane] = (_Float16)keep;
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < 16; k++) { epi_pre(k); epi_post(acc[(NZ - 1) & 1], NZ - 1, k); }   // the last plane's, alone
+#endif
+        CSTAMP(4);  // last epilogue + stores
         // this sample's verdict: its keypoints are meaningless under the split arithmetic (the caller recomputes exactly these
         // samples in fp32: mars.MarsCNN.forward, mmw_mars_range_fixup)
         const bool bad = __any(over || !(amax < 65504.0f));
