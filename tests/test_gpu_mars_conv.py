@@ -136,6 +136,36 @@ def test_fused_dense1_kernel_vs_two_gemms_and_fp64(frames, n):
     assert bool(torch.isnan(hp[1]).all()) and not bool(torch.isnan(hp[0]).any()) and (n < 3 or torch.equal(hp[2:], hk[2:]))
 
 
+def test_cnn_kernels_repeat_bit_for_bit_under_load():
+    """The pipelined Dense-1 tile kernel and the conv kernel hand data between LDS-DMA requests, fragment reads and MFMAs on COUNTED
+    waits (csrc/k_dense.hip, k_mars.hip): a count off by one would read a tile that has not landed -- rarely, and only when the memory
+    system is slow.  The same batch 60 times on one stream while a second stream keeps the fabric busy with copies, a full chip of tiles
+    (31 744 rows) and a ragged one (8500): every repetition equals the first bit for bit (conv output, Dense-1 output, keypoints)."""
+    import torch
+    from mmwave_msc_amd.mars import MarsCNN, random_keras_weights
+    dev = torch.device("cuda:0")
+    mk = MarsCNN.from_keras_weights(random_keras_weights(5, 3)).to(dev)
+    noise_a = torch.empty(64 << 20, dtype=torch.float32, device=dev).normal_()
+    noise_b = torch.empty_like(noise_a)
+    side = torch.cuda.Stream(device=dev)
+    for n in (31744, 8500):
+        x = torch.from_numpy(_inputs(512, 3, 21)).to(dev).repeat((n + 511) // 512, 1, 1, 1, 1)[:n].contiguous()
+        with torch.no_grad():
+            a0 = mk._hip_convs_split(x)
+            h0 = mk._dense1_split(a0)
+            k0 = mk(x)
+            torch.cuda.synchronize()
+            for rep in range(60):
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        noise_b.copy_(noise_a)
+                a1 = mk._hip_convs_split(x)
+                h1 = mk._dense1_split(a1)
+                k1 = mk(x)
+                assert torch.equal(a1, a0) and torch.equal(h1, h0) and torch.equal(k1, k0), (n, rep)
+            torch.cuda.synchronize()
+
+
 def test_split_arithmetic_knows_fp16s_range():
     """fp16 holds |a| < 65 504: a weight beyond it sends the whole model to the fp32 kernels at load time; an input or an
     activation beyond it is noted PER SAMPLE by the conv kernel, and exactly those samples are computed again in fp32 on the
