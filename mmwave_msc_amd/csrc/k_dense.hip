@@ -14,21 +14,18 @@
 // corr += hi.W_lo', corr += lo'.W_hi): 1.5 MFMAs per fragment read from LDS instead of 0.5, half the activation traffic,
 // bias + merge + ReLU in the epilogue.
 //
-// Geometry: workgroup = 512 threads = 8 waves as 4 (M) x 2 (N), tile 256 (batch rows) x 128 (features), K-step 32; a wave owns
-// 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_f16 with TWO accumulator sets (main, corr: 128 VGPRs).  Operand tiles go
-// global -> LDS by the DMA path (global_load_lds, 16 B per lane, no staging registers) into buffers of 48 KB: A (256 rows x
-// 128 B = hi | lo') and W (128 rows x 128 B).  The LDS image of a tile is lane-linear (what the DMA writes), so the bank
-// swizzle is applied to the SOURCE address: 16-byte unit c of row r lives in slot r * 8 + (c ^ ((r >> 1) & 7)) -- the 16 lanes
-// the LDS serves together read 16 different bank groups.  Three such buffers form a ring: one raw barrier per K-step
-// with a counted vmcnt, two tiles' DMA in flight across it.
+// Geometry: workgroup = 512 threads = 8 waves, tiles of 256 or 128 batch rows x 192 or 128 features (k_mars_dense1_t below), K-step 32; a
+// wave owns 64 rows x 32 NT features = 2 x NT tiles of v_mfma_f32_32x32x16_f16 with TWO accumulator sets (main, corr).  Operand tiles go
+// global -> LDS by the DMA path (global_load_lds, 16 B per lane, no staging registers): A (rows x 128 B = hi | lo') and W (features x
+// 128 B).  The LDS image of a tile is lane-linear (what the DMA writes), so the bank swizzle is applied to the SOURCE address: 16-byte
+// unit c of row r lives in slot r * 8 + (c ^ ((r >> 1) & 7)) -- the 16 lanes the LDS serves together read 16 different bank groups.
+// The tiles form rings in LDS (three A slots; three W slots, two for the 192-wide tile): one raw barrier per K-step with a counted
+// vmcnt, two tiles' requests in flight across it.
 // Rows are padded to the tile by the caller (mars.py allocates whole tiles; a pad row only feeds its own output row).
-// What bounds it (measured, 18 304 x 6144 x 1536): not the matrix cores -- with the DMA switched off the loop runs at 1320 TF
-// issued, with the MFMAs switched off the staging alone takes 0.88 of the 1.12 ms: the 8.1 GB a 256 x 128 tile moves from L2
-// to LDS (two accumulator sets cap the tile: 256 x 256 needs 256 accumulator registers per lane at 2 waves per SIMD).  The two
-// library GEMMs move the same bytes and take the same time.  Whole 128-byte lines per row (this layout) and an activation row
-// stride that is not a multiple of 4 KB (mars.py) are worth 6 % and 4 %.  (One accumulator set -- main scaled by 2^11 through a
-// third weight array -- allows 256 x 256 tiles: 0.97 instead of 1.05 ms, but three roundings of the accumulator per K-step
-// instead of one made the keypoints less accurate than the fp32 path's on the stress inputs: measured, not kept.)
+// Whole 128-byte lines per row (this layout) and an activation row stride that is not a multiple of 4 KB (mars.py) are worth 6 % and
+// 4 %.  (One accumulator set -- main scaled by 2^11 through a third weight array -- allows 256 x 256 tiles: 0.97 instead of 1.05 ms, but
+// three roundings of the accumulator per K-step instead of one made the keypoints less accurate than the fp32 path's on the stress
+// inputs: measured, not kept.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
@@ -42,26 +39,15 @@ typedef float df16 __attribute__((ext_vector_type(16)));
 namespace dense {
 constexpr int BM = 256, BN = 128, BK = 32, kThreads = 512;
 constexpr int kRowBytes = BK * 2 * 2;              // 128 B of a tile row: hi (64 B) | lo' (64 B)
-constexpr int kWTile = BN * kRowBytes;             // 16 KB
-constexpr int kStages = 3;                          // LDS ring: the tile in use + two in flight
-// TBM = batch rows of a tile: 256 (8 waves as 4 x 2, a wave owns 64 x 64), or 128 for the tail of the tile list (8 waves as
-// 2 x 4, a wave owns 64 x 32): a last wave of workgroups that fills less than half the chip runs as twice as many half tiles
-constexpr int a_tile(int tbm) { return tbm * kRowBytes; }                         // 32 / 16 KB
-constexpr int buf_bytes(int tbm) { return a_tile(tbm) + kWTile; }                 // 48 / 32 KB per K-step
-constexpr int lds_bytes(int tbm) { return kStages * buf_bytes(tbm); }             // 144 / 96 KB
 constexpr float kInvSplit = 1.0f / 2048.0f;
 
 // 16-byte unit (row, c) of a tile image -> byte offset (c = 0..7: the row's eight units, 0..3 = hi, 4..7 = lo')
 __device__ __forceinline__ int unit_off(int row, int c) { return (row * 8 + (c ^ ((row >> 1) & 7))) * 16; }
 
-__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0,
-                                     0);
-}
-// The same request as ONE asm statement (m0 = the wave's destination, uniform base + 32-bit lane offset).  Why not the builtin: with an
-// LDS-DMA instruction in flight the compiler's wait counting gives up on the LDS counter -- every wait for a fragment becomes
-// `s_waitcnt lgkmcnt(0)`, i.e. for ALL requested fragments, also those asked for on purpose a phase ahead (k_mars_dense1_w192).
+// An LDS-DMA request (global -> LDS, 16 B per lane, no staging registers) as ONE asm statement: m0 = the wave's destination, uniform base +
+// 32-bit lane offset.  Why not __builtin_amdgcn_global_load_lds: with an LDS-DMA instruction in flight the compiler's wait counting gives
+// up on the LDS counter -- every wait for a fragment becomes `s_waitcnt lgkmcnt(0)`, i.e. for ALL requested fragments, also those asked
+// for on purpose a phase ahead.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void glds16_asm(const void *ubase, unsigned voff, void *lds_wave_base)
@@ -74,126 +60,16 @@ __device__ __forceinline__ void glds16_asm(const void *ubase, unsigned voff, voi
 
 using namespace dense;
 
-template <int TBM>
-__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
-                                                             long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
-                                                             long long row0, int tiles_n)
-{
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int WN = TBM == 256 ? 2 : 4;          // waves along the features; 8 / WN along the batch rows, 64 rows each
-    constexpr int NT = BN / WN / 32;                 // MFMA tiles of a wave along the features (2 or 1); two along the rows
-    constexpr int CA = TBM / 64;                     // DMA chunks of the A tile per wave (4 or 2); the W tile: 2
-    constexpr int kATile = a_tile(TBM), kBuf = buf_bytes(TBM);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: see k_mars_dense1_w192)
-    const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: workgroups are dealt to the eight XCDs round-robin; a group of consecutive LOGICAL tiles (one band of
-    // batch rows against all feature tiles) goes to one XCD, whose L2 then serves the band's activations to every tile of it
-    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long long m0 = row0 + (long long)tm * TBM;
-    const int n0 = tn * BN;
-    // ---- this lane's share of a tile's DMA: unit u = chunk * 64 + lane of an operand tile; chunk = one wave instruction ----
-    // A: TBM / 8 chunks (8 waves x CA); W: 16 chunks (8 waves x 2).  A K-step advances every source by 64 halves (hi 32 | lo' 32).
-    const _Float16 *srcA[CA], *srcW[2];
-#pragma unroll
-    for (int i = 0; i < CA; i++) {
-        const int u = (wave * CA + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
-        srcA[i] = a2 + (m0 + row) * lda + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int u = (wave * 2 + i) * 64 + lane, row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
-        srcW[i] = w2 + (long long)(n0 + row) * ldw + c * 8;
-    }
-    auto issue = [&](int kt, int buf) {
-        char *b = lds + buf * kBuf;
-        const int k0 = kt * (2 * BK);
-#pragma unroll
-        for (int i = 0; i < CA; i++) glds16(srcA[i] + k0, b + (wave * CA + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < 2; i++) glds16(srcW[i] + k0, b + kATile + (wave * 2 + i) * 1024);
-    };
-    // ---- fragment addresses: lane (row = l & 31, k-group g = l >> 5) reads unit c = 2 kk + g (hi) and 4 + 2 kk + g (lo') ----
-    int offA[2][2], offW[NT][2];   // [tile][kk]
-#pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-#pragma unroll
-        for (int x = 0; x < 2; x++) offA[x][kk] = unit_off(wm * 64 + x * 32 + (lane & 31), kk * 2 + (lane >> 5));
-#pragma unroll
-        for (int y = 0; y < NT; y++) offW[y][kk] = unit_off(wn * (32 * NT) + y * 32 + (lane & 31), kk * 2 + (lane >> 5));
-    }
-    df16 am[2][NT], ac[2][NT];
-#pragma unroll
-    for (int x = 0; x < 2; x++)
-#pragma unroll
-        for (int y = 0; y < NT; y++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-    // Three LDS buffers, ONE barrier per K-step: tile kt + 2 is requested into the buffer tile kt - 1 was read from, which every
-    // wave has left once it has passed this step's barrier; two tiles stay in flight behind the one in use (vmcnt(6) retires
-    // tile kt while tile kt + 1 is still landing).  The fragments of the next 16-deep half step are requested before the
-    // twelve MFMAs of the current one.
-    const int KT = K / BK;
-    issue(0, 0);
-    if (KT > 1) issue(1, 1);
-    int cur = 0;
-    for (int kt = 0; kt < KT; kt++) {
-        if (kt + 1 < KT) {                                                   // tile kt has landed (this wave's share: CA + 2 requests per tile)
-            if constexpr (CA == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                        // ... everyone's share; buffer of tile kt - 1 is free
-        asm volatile("" ::: "memory");
-        const int nxt2 = cur >= 1 ? cur - 1 : kStages - 1;                   // (cur + 2) % 3
-        if (kt + 2 < KT) issue(kt + 2, nxt2);
-        const char *b = lds + cur * kBuf;
-        dh8 ah[2][2], al[2][2], wh[2][NT], wl[2][NT];   // [kk][tile]
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-#pragma unroll
-            for (int x = 0; x < 2; x++) {
-                ah[kk][x] = *reinterpret_cast<const dh8 *>(b + offA[x][kk]);
-                al[kk][x] = *reinterpret_cast<const dh8 *>(b + (offA[x][kk] ^ 64));
-            }
-#pragma unroll
-            for (int y = 0; y < NT; y++) {
-                wh[kk][y] = *reinterpret_cast<const dh8 *>(b + kATile + offW[y][kk]);
-                wl[kk][y] = *reinterpret_cast<const dh8 *>(b + kATile + (offW[y][kk] ^ 64));
-            }
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-            for (int x = 0; x < 2; x++)
-#pragma unroll
-                for (int y = 0; y < NT; y++) {
-                    am[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][x], wh[kk][y], am[x][y], 0, 0, 0);
-                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk][x], wl[kk][y], ac[x][y], 0, 0, 0);
-                    ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk][x], wh[kk][y], ac[x][y], 0, 0, 0);
-                }
-        __builtin_amdgcn_s_setprio(0);
-        cur = cur + 1 == kStages ? 0 : cur + 1;
-    }
-    // ---- epilogue: D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]; a register of the 64 lanes = two rows x 128 B ----
-#pragma unroll
-    for (int y = 0; y < NT; y++) {
-        const int col = n0 + wn * (32 * NT) + y * 32 + (lane & 31);
-        const float bv = bias[col];
-#pragma unroll
-        for (int x = 0; x < 2; x++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const long long row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (am[x][y][r] + ac[x][y][r] * kInvSplit) + bv;
-                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);   // relu that keeps NaN (as torch's)
-            }
-        }
-    }
-}
-
+// ONE kernel template for the three tile shapes (TBM batch rows x BN = WN * 32 * NT features; 8 waves as (8 / WN) x WN, a wave owns 64 rows
+// x 32 NT features = 2 x NT MFMA tiles, two accumulator sets):
+//   <256, 2, 3, 2>  256 x 192, feature counts that are a multiple of 192 (define_CNN_3D: 1536): three A slots and TWO W slots in 144 KB
+//                   (W requested one K-step ahead; a third slot does not fit);
+//   <256, 2, 2, 3>  256 x 128, the other feature counts (define_CNN: 512); three slots each, 144 KB;
+//   <128, 4, 1, 3>  128 x 128, the tail of the tile list (a last wave of workgroups that fills less than half the chip runs as twice as
+//                   many half tiles); 96 KB.
 // ---- 256 x 192 tiles, for feature counts that are a multiple of 192 (define_CNN_3D: 1536): fewer bytes from L2 per
 //      multiply-add (56 KB per K-step for 1.5 x the work of the 48 KB of a 256 x 128 tile) and a third fewer workgroups.  Two
 //      accumulator sets of a 64 x 96 wave tile are 192 of the 256 registers a lane has at two waves per SIMD; the LDS holds a
@@ -215,53 +91,59 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1(const _Float16 *__r
 //      (the MFMA-only build at ~2.3): with all three units busy the clock, not a unit, is what gives.  Every request an L2 hit
 //      (operands from a 1 MB footprint) was worth 5 %, weights requested two K-steps ahead instead of one 2.5 %, a wave that only
 //      touches lines six steps ahead -5 % (slower): the fabric's latency is covered. ----
-namespace dense192 {
-constexpr int BN2 = 192;
-constexpr int kA = 256 * kRowBytes, kW = BN2 * kRowBytes;   // 32 KB, 24 KB
-constexpr int kLds = 3 * kA + 2 * kW;                        // 144 KB
-}
-__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
-                                                                   long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
-                                                                   int tiles_n)
+template <int TBM, int WN, int NT, int WS>
+__global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_t(const _Float16 *__restrict__ a2, long long lda, const _Float16 *__restrict__ w2,
+                                                               long long ldw, const float *__restrict__ bias, float *__restrict__ out, int K, int N,
+                                                               long long row0, int tiles_n)
 {
-    using namespace dense192;
+    constexpr int BNT = WN * 32 * NT;                  // features of a tile
+    constexpr int CA = TBM / 64, CW = BNT / 64;       // this wave's 1 KB pieces of an A tile / a W tile
+    constexpr int kA = TBM * kRowBytes, kW = BNT * kRowBytes;
+    constexpr int kWLead = WS == 3 ? 3 : 2;           // W(j + kWLead) is requested in stretch j (A: always j + 3)
+    static_assert(TBM == 64 * (8 / WN) && (WS == 2 || WS == 3) && CA + CW <= 4 * NT, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: ring slots, tile origins and DMA destinations stay out of the VGPRs)
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt to the eight XCDs round-robin; a group of consecutive LOGICAL tiles (one band of
+    // batch rows against all feature tiles) goes to one XCD, whose L2 then serves the band's activations to every tile of it
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int tm = t / tiles_n, tn = t - tm * tiles_n;
-    const long long m0 = (long long)tm * 256;
-    const int n0 = tn * BN2;
-    // this wave's pieces of a tile (1 KB = 8 rows x 128 B each): A pieces wave * 4 + i, W pieces wave * 3 + i.  A piece's source is a
+    const long long m0 = row0 + (long long)tm * TBM;
+    const int n0 = tn * BNT;
+    // this wave's pieces of a tile (1 KB = 8 rows x 128 B each): A pieces wave * CA + i, W pieces wave * CW + i.  A piece's source is a
     // uniform base + i * 8 rows + one of TWO per-lane offsets (the swizzle of rows 8 p + r depends on p's parity only): four VGPRs
-    // instead of seven 64-bit pointers -- the fragment double buffer needs the registers
+    // instead of a 64-bit pointer per piece -- the fragment double buffer needs the registers
     const int rr = lane >> 3, c0 = (lane & 7) ^ (rr >> 1);
     const int ldA = (int)lda, ldW = (int)ldw;
+    const int pbW = (wave * CW) & 1;   // parity of this wave's first W piece (CA is even: its first A piece is an even one)
     const unsigned vA0 = (unsigned)((rr * ldA + c0 * 8) * 2), vA1 = (unsigned)((rr * ldA + (c0 ^ 4) * 8) * 2);
-    const unsigned vW0 = (unsigned)((rr * ldW + (c0 ^ ((wave & 1) * 4)) * 8) * 2), vW1 = (unsigned)((rr * ldW + (c0 ^ ((~wave & 1) * 4)) * 8) * 2);   // (W piece wave * 3 + i: parity (wave + i) & 1)
-    const char *const uA = reinterpret_cast<const char *>(a2 + (m0 + wave * 32) * lda), *const uW = reinterpret_cast<const char *>(w2 + (long long)(n0 + wave * 24) * ldw);
-    char *const dA = lds + wave * 4 * 1024, *const dW = lds + 3 * kA + wave * 3 * 1024;
+    const unsigned vW0 = (unsigned)((rr * ldW + (c0 ^ (pbW * 4)) * 8) * 2), vW1 = (unsigned)((rr * ldW + (c0 ^ ((pbW ^ 1) * 4)) * 8) * 2);
+    const char *const uA = reinterpret_cast<const char *>(a2 + (m0 + wave * (8 * CA)) * lda),
+               *const uW = reinterpret_cast<const char *>(w2 + (long long)(n0 + wave * (8 * CW)) * ldw);
+    char *const dA = lds + wave * CA * 1024, *const dW = lds + 3 * kA + wave * CW * 1024;
 #ifdef MMW_DIAG_DENSE_NODMA   // (timing-only builds, scripts/ab_dense.sh: no requests / MMW_DIAG_DENSE_NOLDS: no fragment reads / _NOBAR: no barrier)
 #define glds16_asm(a, b, c) ((void)0)
 #endif
     auto pieceA = [&](int i, int kt, int slot) { glds16_asm(uA + ((long long)i * 16 * ldA + (long long)kt * (4 * BK)), (i & 1) ? vA1 : vA0, dA + slot * kA + i * 1024); };
     auto pieceW = [&](int i, int kt, int slot) { glds16_asm(uW + ((long long)i * 16 * ldW + (long long)kt * (4 * BK)), (i & 1) ? vW1 : vW0, dW + slot * kW + i * 1024); };
-    const int offA0 = unit_off(wm * 64 + (lane & 31), lane >> 5), offW0 = unit_off(wn * 96 + (lane & 31), lane >> 5);
-    df16 am[2][3], ac[2][3];
+    const int offA0 = unit_off(wm * 64 + (lane & 31), lane >> 5), offW0 = unit_off(wn * (32 * NT) + (lane & 31), lane >> 5);
+    df16 am[2][NT], ac[2][NT];
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
-        for (int y = 0; y < 3; y++)
+        for (int y = 0; y < NT; y++)
 #pragma unroll
             for (int r = 0; r < 16; r++) { am[x][y][r] = 0.f; ac[x][y][r] = 0.f; }
-    dh8 wh[3], wl[3], ab[2][2];   // weight fragments of the half step in hand; activation fragments [buffer][hi, lo']
+    dh8 wh[NT], wl[NT], ab[2][2];   // weight fragments of the half step in hand; activation fragments [buffer][hi, lo']
 #ifdef MMW_DIAG_DENSE_NOLDS
-    for (int y = 0; y < 3; y++) { wh[y] = dh8{1, 1, 1, 1, 1, 1, 1, 1}; wl[y] = wh[y]; }
+    for (int y = 0; y < NT; y++) { wh[y] = dh8{1, 1, 1, 1, 1, 1, 1, 1}; wl[y] = wh[y]; }
     ab[0][0] = ab[0][1] = ab[1][0] = ab[1][1] = wh[0];
     auto LA = [&](int, const char *, int, int) {};
     auto LW = [&](const char *, int, int) {};
 #else
+    // lane (row = l & 31, k-group g = l >> 5) reads unit c = 2 kk + g (hi) and 4 + 2 kk + g (lo'): one register per operand -- tile x / y is
+    // 32 rows = 4096 bytes further, the second half step (kk = 1) flips bit 5 of the offset (unit c ^ 2), lo' bit 6
     auto LA = [&](int buf, const char *ba, int kk, int x) {
         ab[buf][0] = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32)) + x * 4096));
         ab[buf][1] = *reinterpret_cast<const dh8 *>(ba + ((offA0 ^ (kk * 32) ^ 64) + x * 4096));
@@ -279,22 +161,27 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
         ac[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[buf][1], wh[y], ac[x][y], 0, 0, 0);       \
     } while (0)
     const int KT = K / BK;
-    // requests in the order the counted waits rely on: ... W(kt), A(kt + 1) | W(kt + 1), A(kt + 2) | ...
-    pieceW(0, 0, 0); pieceW(1, 0, 0); pieceW(2, 0, 0);
+    // requests in the order the counted waits rely on.  Two W slots:  W(0) A(0) | A(1) W(1) | A(2), then per stretch W(j + 2) A(j + 3);
+    // three: W(0) A(0) | W(1) A(1) | W(2) A(2), then per stretch W(j + 3) A(j + 3)
+    auto tileW = [&](int kt, int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) pieceA(i, 0, 0);
+        for (int i = 0; i < CW; i++) pieceW(i, kt, slot);
+    };
+    auto tileA = [&](int kt, int slot) {
+#pragma unroll
+        for (int i = 0; i < CA; i++) pieceA(i, kt, slot);
+    };
+    tileW(0, 0); tileA(0, 0);
     if (KT > 1) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) pieceA(i, 1, 1);
-        pieceW(0, 1, 1); pieceW(1, 1, 1); pieceW(2, 1, 1);
+        if (WS == 3) { tileW(1, 1); tileA(1, 1); } else { tileA(1, 1); tileW(1, 1); }
     }
     if (KT > 2) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) pieceA(i, 2, 2);
+        if (WS == 3) tileW(2, 2);
+        tileA(2, 2);
     }
-    if (KT > 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else if (KT > 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (KT > 2) wait_vmcnt<WS == 3 ? 2 * (CA + CW) : 2 * CA + CW>();
+    else if (KT > 1) wait_vmcnt<CA + CW>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     int sa = 0, sw = 0;   // ring slots of the tile in hand
@@ -302,32 +189,38 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
         const char *ba = lds, *bw = lds + 3 * kA;
         LA(0, ba, 0, 0);
 #pragma unroll
-        for (int y = 0; y < 3; y++) LW(bw, 0, y);
+        for (int y = 0; y < NT; y++) LW(bw, 0, y);
         __builtin_amdgcn_sched_barrier(0);
         LA(1, ba, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int y = 0; y < 3; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
+        for (int y = 0; y < NT; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
         LA(0, ba, 1, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int y = 0; y < 3; y++) { MMW_MF(1, 1, y); __builtin_amdgcn_sched_barrier(0); LW(bw, 1, y); __builtin_amdgcn_sched_barrier(0); }
+        for (int y = 0; y < NT; y++) { MMW_MF(1, 1, y); __builtin_amdgcn_sched_barrier(0); LW(bw, 1, y); __builtin_amdgcn_sched_barrier(0); }
         LA(1, ba, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int y = 0; y < 3; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
+        for (int y = 0; y < NT; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
     }
     // One barrier-to-barrier stretch: the last phase of tile j, then -- if there is a tile j + 1 -- its first three.  MORE1..3 = "tiles
     // j + 1, j + 2, j + 3 exist" as COMPILE-TIME flags (the steady state is straight-line code; the last three stretches are
     // instantiated separately): at a join of two paths the compiler's wait counting falls back to lgkmcnt(0).
+    // The stretch's requests -- CW pieces of W, then CA of A -- go one per feature block into its 4 NT gaps between MFMA groups.
     auto stretch = [&](auto M1, auto M2, auto M3, int j) {
         constexpr bool more1 = decltype(M1)::value, more2 = decltype(M2)::value, more3 = decltype(M3)::value;
+        constexpr bool moreW = kWLead == 3 ? more3 : more2;
         // here: every read of tile j has been requested (its last phase's operands are in, or on their way to, registers)
-        const int sa1 = sa + 1 == 3 ? 0 : sa + 1, sw1 = sw ^ 1;   // slots of tile j + 1; tile j's own become those of A(j + 3), W(j + 2)
+        const int sa1 = sa + 1 == 3 ? 0 : sa + 1, sw1 = sw + 1 == WS ? 0 : sw + 1;   // slots of tile j + 1; tile j's own become those of A(j + 3), W(j + kWLead)
         const char *ba = lds + sa1 * kA, *bw = lds + 3 * kA + sw1 * kW;
+        auto request = [&](int q) {   // q-th gap of the stretch (compile time)
+            if (q < CW) { if constexpr (moreW) pieceW(q, j + kWLead, sw); }
+            else if (q < CW + CA) { if constexpr (more3) pieceA(q - CW, j + 3, sa); }
+        };
         if constexpr (more1) {
-            if constexpr (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // W(j + 1) and everything before it; A(j + 2) stays in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (more2) wait_vmcnt<WS == 3 ? CA + CW : CA>();   // tile j + 1 and everything before it; the requests of the stretch before stay in flight
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's reads of tile j have arrived, its buffers may be refilled (the
                                                   // builtin, not asm: the compiler's own wait counting must see it)
 #ifndef MMW_DIAG_DENSE_NOBAR
@@ -336,15 +229,15 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
             asm volatile("" ::: "memory");
         }
         __builtin_amdgcn_s_setprio(1);
-        // ---- last phase of tile j (registers only) | first reads of tile j + 1 | requests W(j + 2), then A(j + 3) ----
+        // ---- last phase of tile j (registers only) | first reads of tile j + 1 | the stretch's first requests ----
         if constexpr (more1) LA(0, ba, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int y = 0; y < 3; y++) {
+        for (int y = 0; y < NT; y++) {
             MMW_MF(1, 1, y);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (more1) LW(bw, 0, y);
-            if constexpr (more2) pieceW(y, j + 2, sw);
+            request(y);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (more1) {
@@ -352,27 +245,35 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
             LA(1, ba, 0, 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int y = 0; y < 3; y++) {
+            for (int y = 0; y < NT; y++) {
                 MMW_MF(0, 0, y);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more3) pieceA(y, j + 3, sa);
+                request(NT + y);
                 __builtin_amdgcn_sched_barrier(0);
             }
             LA(0, ba, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int y = 0; y < 3; y++) {
+            for (int y = 0; y < NT; y++) {
                 MMW_MF(1, 1, y);
                 __builtin_amdgcn_sched_barrier(0);
                 LW(bw, 1, y);
-                if constexpr (more3) { if (y == 0) pieceA(3, j + 3, sa); }
+                request(2 * NT + y);
                 __builtin_amdgcn_sched_barrier(0);
             }
             LA(1, ba, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int y = 0; y < 3; y++) { MMW_MF(0, 0, y); __builtin_amdgcn_sched_barrier(0); }
+            for (int y = 0; y < NT; y++) {
+                MMW_MF(0, 0, y);
+                __builtin_amdgcn_sched_barrier(0);
+                request(3 * NT + y);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             sa = sa1; sw = sw1;
+        } else {
+#pragma unroll
+            for (int q = NT; q < CW + CA; q++) request(q);   // (nothing: no tile j + 3 without a tile j + 1)
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -387,9 +288,10 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
 #ifdef MMW_DIAG_DENSE_NODMA
 #undef glds16_asm
 #endif
+    // ---- epilogue: D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]; a register of the 64 lanes = two rows x 128 B ----
 #pragma unroll
-    for (int y = 0; y < 3; y++) {
-        const int col = n0 + wn * 96 + y * 32 + (lane & 31);
+    for (int y = 0; y < NT; y++) {
+        const int col = n0 + wn * (32 * NT) + y * 32 + (lane & 31);
         const float bv = bias[col];
 #pragma unroll
         for (int x = 0; x < 2; x++) {
@@ -397,7 +299,7 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
             for (int r = 0; r < 16; r++) {
                 const long long row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const float v = (am[x][y][r] + ac[x][y][r] * kInvSplit) + bv;
-                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);
+                out[row * N + col] = v > 0.f ? v : (v != v ? v : 0.f);   // relu that keeps NaN (as torch's)
             }
         }
     }
@@ -407,6 +309,9 @@ __global__ __launch_bounds__(kThreads, 1) void k_mars_dense1_w192(const _Float16
 // The tile list is cut where its last wave of workgroups would fill less than half the chip: bands of 256 rows that make whole
 // waves go to the 256-row instantiation, the rest -- as twice as many 128-row tiles -- to the other (18 304 rows x 1536: 864
 // tiles = 3 waves + 96 tiles on 256 CUs; the 96 become 192 half tiles: 3.5 tile-times instead of 4).
+constexpr int kLds192 = 3 * 256 * kRowBytes + 2 * 192 * kRowBytes;   // 144 KB: three A slots, two W slots
+constexpr int kLds256 = 3 * (256 + 128) * kRowBytes;                  // 144 KB
+constexpr int kLds128 = 3 * (128 + 128) * kRowBytes;                  // 96 KB
 int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long ldw, const float *bias, float *out, int rows_padded, int K, int N,
                        hipStream_t stream)
 {
@@ -418,9 +323,9 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
     DevPrep &P = g_prep[dev];
     std::call_once(P.once, [&]() {
-        if (hipFuncSetAttribute((const void *)k_mars_dense1<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(256)) != hipSuccess) return;
-        if (hipFuncSetAttribute((const void *)k_mars_dense1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(128)) != hipSuccess) return;
-        if (hipFuncSetAttribute((const void *)k_mars_dense1_w192, hipFuncAttributeMaxDynamicSharedMemorySize, dense192::kLds) != hipSuccess) return;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1_t<256, 2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds192) != hipSuccess) return;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1_t<256, 2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds256) != hipSuccess) return;
+        if (hipFuncSetAttribute((const void *)k_mars_dense1_t<128, 4, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds128) != hipSuccess) return;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) P.n_cu = prop.multiProcessorCount;
         P.ok = true;
@@ -437,8 +342,8 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
         if (2LL * (bands - bands_main) * tiles_n > n_cu) bands_main = bands;   // (the remainder would be more than one wave of half tiles)
     }
     const _Float16 *A = reinterpret_cast<const _Float16 *>(a2), *W = reinterpret_cast<const _Float16 *>(w2);
-    if (N % dense192::BN2 == 0) {   // 256 x 192 tiles for the whole waves of workgroups, the rest as below
-        const int tn2 = N / dense192::BN2;
+    if (N % 192 == 0) {   // 256 x 192 tiles for the whole waves of workgroups, the rest as below
+        const int tn2 = N / 192;
         const long long total2 = (long long)bands * tn2, rem2 = total2 % n_cu;
         int bm2 = bands;
         if (rem2 != 0 && 2 * rem2 <= n_cu) {   // the last wave of workgroups would fill less than half the chip: cut it off at a band boundary
@@ -446,17 +351,17 @@ int launch_mars_dense1(const void *a2, long long lda, const void *w2, long long 
             if (2LL * (bands - bm2) * tiles_n > n_cu) bm2 = bands;   // (... unless the rest is more than one wave of 128 x 128 half tiles)
         }
         if (bm2 > 0)
-            hipLaunchKernelGGL(k_mars_dense1_w192, dim3(bm2 * tn2), dim3(kThreads), dense192::kLds, stream, A, lda, W, ldw, bias, out, K, N, tn2);
+            hipLaunchKernelGGL((k_mars_dense1_t<256, 2, 3, 2>), dim3(bm2 * tn2), dim3(kThreads), kLds192, stream, A, lda, W, ldw, bias, out, K, N, 0LL, tn2);
         if (bm2 < bands)
-            hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * (bands - bm2) * tiles_n), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias, out, K,
+            hipLaunchKernelGGL((k_mars_dense1_t<128, 4, 1, 3>), dim3(2 * (bands - bm2) * tiles_n), dim3(kThreads), kLds128, stream, A, lda, W, ldw, bias, out, K,
                                N, (long long)bm2 * BM, tiles_n);
         return 0;
     }
     if (bands_main > 0)
-        hipLaunchKernelGGL(k_mars_dense1<256>, dim3(bands_main * tiles_n), dim3(kThreads), lds_bytes(256), stream, A, lda, W, ldw, bias, out, K, N, 0LL,
+        hipLaunchKernelGGL((k_mars_dense1_t<256, 2, 2, 3>), dim3(bands_main * tiles_n), dim3(kThreads), kLds256, stream, A, lda, W, ldw, bias, out, K, N, 0LL,
                            tiles_n);
     if (bands_main < bands)
-        hipLaunchKernelGGL(k_mars_dense1<128>, dim3(2 * (bands - bands_main) * tiles_n), dim3(kThreads), lds_bytes(128), stream, A, lda, W, ldw, bias,
+        hipLaunchKernelGGL((k_mars_dense1_t<128, 4, 1, 3>), dim3(2 * (bands - bands_main) * tiles_n), dim3(kThreads), kLds128, stream, A, lda, W, ldw, bias,
                            out, K, N, (long long)bands_main * BM, tiles_n);
     return 0;
 }

@@ -176,30 +176,33 @@ def test_gate_records_are_not_read_before_the_scalar_cache_invalidate():
 
 
 def test_dense1_tile_kernel_keeps_its_pipeline():
-    """k_mars_dense1_w192 (csrc/k_dense.hip) is software-pipelined by hand and only works as built if the compiler keeps three
-    properties, read here from its report and ISA: (1) no scratch at 250-odd VGPRs and two waves per SIMD -- a spill's reload is an
-    `s_waitcnt vmcnt(0)` in the middle of the counted waits for the LDS-DMA pieces; (2) the fragment waits of the steady-state loop
+    """k_mars_dense1_t (csrc/k_dense.hip; three tile shapes) is software-pipelined by hand and only works as built if the compiler keeps
+    three properties, read here from its report and ISA: (1) no scratch at up to 250 VGPRs and two waves per SIMD -- a spill's reload is
+    an `s_waitcnt vmcnt(0)` in the middle of the counted waits for the LDS-DMA pieces; (2) the fragment waits of the steady-state loop
     are COUNTED (lgkmcnt(6) ...: fragments are requested a phase ahead and must not be waited for as a block -- what the compiler
     did to every wait while the requests were the LDS-DMA builtin); (3) between the barrier of a K-step and the first MFMA that
     follows it there is no LDS wait at all (that phase's operands are in registers)."""
     import re
     rep, asm = _device_isa(("k_dense",))["k_dense"]
-    rows = [k for k in _kernel_report(rep) if "k_mars_dense1_w192" in k[0]]
-    assert len(rows) == 1, [k[0] for k in _kernel_report(rep)]
-    name, scratch, vspill, vgprs, occ, sspill = rows[0]
-    assert scratch == 0 and vspill == 0 and sspill == 0 and vgprs <= 256 and occ == 2, rows[0]
-    body = asm[asm.index("\n" + name + ":"):]
-    body = body[: body.index("s_endpgm")]
-    assert "scratch_" not in body
-    # the steady-state loop: the basic block with the back edge that holds 36 MFMAs and one barrier
-    blocks = re.split(r"\n\.LBB\d+_\d+:", body)
-    loops = [b for b in blocks if b.count("v_mfma_f32_32x32x16_f16") == 36 and b.count("s_barrier") == 1 and b.count("global_load_lds_dwordx4") == 7]
-    assert loops, [(b.count("v_mfma"), b.count("s_barrier")) for b in blocks]
-    for b in loops:
-        waits = re.findall(r"s_waitcnt lgkmcnt\((\d+)\)", b)
-        assert waits.count("0") == 1 and len(waits) >= 6 and max(int(w) for w in waits) >= 6, waits   # the one lgkmcnt(0) stands in front of the barrier
-        bar = b.index("s_barrier")
-        assert b.rfind("s_waitcnt lgkmcnt(0)", 0, bar) > 0
-        first_mfma = b.index("v_mfma_f32_32x32x16_f16", bar)
-        assert "s_waitcnt lgkmcnt" not in b[bar:first_mfma], b[bar:first_mfma]
-        assert re.search(r"s_waitcnt vmcnt\(4\)", b[:bar])
+    # (mangled template arguments: TBM, WN, NT, W slots) -> MFMAs and LDS-DMA pieces of a K-step per wave, pieces in flight across the barrier
+    shapes = {"ILi256ELi2ELi3ELi2EE": (36, 7, 4), "ILi256ELi2ELi2ELi3EE": (24, 6, 6), "ILi128ELi4ELi1ELi3EE": (12, 4, 4)}
+    rows = {k[0]: k for k in _kernel_report(rep) if "k_mars_dense1_t" in k[0]}
+    assert len(rows) == 3, list(rows)
+    for name, (_, scratch, vspill, vgprs, occ, sspill) in rows.items():
+        n_mfma, n_dma, vm = next(v for k, v in shapes.items() if k in name)
+        assert scratch == 0 and vspill == 0 and sspill == 0 and vgprs <= 256 and occ >= 2, rows[name]
+        body = asm[asm.index("\n" + name + ":"):]
+        body = body[: body.index("s_endpgm")]
+        assert "scratch_" not in body
+        # the steady-state loop: the basic block with the back edge that holds a K-step's MFMAs and one barrier
+        blocks = re.split(r"\n\.LBB\d+_\d+:", body)
+        loops = [b for b in blocks if b.count("v_mfma_f32_32x32x16_f16") == n_mfma and b.count("s_barrier") == 1 and b.count("global_load_lds_dwordx4") == n_dma]
+        assert loops, (name, [(b.count("v_mfma"), b.count("s_barrier"), b.count("global_load_lds_dwordx4")) for b in blocks])
+        for b in loops:
+            waits = re.findall(r"s_waitcnt lgkmcnt\((\d+)\)", b)
+            assert waits.count("0") == 1 and len(waits) >= 3 and max(int(w) for w in waits) >= 2, (name, waits)   # the one lgkmcnt(0) stands in front of the barrier
+            bar = b.index("s_barrier")
+            assert b.rfind("s_waitcnt lgkmcnt(0)", 0, bar) > 0
+            first_mfma = b.index("v_mfma_f32_32x32x16_f16", bar)
+            assert "s_waitcnt lgkmcnt" not in b[bar:first_mfma], (name, b[bar:first_mfma])
+            assert re.search(r"s_waitcnt vmcnt\(%d\)" % vm, b[:bar]), name
