@@ -149,27 +149,27 @@ __global__ __launch_bounds__(256) void k_normalize_tlv(DevCfg cfg, const uint8_t
 }
 
 // ---------------------------------------------------------------------------
-__device__ inline int eligible_tracks(const DevCfg &cfg, const DevState &st, int s)
+// eligible tracks per scene (Tracking.py:721): a WAVE per scene, a lane per track of its list (t_cap <= 64) -- the records are scattered, so a
+// thread per scene walked up to t_cap dependent round trips (19 us at 4096 x 8 tracks; as a loop inside the single scan workgroup below it
+// had been 170 of the scan's 185 us); here every record of a scene is requested at once
+__global__ __launch_bounds__(256) void k_feat_count(DevCfg cfg, DevState st, int32_t *__restrict__ row_off /*[S+1]*/)
 {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= cfg.n_scenes) return;   // (wave-uniform)
     const SceneHdr *hdr = st.hdr + s;
     const int32_t *order = st.order + (size_t)s * cfg.t_cap;
     const TrackRec *trk = st.trk + (size_t)s * cfg.t_cap;
-    int c = 0;
-    for (int j = 0; j < hdr->n_tracks; j++) {
-        const TrackRec *rec = trk + order[j];
+    bool elig = false;
+    if (lane < hdr->n_tracks) {
+        const TrackRec *rec = trk + order[lane];
+        const int rl = rec->ring_len;
         int total = 0;
-        for (int k = 0; k < rec->ring_len; k++) total += rec->ring_n[k];
-        c += total > cfg.model_min_input ? 1 : 0;  // Tracking.py:721
+#pragma unroll
+        for (int k = 0; k < MMW_RING_MAX; k++) total += k < rl ? rec->ring_n[k] : 0;
+        elig = total > cfg.model_min_input;
     }
-    return c;
-}
-
-// eligible tracks per scene, one thread per scene over the whole chip (the records are scattered: as a loop inside
-// the single scan workgroup below this was 170 of the scan's 185 us)
-__global__ __launch_bounds__(256) void k_feat_count(DevCfg cfg, DevState st, int32_t *__restrict__ row_off /*[S+1]*/)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < cfg.n_scenes) row_off[s] = eligible_tracks(cfg, st, s);
+    const int c = __popcll(__ballot(elig));
+    if (lane == 0) row_off[s] = c;
 }
 
 // single workgroup: in-place exclusive scan of the counts; row_off[S] = total
@@ -495,7 +495,7 @@ void launch_normalize_tlv(const DevCfg &cfg, const uint8_t *packets, long long p
 }
 void launch_feat_scan(const DevCfg &cfg, const DevState &s, int32_t *row_off, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_feat_count, dim3((cfg.n_scenes + 255) / 256), dim3(256), 0, st, cfg, s, row_off);
+    hipLaunchKernelGGL(k_feat_count, dim3((cfg.n_scenes + 3) / 4), dim3(256), 0, st, cfg, s, row_off);
     hipLaunchKernelGGL(k_feat_scan, dim3(1), dim3(1024), 0, st, cfg, row_off);
 }
 void launch_features(const DevCfg &cfg, const DevState &s, const int32_t *row_off, float *feat, int32_t *owner, int32_t *uid, int cap,
