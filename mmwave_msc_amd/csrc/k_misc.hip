@@ -194,23 +194,51 @@ __global__ __launch_bounds__(1024) void k_feat_scan(DevCfg cfg, int32_t *__restr
     if (tid == 1023) row_off[S] = part[1023];
 }
 
+// lane ^ J of a 32-bit value without the LDS crossbar where the hardware allows it: DPP inside quads (J = 1, 2) and inside rows of 16
+// (J = 4, 8: the two row shifts, picked by the lane's bit J); ds_bpermute for 16 and 32 (mmw_cloud.hpp's xor_lane_d, for ints)
+template <int J>
+__device__ __forceinline__ int xor_lane_i(int v)
+{
+    if constexpr (J == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 4 || J == 8) {
+        const int up = __builtin_amdgcn_update_dpp(0, v, 0x100 + J, 0xF, 0xF, true), dn = __builtin_amdgcn_update_dpp(0, v, 0x110 + J, 0xF, 0xF, true);   // row_shl: lane i <- i + J; row_shr: i - J
+        return (__lane_id() & J) ? dn : up;
+    } else return __shfl_xor(v, J);
+}
+// one compare-exchange step of the bitonic network on (key, row): block size SZ, partner lane ^ STRIDE
+template <int SZ, int STRIDE>
+__device__ __forceinline__ void bitonic_step(int lane, double &key, int &src)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(key);
+    const int olo = xor_lane_i<STRIDE>((int)(unsigned)u), ohi = xor_lane_i<STRIDE>((int)(unsigned)(u >> 32)), os = xor_lane_i<STRIDE>(src);
+    const double ok = __longlong_as_double((long long)(((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo));
+    const bool up = (lane & SZ) == 0;          // ascending block
+    const bool lower = (lane & STRIDE) == 0;   // this lane keeps the smaller of the pair
+    const bool other_less = ok < key || (ok == key && os < src);
+    const bool take = (up == lower) ? other_less : !other_less;
+    if (take) { key = ok; src = os; }
+}
+template <int SZ, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(int lane, double &key, int &src)
+{
+    bitonic_step<SZ, STRIDE>(lane, key, src);
+    if constexpr (STRIDE > 1) bitonic_merge<SZ, STRIDE / 2>(lane, key, src);
+}
+
 // np.argsort(padded[:, 0]) (Utils.py:513) + the gather it drives: a bitonic network over
-// the wave on (x, row) -- ties ordered by row position -- then 5 fp32 stores per lane.
+// the wave on (x, row) -- ties ordered by row position -- then 5 fp32 stores per lane.  18 of its 21 steps exchange by DPP (partners inside a row of
+// 16 lanes); with every step three trips through the LDS crossbar the kernel was a chain of ds_bpermute latencies (118 us at 98 k sorts).
 __device__ inline void sort_rows_store(int lane, double v0, double v1, double v2, double v3, double v4, float *dst)
 {
     double key = v0;
     int src = lane;
-    for (int sz = 2; sz <= 64; sz <<= 1) {
-        for (int stride = sz >> 1; stride > 0; stride >>= 1) {
-            const double ok = __shfl_xor(key, stride);
-            const int os = __shfl_xor(src, stride);
-            const bool up = (lane & sz) == 0;          // ascending block
-            const bool lower = (lane & stride) == 0;   // this lane keeps the smaller of the pair
-            const bool other_less = ok < key || (ok == key && os < src);
-            const bool take = (up == lower) ? other_less : !other_less;
-            if (take) { key = ok; src = os; }
-        }
-    }
+    bitonic_merge<2, 1>(lane, key, src);
+    bitonic_merge<4, 2>(lane, key, src);
+    bitonic_merge<8, 4>(lane, key, src);
+    bitonic_merge<16, 8>(lane, key, src);
+    bitonic_merge<32, 16>(lane, key, src);
+    bitonic_merge<64, 32>(lane, key, src);
     const double s0 = __shfl(v0, src), s1 = __shfl(v1, src), s2 = __shfl(v2, src), s3 = __shfl(v3, src), s4 = __shfl(v4, src);
     // a lane's five values are 20 consecutive bytes: one 16-byte and one 4-byte store (4-byte aligned: global memory takes that)
     struct __attribute__((packed, aligned(4))) F4 { float a, b, c, d; };
@@ -260,7 +288,7 @@ __global__ __launch_bounds__(256) void k_features(DevCfg cfg, DevState st, const
     }
     const int ne = __popcll(um);
     if (total_out && tid == 0) *total_out = ne;
-    for (int item = wave; item < ne * ring; item += 4) {   // (uniform per wave)
+    for (int item = wave; item < ne * ring; item += 4) {   // (uniform per wave; the next item's rows requested ahead of this item's sort: 135 us against 106 -- registers)
         const int i = item / ring, k = item - i * ring;
         unsigned long long m = um;
         for (int t = 0; t < i; t++) m &= m - 1ULL;
